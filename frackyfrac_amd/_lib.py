@@ -1,0 +1,120 @@
+"""ctypes binding of libfrackyfrac_amd.so (C ABI: include/frackyfrac_amd.h).
+
+The library is built in-tree by `make -C frackyfrac_amd/csrc` (or
+`__graft_entry__.build()`) into frackyfrac_amd/lib/.  There is no Python or CPU
+fallback: if the library is missing, importing the compute API raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfrackyfrac_amd.so")
+FRCFRC_PATH = os.path.join(_HERE, "lib", "frcfrc")
+
+FF_OK = 0
+FF_ERR_ARG, FF_ERR_PARSE, FF_ERR_SPECIES, FF_ERR_DEVICE, FF_ERR_IO, FF_ERR_INTERNAL = 1, 2, 3, 4, 5, 6
+PRECISION_AUTO, PRECISION_FIXED32, PRECISION_EXACT64 = 0, 1, 2
+PRECISION_NAMES = {"auto": 0, "fixed32": 1, "exact64": 2}
+
+
+class FFError(RuntimeError):
+    """A non-zero ff_status; .code is the status, str(e) the library's message
+    (the text the reference would print after "ERROR: ")."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+class ff_problem(ctypes.Structure):
+    _fields_ = [("n_samples", c_int64), ("n_branches", c_int64), ("branch_len", c_void_p),
+                ("indptr", c_void_p), ("branch_id", c_void_p), ("abnd", c_void_p)]
+
+
+class ff_options(ctypes.Structure):
+    _fields_ = [("weighted", c_int32), ("precision", c_int32), ("device", c_int32),
+                ("rank", c_int32), ("world", c_int32), ("reserved", c_int32 * 3)]
+
+
+class ff_plan_info(ctypes.Structure):
+    _fields_ = [("precision", c_int32), ("scale_log2", c_int32), ("lengths_exact", c_int32),
+                ("n_compute_units", c_int32), ("n_samples", c_int64), ("n_branches", c_int64),
+                ("ld", c_int64), ("rows_padded", c_int64), ("row_begin", c_int64),
+                ("row_end", c_int64), ("slot_begin", c_int64), ("slot_end", c_int64),
+                ("n_tiles", c_int64), ("n_items", c_int64), ("n_wave_slots", c_int64),
+                ("staged_bytes", c_double), ("elements", c_double)]
+
+
+# name -> (restype, argtypes); exactly the symbols include/frackyfrac_amd.h declares
+SIGNATURES = {
+    "ff_options_default": (None, [POINTER(ff_options)]),
+    "ff_num_pairs": (c_int64, [c_int64]),
+    "ff_shard_rows": (c_int, [c_int64, c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "ff_unifrac_dists": (c_int, [POINTER(ff_problem), POINTER(ff_options), c_void_p, c_char_p, c_size_t]),
+    "ff_plan_create": (c_int, [POINTER(ff_problem), POINTER(ff_options), POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_plan_destroy": (None, [c_void_p]),
+    "ff_plan_info_get": (c_int, [c_void_p, POINTER(ff_plan_info)]),
+    "ff_plan_run": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),
+    "ff_plan_run_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),
+    "ff_plan_last_kernel_ms": (c_double, [c_void_p]),
+    "ff_tree_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_tree_read_file": (c_int, [c_char_p, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_tree_free": (None, [c_void_p]),
+    "ff_tree_num_nodes": (c_int64, [c_void_p]),
+    "ff_tree_branch_len": (c_void_p, [c_void_p]),
+    "ff_tree_parent": (c_void_p, [c_void_p]),
+    "ff_tree_subtree_size": (c_void_p, [c_void_p]),
+    "ff_tree_name": (c_char_p, [c_void_p, c_int64]),
+    "ff_table_parse_dense": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_table_parse_sparse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_table_read_file": (c_int, [c_char_p, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_table_free": (None, [c_void_p]),
+    "ff_table_num_samples": (c_int64, [c_void_p]),
+    "ff_table_sample_size": (c_int64, [c_void_p, c_int64]),
+    "ff_table_sample_entry": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_char_p), POINTER(c_double)]),
+    "ff_validate_species": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
+    "ff_flatten": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_flatten_leaf_csr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                    POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_flat_free": (None, [c_void_p]),
+    "ff_flat_problem": (None, [c_void_p, POINTER(ff_problem)]),
+    "ff_unifrac": (c_int, [c_void_p, c_void_p, POINTER(ff_options), c_int, c_void_p, c_char_p, c_size_t]),
+    "ff_format_float": (c_int, [c_double, c_char_p]),
+    "ff_write_distances": (c_int, [c_char_p, c_void_p, c_int64, c_int, c_char_p, c_size_t]),
+    "ff_frcfrc_main": (c_int, [c_int, POINTER(c_char_p)]),
+    "ff_version": (c_char_p, []),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Loads the in-tree shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "frackyfrac_amd: %s not found. Build it with `make -C frackyfrac_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+ERRLEN = 1024
+
+
+def errbuf():
+    return ctypes.create_string_buffer(ERRLEN)
+
+
+def check(rc: int, err) -> None:
+    if rc != FF_OK:
+        raise FFError(rc, err.value.decode("utf-8", "replace"))

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's interface for the UniFrac path.
+
+Names follow frackyfrac: `unifrac` (frcfrc/unifrac.go:97), `unifrac_dists`
+(unifracDists, unifrac.go:209), `parse_abundance` / `parse_sparse_abundance`
+(parser/parser.go:21,85), `validate_species` (unifrac.go:80), `iter_pairs`
+(common.IterPairs, common/common.go:21).  Everything here is a thin ctypes layer
+over the C ABI (include/frackyfrac_amd.h); the arithmetic happens in the HIP
+kernels of frackyfrac_amd/csrc/ff_device.hip.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import FFError, ff_options, ff_plan_info, ff_problem
+
+
+def _opts(weighted: bool, precision="auto", device: int = -1, rank: int = 0, world: int = 1) -> ff_options:
+    o = ff_options()
+    L.lib().ff_options_default(ctypes.byref(o))
+    o.weighted = 1 if weighted else 0
+    o.precision = L.PRECISION_NAMES[precision] if isinstance(precision, str) else int(precision)
+    o.device = device
+    o.rank = rank
+    o.world = world
+    return o
+
+
+def num_pairs(n: int) -> int:
+    return int(L.lib().ff_num_pairs(n))
+
+
+def iter_pairs(n: int) -> Iterator[Tuple[int, int]]:
+    """common.IterPairs as index pairs: (i, j) for i in 0..n-1, j in 0..i-1."""
+    for i in range(n):
+        for j in range(i):
+            yield i, j
+
+
+def shard_rows(n: int, rank: int, world: int) -> Tuple[int, int]:
+    rb, re = ctypes.c_int64(), ctypes.c_int64()
+    rc = L.lib().ff_shard_rows(n, rank, world, ctypes.byref(rb), ctypes.byref(re))
+    if rc:
+        raise FFError(rc, "bad shard %d of %d" % (rank, world))
+    return rb.value, re.value
+
+
+def shard_slots(n: int, rank: int, world: int) -> Tuple[int, int]:
+    rb, re = shard_rows(n, rank, world)
+    return rb * (rb - 1) // 2 if rb else 0, re * (re - 1) // 2 if re else 0
+
+
+class Tree:
+    """newick.Node tree flattened in enumerateNodes' pre-order numbering."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def parse(cls, text: str) -> "Tree":
+        data = text.encode("utf-8")
+        h, err = ctypes.c_void_p(), L.errbuf()
+        L.check(L.lib().ff_tree_parse(data, len(data), ctypes.byref(h), err, L.ERRLEN), err)
+        return cls(h)
+
+    @classmethod
+    def read_file(cls, path: str) -> "Tree":
+        h, err = ctypes.c_void_p(), L.errbuf()
+        L.check(L.lib().ff_tree_read_file(path.encode(), ctypes.byref(h), err, L.ERRLEN), err)
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            L.lib().ff_tree_free(self._h)
+            self._h = None
+
+    @property
+    def n(self) -> int:
+        return int(L.lib().ff_tree_num_nodes(self._h))
+
+    def _arr(self, fn, dtype) -> np.ndarray:
+        n = self.n
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        ptr = fn(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dtype))),
+                                     shape=(n,)).copy()
+
+    @property
+    def branch_len(self) -> np.ndarray:
+        return self._arr(L.lib().ff_tree_branch_len, np.float64)
+
+    @property
+    def parent(self) -> np.ndarray:
+        return self._arr(L.lib().ff_tree_parent, np.int64)
+
+    @property
+    def subtree_size(self) -> np.ndarray:
+        return self._arr(L.lib().ff_tree_subtree_size, np.int64)
+
+    @property
+    def names(self) -> List[str]:
+        f = L.lib().ff_tree_name
+        return [f(self._h, k).decode("utf-8") for k in range(self.n)]
+
+
+class Table:
+    """[]map[string]float64 as the loaders return it."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def _parse(cls, fn, text: str) -> "Table":
+        data = text.encode("utf-8")
+        h, err = ctypes.c_void_p(), L.errbuf()
+        L.check(fn(data, len(data), ctypes.byref(h), err, L.ERRLEN), err)
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            L.lib().ff_table_free(self._h)
+            self._h = None
+
+    def __len__(self) -> int:
+        return int(L.lib().ff_table_num_samples(self._h))
+
+    def to_maps(self) -> List[Dict[str, float]]:
+        out = []
+        lib = L.lib()
+        name, val = ctypes.c_char_p(), ctypes.c_double()
+        for s in range(len(self)):
+            m = {}
+            for k in range(lib.ff_table_sample_size(self._h, s)):
+                lib.ff_table_sample_entry(self._h, s, k, ctypes.byref(name), ctypes.byref(val))
+                m[name.value.decode("utf-8")] = val.value
+            out.append(m)
+        return out
+
+
+def parse_abundance(text: str) -> Table:
+    """parser.ParseAbundance (parser/parser.go:21)."""
+    return Table._parse(L.lib().ff_table_parse_dense, text)
+
+
+def parse_sparse_abundance(text: str) -> Table:
+    """parser.ParseSparseAbundance (parser/parser.go:85)."""
+    return Table._parse(L.lib().ff_table_parse_sparse, text)
+
+
+def parse_newick(text: str) -> Tree:
+    return Tree.parse(text)
+
+
+def validate_species(table: Table, tree: Tree) -> None:
+    """validateSpecies (frcfrc/unifrac.go:80-93); raises FFError with its message."""
+    err = L.errbuf()
+    L.check(L.lib().ff_validate_species(table._h, tree._h, err, L.ERRLEN), err)
+
+
+class FlatNodes:
+    """Stage-A output: the [][]flatNode of unifrac.go:99-116 as CSR, plus treeDists."""
+
+    def __init__(self, indptr, branch_id, abnd, branch_len):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.branch_id = np.ascontiguousarray(branch_id, dtype=np.int32)
+        self.abnd = np.ascontiguousarray(abnd, dtype=np.float64)
+        self.branch_len = np.ascontiguousarray(branch_len, dtype=np.float64)
+
+    @property
+    def n_samples(self) -> int:
+        return len(self.indptr) - 1
+
+    @property
+    def n_branches(self) -> int:
+        return len(self.branch_len)
+
+    def problem(self) -> ff_problem:
+        p = ff_problem()
+        p.n_samples = self.n_samples
+        p.n_branches = self.n_branches
+        p.branch_len = self.branch_len.ctypes.data
+        p.indptr = self.indptr.ctypes.data
+        p.branch_id = self.branch_id.ctypes.data
+        p.abnd = self.abnd.ctypes.data
+        return p
+
+    @classmethod
+    def _from_handle(cls, h) -> "FlatNodes":
+        p = ff_problem()
+        L.lib().ff_flat_problem(h, ctypes.byref(p))
+        n, b = p.n_samples, p.n_branches
+
+        def arr(ptr, ct, count):
+            if count == 0:
+                return np.zeros(0, dtype=ct)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(ct))),
+                                         shape=(count,)).copy()
+
+        indptr = arr(p.indptr, np.int64, n + 1)
+        nnz = int(indptr[-1]) if n >= 0 and len(indptr) else 0
+        out = cls(indptr, arr(p.branch_id, np.int32, nnz), arr(p.abnd, np.float64, nnz),
+                  arr(p.branch_len, np.float64, b))
+        L.lib().ff_flat_free(h)
+        return out
+
+
+def flatten(table: Table, tree: Tree, leave_unnormalized: bool = False) -> FlatNodes:
+    """Stage A (unifrac.go:32-67,99-116) on the host."""
+    h, err = ctypes.c_void_p(), L.errbuf()
+    L.check(L.lib().ff_flatten(table._h, tree._h, 1 if leave_unnormalized else 0, ctypes.byref(h), err, L.ERRLEN), err)
+    return FlatNodes._from_handle(h)
+
+
+def flatten_leaf_csr(tree: Tree, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized: bool = False) -> FlatNodes:
+    leaf_ptr = np.ascontiguousarray(leaf_ptr, dtype=np.int64)
+    leaf_idx = np.ascontiguousarray(leaf_idx, dtype=np.int64)
+    leaf_val = np.ascontiguousarray(leaf_val, dtype=np.float64)
+    h, err = ctypes.c_void_p(), L.errbuf()
+    L.check(L.lib().ff_flatten_leaf_csr(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data, leaf_idx.ctypes.data,
+                                        leaf_val.ctypes.data, 1 if leave_unnormalized else 0,
+                                        ctypes.byref(h), err, L.ERRLEN), err)
+    return FlatNodes._from_handle(h)
+
+
+def unifrac_dists(nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1,
+                  rank: int = 0, world: int = 1, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """unifracDists (frcfrc/unifrac.go:209): all pair distances of this shard in
+    IterPairs order, computed on the GPU.  Returns the full-length array; slots
+    outside the shard keep NaN (or the contents of `out`)."""
+    n = nodes.n_samples
+    if out is None:
+        out = np.full(num_pairs(n), np.nan, dtype=np.float64)
+    p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+    L.check(L.lib().ff_unifrac_dists(ctypes.byref(p), ctypes.byref(o), out.ctypes.data, err, L.ERRLEN), err)
+    return out
+
+
+def unifrac(table: Table, tree: Tree, weighted: bool, leave_unnormalized: bool = False,
+            precision="auto", device: int = -1) -> np.ndarray:
+    """unifrac (frcfrc/unifrac.go:97): flatten on the host, distances on the GPU."""
+    out = np.full(num_pairs(len(table)), np.nan, dtype=np.float64)
+    o, err = _opts(weighted, precision, device), L.errbuf()
+    L.check(L.lib().ff_unifrac(table._h, tree._h, ctypes.byref(o), 1 if leave_unnormalized else 0,
+                               out.ctypes.data, err, L.ERRLEN), err)
+    return out
+
+
+class Plan:
+    """Staged inputs resident in HBM + tile schedule (ff_plan)."""
+
+    def __init__(self, nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1,
+                 rank: int = 0, world: int = 1):
+        p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+        self._h = ctypes.c_void_p()
+        L.check(L.lib().ff_plan_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(self._h), err, L.ERRLEN), err)
+        self.info = ff_plan_info()
+        L.lib().ff_plan_info_get(self._h, ctypes.byref(self.info))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().ff_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def n_slots(self) -> int:
+        return int(self.info.slot_end - self.info.slot_begin)
+
+    def run(self, d_out_ptr: int, stream: int = 0, timed: bool = False) -> None:
+        """One pass of the hot path; d_out_ptr is a device pointer to n_slots doubles,
+        stream a hipStream_t handle (0 = null stream).  Asynchronous."""
+        err = L.errbuf()
+        fn = L.lib().ff_plan_run_timed if timed else L.lib().ff_plan_run
+        L.check(fn(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(d_out_ptr), err, L.ERRLEN), err)
+
+    def last_kernel_ms(self) -> float:
+        return float(L.lib().ff_plan_last_kernel_ms(self._h))
+
+
+def format_float(f: float) -> str:
+    """fmt.Fprintln's rendering of a float64, without the newline."""
+    buf = ctypes.create_string_buffer(40)
+    n = L.lib().ff_format_float(float(f), buf)
+    return buf.raw[:n].decode("ascii")
+
+
+def write_distances(path: Optional[str], d: np.ndarray, threads: int = 1) -> None:
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    err = L.errbuf()
+    L.check(L.lib().ff_write_distances(path.encode() if path else None, d.ctypes.data, len(d), threads, err, L.ERRLEN), err)
+
+
+def frcfrc_main(argv: List[str]) -> int:
+    """The whole `frcfrc` command in-process; argv[0] is the program name."""
+    arr = (ctypes.c_char_p * len(argv))(*[a.encode() for a in argv])
+    return int(L.lib().ff_frcfrc_main(len(argv), arr))

@@ -1,0 +1,243 @@
+// ff_cli.cpp -- the `frcfrc` command (frcfrc/frcfrc.go:29-125) on top of the C ABI.
+//
+// Same flags as the reference (frcfrc.go:18-27): -i -o -t -w -s -p -l, parsed with
+// the conventions of Go's flag package (-x, --x, -x=v, "-x v" for non-booleans,
+// parsing stops at the first non-flag or "--"), the same validation messages
+// (frcfrc.go:78-86), the same stderr phase lines and the same output: one
+// distance per line in IterPairs order, formatted like fmt.Fprintln (frcfrc.go:58-62).
+// Errors print "ERROR: <msg>" and exit 2 (common/common.go:13-18).
+// Extensions (not in the reference): -precision auto|fixed32|exact64, -stats.
+#include <chrono>
+#include <cstdlib>
+
+#include "ff_host.hpp"
+
+namespace {
+
+const char *USAGE =
+    "FrackyFrac calculates UniFrac on the given abundance table.\n"
+    "Outputs one distance per line in the order (1,2),(1,3),(2,3)...(1,n)...(n-1,n).\n"
+    "\n"
+    "Params:\n";
+
+void usage()
+{
+    fputs(USAGE, stderr);
+    // flag.PrintDefaults(): flags in lexical order
+    fputs("  -i string\n    \tPath to input file (default stdin)\n", stderr);
+    fputs("  -l\tLeave abundance values unnormalized (default normalize each sample to sum up to 1)\n", stderr);
+    fputs("  -o string\n    \tPath to output file (default stdout)\n", stderr);
+    fputs("  -p int\n    \tNumber of threads (default 1)\n", stderr);
+    fputs("  -precision string\n    \tDevice arithmetic: auto, fixed32 or exact64 (default \"auto\")\n", stderr);
+    fputs("  -s\tInput is in sparse format\n", stderr);
+    fputs("  -stats\n    \tPrint device statistics to stderr\n", stderr);
+    fputs("  -t string\n    \tPath to tree file, required\n", stderr);
+    fputs("  -w\tUse weighted UniFrac (default unweighted)\n", stderr);
+}
+
+int die(const char *msg)
+{
+    fprintf(stderr, "ERROR: %s\n", msg);  // common.ExitIfError
+    return 2;
+}
+
+struct Flags {
+    std::string in, out, tree, precision = "auto";
+    bool weighted = false, sparse = false, nnorm = false, stats = false;
+    long nt = 1;
+};
+
+bool parse_bool(const std::string &v, bool *out)
+{
+    static const char *T[] = {"1", "t", "T", "true", "TRUE", "True"};
+    static const char *F[] = {"0", "f", "F", "false", "FALSE", "False"};
+    for (auto s : T)
+        if (v == s) {
+            *out = true;
+            return true;
+        }
+    for (auto s : F)
+        if (v == s) {
+            *out = false;
+            return true;
+        }
+    return false;
+}
+
+// Returns -1 to continue, otherwise an exit code.
+int parse_flags(int argc, char **argv, Flags *f)
+{
+    for (int a = 1; a < argc; ++a) {
+        std::string s = argv[a];
+        if (s.size() < 2 || s[0] != '-') break;  // first non-flag ends parsing
+        size_t dashes = 1;
+        if (s[1] == '-') {
+            dashes = 2;
+            if (s.size() == 2) break;  // "--"
+        }
+        std::string name = s.substr(dashes), value;
+        bool has_value = false;
+        size_t eq = name.find('=');
+        if (eq != std::string::npos) {
+            value = name.substr(eq + 1);
+            name = name.substr(0, eq);
+            has_value = true;
+        }
+        if (name.empty() || name[0] == '-' || name[0] == '=') {
+            fprintf(stderr, "bad flag syntax: %s\n", s.c_str());
+            usage();
+            return 2;
+        }
+        bool *bp = name == "w" ? &f->weighted : name == "s" ? &f->sparse : name == "l" ? &f->nnorm
+                   : name == "stats" ? &f->stats : nullptr;
+        if (bp) {
+            if (has_value) {
+                if (!parse_bool(value, bp)) {
+                    fprintf(stderr, "invalid boolean value %s for -%s: parse error\n", ff::go_quote(value).c_str(), name.c_str());
+                    usage();
+                    return 2;
+                }
+            } else {
+                *bp = true;
+            }
+            continue;
+        }
+        if (name == "h" || name == "help") {
+            usage();
+            return 0;
+        }
+        std::string *sp = name == "i" ? &f->in : name == "o" ? &f->out : name == "t" ? &f->tree
+                          : name == "precision" ? &f->precision : nullptr;
+        if (!sp && name != "p") {
+            fprintf(stderr, "flag provided but not defined: -%s\n", name.c_str());
+            usage();
+            return 2;
+        }
+        if (!has_value) {
+            if (a + 1 >= argc) {
+                fprintf(stderr, "flag needs an argument: -%s\n", name.c_str());
+                usage();
+                return 2;
+            }
+            value = argv[++a];
+        }
+        if (sp) {
+            *sp = value;
+        } else {
+            char *end = nullptr;
+            errno = 0;
+            long v = strtol(value.c_str(), &end, 0);
+            if (value.empty() || *end || errno) {
+                fprintf(stderr, "invalid value %s for flag -p: parse error\n", ff::go_quote(value).c_str());
+                usage();
+                return 2;
+            }
+            f->nt = v;
+        }
+    }
+    return -1;
+}
+
+std::string go_duration(double sec)
+{
+    char b[64];
+    if (sec < 1e-6) snprintf(b, sizeof b, "%.0fns", sec * 1e9);
+    else if (sec < 1e-3) snprintf(b, sizeof b, "%.3fµs", sec * 1e6);
+    else if (sec < 1) snprintf(b, sizeof b, "%.6fms", sec * 1e3);
+    else if (sec < 60) snprintf(b, sizeof b, "%.9fs", sec);
+    else {
+        long m = (long)(sec / 60);
+        double s = sec - 60.0 * (double)m;
+        if (m >= 60) snprintf(b, sizeof b, "%ldh%ldm%.9fs", m / 60, m % 60, s);
+        else snprintf(b, sizeof b, "%ldm%.9fs", m, s);
+    }
+    return b;
+}
+
+}  // namespace
+
+extern "C" int ff_frcfrc_main(int argc, char **argv)
+{
+    if (argc <= 1) {  // frcfrc.go:71-74
+        usage();
+        return 0;
+    }
+    Flags f;
+    int rc = parse_flags(argc, argv, &f);
+    if (rc >= 0) return rc;
+    if (f.tree.empty()) return die("please provide a tree file with -t");  // frcfrc.go:78-80
+    if (f.nt < 1) {                                                         // :81-83
+        char m[64];
+        snprintf(m, sizeof m, "bad number of threads: %ld", f.nt);
+        return die(m);
+    }
+    if (f.nnorm && !f.weighted) return die("-l can only be used with weighted unifrac");  // :84-86
+    ff_options opt;
+    ff_options_default(&opt);
+    opt.weighted = f.weighted;
+    if (f.precision == "auto") opt.precision = FF_PRECISION_AUTO;
+    else if (f.precision == "fixed32") opt.precision = FF_PRECISION_FIXED32;
+    else if (f.precision == "exact64") opt.precision = FF_PRECISION_EXACT64;
+    else return die("bad -precision: want auto, fixed32 or exact64");
+
+    char err[1024];
+    auto t0 = std::chrono::steady_clock::now();
+    fputs("Reading tree\n", stderr);
+    ff_tree *tree = nullptr;
+    if (ff_tree_read_file(f.tree.c_str(), &tree, err, sizeof err)) return die(err);
+
+    fputs("Loading abundances\n", stderr);
+    ff_table *table = nullptr;
+    if (ff_table_read_file(f.in.empty() ? nullptr : f.in.c_str(), f.sparse, &table, err, sizeof err)) {
+        ff_tree_free(tree);
+        return die(err);
+    }
+
+    fputs("Validating\n", stderr);
+    if (ff_validate_species(table, tree, err, sizeof err)) {
+        ff_table_free(table);
+        ff_tree_free(tree);
+        return die(err);
+    }
+
+    fputs("Converting abundances\n", stderr);  // unifrac.go:101
+    ff_flat *flat = nullptr;
+    if (ff_flatten(table, tree, f.nnorm, &flat, err, sizeof err)) {
+        ff_table_free(table);
+        ff_tree_free(tree);
+        return die(err);
+    }
+    const int64_t n = ff_table_num_samples(table);
+    ff_table_free(table);
+    ff_tree_free(tree);
+
+    fputs("Calculating distances\n", stderr);  // unifrac.go:122
+    ff_problem p;
+    ff_flat_problem(flat, &p);
+    std::vector<double> out((size_t)ff_num_pairs(n));
+    ff_plan *plan = nullptr;
+    ff_plan_info info{};
+    rc = ff_plan_create(&p, &opt, &plan, err, sizeof err);
+    if (rc == FF_OK) {
+        ff_plan_info_get(plan, &info);
+        ff_plan_destroy(plan);
+        rc = ff_unifrac_dists(&p, &opt, out.data(), err, sizeof err);
+    }
+    ff_flat_free(flat);
+    if (rc) return die(err);
+    if (f.stats)
+        fprintf(stderr,
+                "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"tiles\": %lld, "
+                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f}\n",
+                info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
+                info.lengths_exact, (long long)info.n_tiles, (long long)info.n_items,
+                (long long)info.n_wave_slots, info.staged_bytes);
+
+    if (ff_write_distances(f.out.empty() ? nullptr : f.out.c_str(), out.data(), (int64_t)out.size(), (int)f.nt, err,
+                           sizeof err))
+        return die(err);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "Took %s\n", go_duration(sec).c_str());
+    fputs("Done\n", stderr);
+    return 0;
+}

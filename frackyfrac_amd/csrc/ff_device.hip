@@ -1,0 +1,837 @@
+// ff_device.hip -- stage B of the UniFrac path on gfx950 (MI355X): staging of the
+// flat-node vectors into a dense branch-major matrix in HBM, the pair-tile
+// reduction kernels, and the plan/run C ABI around them.
+//
+// Replaces the per-pair merge walks unifracDistWeighted / unifracDistUnweighted
+// (frcfrc/unifrac.go:144-205) and their driver unifracDists (unifrac.go:209-228).
+// See DESIGN.md for the derivation; in short, with q_s(b) the staged value of
+// sample s on branch b (0 where the sample has no flat node):
+//
+//   FIXED32  q_s(b) = round(l_b * abnd_s(b) * 2^e)   (weighted)
+//            q_s(b) = round(l_b * 2^e) * [present]   (unweighted)
+//            U(i,j) = sum_b |q_i(b) - q_j(b)|        one v_sad_u32 per term, exact
+//            weighted   d = U / (W_i + W_j),                  W_s = sum_b q_s(b)
+//            unweighted d = U / (U + C),  C = (W_i + W_j - U) / 2
+//   EXACT64  binary64 running sums over b ascending, with the reference's own
+//            operations (no contraction), so every rounding is the reference's.
+//
+// Layout: QT[b][s], row = branch (pre-order id), column = sample, so that the 64
+// lanes of a wave read 64 consecutive samples of one branch (coalesced) while the
+// other side of the pair tile -- 32 samples of the same branch -- arrives through
+// the scalar cache as SGPR operands.  No LDS, no cross-lane traffic.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ff_host.hpp"
+
+// ----------------------------------------------------------------------------
+// Geometry
+// ----------------------------------------------------------------------------
+namespace {
+
+constexpr int TILE_I = 32;    // rows of a wave's pair tile: samples held in SGPRs
+constexpr int TILE_J = 128;   // columns: 2 per lane
+constexpr int KSTEP = 8;      // branch rows per unrolled iteration = vector prefetch ring
+constexpr int SLACK_ROWS = 16;  // zero rows past the matrix, read by the prefetch
+constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
+constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
+constexpr int X_TILE_J = 64;
+
+struct Item {        // one unit of work for a persistent wave: a pair tile over a
+    int32_t i0, j0;  // branch range [k0, k1) (multiples of KSTEP)
+    int32_t k0, k1;
+    uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
+    int32_t pad[3];
+};
+static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
+
+struct XTile {
+    int32_t i0, j0;
+};
+
+// ----------------------------------------------------------------------------
+// Device code
+// ----------------------------------------------------------------------------
+
+// D = |a - b| + c on 32-bit unsigned integers, `a` wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t sad_u32(uint32_t s, uint32_t v, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(acc));
+    return r;
+}
+
+// Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
+__global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
+                                     const int32_t *__restrict__ branch_id,
+                                     const double *__restrict__ abnd,
+                                     const double *__restrict__ branch_len,
+                                     const uint32_t *__restrict__ klen, int weighted, int e,
+                                     uint32_t *__restrict__ QT, int64_t ld)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t b0 = indptr[s], b1 = indptr[s + 1];
+    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x) {
+        const int32_t b = branch_id[t];
+        uint32_t q;
+        if (weighted) {
+            const double x = branch_len[b] * abnd[t];  // treeDists[id] * abnd (unifrac.go:180)
+            q = (uint32_t)(unsigned long long)rint(ldexp(x, e));
+        } else {
+            q = klen[b];
+        }
+        QT[(int64_t)b * ld + s] = q;
+    }
+}
+
+// Stage EXACT64: the abundance itself (weighted) or 1.0 for presence (unweighted).
+__global__ void stage_exact64_kernel(const int64_t *__restrict__ indptr,
+                                     const int32_t *__restrict__ branch_id,
+                                     const double *__restrict__ abnd, int weighted,
+                                     double *__restrict__ DT, int64_t ld)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t b0 = indptr[s], b1 = indptr[s + 1];
+    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x)
+        DT[(int64_t)branch_id[t] * ld + s] = weighted ? abnd[t] : 1.0;
+}
+
+// W_s = sum_b q_s(b): grid (ld/64, row chunks), one column per lane.
+__global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
+                              int64_t rows_per_block, unsigned long long *__restrict__ W)
+{
+    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    unsigned long long acc = 0;
+    for (int64_t r = r0; r < r1; ++r) acc += QT[r * ld + s];
+    if (acc) atomicAdd(&W[s], acc);
+}
+
+// The pair-tile reduction.  Persistent: wave slot w runs items[item_ptr[w] .. item_ptr[w+1]).
+// Per branch row a wave issues 1 coalesced 512-B vector load (2 samples per lane),
+// 2 scalar 64-B loads (32 samples, wave-uniform) and 64 v_sad_u32.
+__global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
+void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
+                     const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
+                     uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                     int64_t slot_begin)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * WAVES_PER_WG + wave;
+    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
+    for (int it = it_begin; it < it_end; ++it) {
+        const Item item = items[it];
+        const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + 2 * lane;
+        const uint32_t *ps = QT + (int64_t)item.k0 * ld + item.i0;
+        uint32_t acc0[TILE_I], acc1[TILE_I];
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) {
+            acc0[r] = 0;
+            acc1[r] = 0;
+        }
+        // vector ring: slot d holds row k+d; prologue fills slots 0..KSTEP-2
+        uint2 vj[KSTEP];
+#pragma unroll
+        for (int d = 0; d < KSTEP - 1; ++d) vj[d] = *(const uint2 *)(pj + (int64_t)d * ld);
+        const uint32_t *pv = pj + (int64_t)(KSTEP - 1) * ld;
+        uint32_t sA[TILE_I], sB[TILE_I];
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
+        const int nk = item.k1 - item.k0;
+        for (int k = 0; k < nk; k += KSTEP) {
+#pragma unroll
+            for (int d = 0; d < KSTEP; d += 2) {
+                // even step: consume sA and ring slot d; fetch the next row's 32
+                // scalars into sB and refill ring slot d-1 (free since last step)
+                acc0[0] = sad_u32(sA[0], vj[d].x, acc0[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    ps += ld;
+#pragma unroll
+                    for (int r = 0; r < TILE_I; ++r) sB[r] = ps[r];
+                    vj[(d + KSTEP - 1) % KSTEP] = *(const uint2 *)pv;
+                    pv += ld;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc1[0] = sad_u32(sA[0], vj[d].y, acc1[0]);
+#pragma unroll
+                for (int r = 1; r < TILE_I; ++r) {
+                    acc0[r] = sad_u32(sA[r], vj[d].x, acc0[r]);
+                    acc1[r] = sad_u32(sA[r], vj[d].y, acc1[r]);
+                }
+                // odd step: roles of sA and sB swapped
+                acc0[0] = sad_u32(sB[0], vj[d + 1].x, acc0[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    ps += ld;
+#pragma unroll
+                    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
+                    vj[d] = *(const uint2 *)pv;
+                    pv += ld;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc1[0] = sad_u32(sB[0], vj[d + 1].y, acc1[0]);
+#pragma unroll
+                for (int r = 1; r < TILE_I; ++r) {
+                    acc0[r] = sad_u32(sB[r], vj[d + 1].x, acc0[r]);
+                    acc1[r] = sad_u32(sB[r], vj[d + 1].y, acc1[r]);
+                }
+            }
+        }
+        // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
+        const int64_t j = item.j0 + 2 * lane;
+        const bool atomic = item.flags & 1u;
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) {
+            const int64_t i = item.i0 + r;
+            if (i < row_begin || i >= row_end) continue;
+            const int64_t base = i * (i - 1) / 2 - slot_begin + j;
+            if (atomic) {
+                if (j < i && acc0[r]) atomicAdd(&num[base], acc0[r]);
+                if (j + 1 < i && acc1[r]) atomicAdd(&num[base + 1], acc1[r]);
+            } else {
+                if (j < i) num[base] = acc0[r];
+                if (j + 1 < i) num[base + 1] = acc1[r];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj)
+{
+    int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
+    while (i * (i - 1) / 2 > k) --i;
+    while ((i + 1) * i / 2 <= k) ++i;
+    *pi = i;
+    *pj = k - i * (i - 1) / 2;
+}
+
+// Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
+__global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
+                                      const unsigned long long *__restrict__ W, int weighted,
+                                      int64_t slot_begin, int64_t n_slots,
+                                      double *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots) return;
+    int64_t i, j;
+    slot_to_pair(slot_begin + t, &i, &j);
+    const unsigned long long u = num[t];
+    const unsigned long long w = W[i] + W[j];
+    double d;
+    if (weighted) {
+        d = (double)u / (double)w;                 // numer / denom
+    } else {
+        const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
+        d = (double)u / (double)(u + common);      // result / (result + common)
+    }
+    out[t] = d;
+}
+
+// EXACT64: each lane owns the pairs (i0..i0+15, j0+lane) and walks every branch in
+// ascending id with the reference's operations.  Compiled with -ffp-contract=off.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256)
+void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
+                         const double *__restrict__ branch_len, int64_t n_branches,
+                         const XTile *__restrict__ tiles, int n_tiles, int64_t row_begin,
+                         int64_t row_end, int64_t slot_begin, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= n_tiles) return;
+    const XTile tile = tiles[t];
+    double a[X_TILE_I], c[X_TILE_I];  // numer/denom, or result/common
+#pragma unroll
+    for (int r = 0; r < X_TILE_I; ++r) {
+        a[r] = 0.0;
+        c[r] = 0.0;
+    }
+    const double *pj = DT + tile.j0 + lane;
+    const double *pi = DT + tile.i0;
+#pragma unroll 2
+    for (int64_t k = 0; k < n_branches; ++k) {
+        const double l = branch_len[k];
+        const double y = pj[k * ld];
+        const double *row = pi + k * ld;
+#pragma unroll
+        for (int r = 0; r < X_TILE_I; ++r) {
+            const double x = row[r];
+            if (WEIGHTED) {
+                a[r] = a[r] + l * fabs(x - y);  // numer += treeDists[id] * |a-b|  (:191)
+                c[r] = c[r] + l * (x + y);      // denom += treeDists[id] * (a+b)  (:192)
+            } else {
+                a[r] = a[r] + l * fabs(x - y);  // result += treeDists[id] iff exactly one present
+                c[r] = c[r] + l * (x * y);      // common += treeDists[id] iff both present
+            }
+        }
+    }
+    const int64_t j = tile.j0 + lane;
+#pragma unroll
+    for (int r = 0; r < X_TILE_I; ++r) {
+        const int64_t i = tile.i0 + r;
+        if (i < row_begin || i >= row_end || j >= i) continue;
+        const double d = WEIGHTED ? a[r] / c[r] : a[r] / (a[r] + c[r]);
+        out[i * (i - 1) / 2 - slot_begin + j] = d;
+    }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------
+// Plan
+// ----------------------------------------------------------------------------
+
+struct ff_plan {
+    ff_plan_info info{};
+    int device = 0;
+    int weighted = 0;
+    // FIXED32
+    uint32_t *d_QT = nullptr;
+    unsigned long long *d_W = nullptr;
+    uint32_t *d_num = nullptr;
+    Item *d_items = nullptr;
+    int32_t *d_item_ptr = nullptr;
+    int n_workgroups = 0;
+    size_t lds_bytes = 0;
+    // EXACT64
+    double *d_DT = nullptr;
+    double *d_len = nullptr;
+    XTile *d_xtiles = nullptr;
+    int n_xtiles = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed_valid = false;
+};
+
+namespace {
+
+#define FF_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: %s failed: %s", #call,           \
+                            hipGetErrorString(e_));                                           \
+    } while (0)
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+int validate_problem(const ff_problem *p, char *err, size_t errlen)
+{
+    if (!p) return ff::fail(FF_ERR_ARG, err, errlen, "null problem");
+    if (p->n_samples < 0 || p->n_branches < 0 || p->n_branches > (int64_t)INT32_MAX - 64)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad problem size N=%lld B=%lld",
+                        (long long)p->n_samples, (long long)p->n_branches);
+    if (p->n_samples > 0 && !p->indptr) return ff::fail(FF_ERR_ARG, err, errlen, "null indptr");
+    if (p->n_branches > 0 && !p->branch_len) return ff::fail(FF_ERR_ARG, err, errlen, "null branch_len");
+    if (p->n_samples > (int64_t)1 << 22)
+        return ff::fail(FF_ERR_ARG, err, errlen, "too many samples (%lld)", (long long)p->n_samples);
+    if (p->n_samples == 0) return FF_OK;
+    if (p->indptr[0] != 0) return ff::fail(FF_ERR_ARG, err, errlen, "indptr[0] != 0");
+    for (int64_t s = 0; s < p->n_samples; ++s) {
+        int64_t b = p->indptr[s], e = p->indptr[s + 1];
+        if (e < b) return ff::fail(FF_ERR_ARG, err, errlen, "indptr not monotone at sample %lld", (long long)s);
+        for (int64_t t = b; t < e; ++t) {
+            int32_t id = p->branch_id[t];
+            if (id < 0 || id >= p->n_branches)
+                return ff::fail(FF_ERR_ARG, err, errlen, "sample %lld: branch id %d out of range", (long long)s, id);
+            if (t > b && id <= p->branch_id[t - 1])
+                return ff::fail(FF_ERR_ARG, err, errlen,
+                                "sample %lld: branch ids not strictly ascending", (long long)s);
+            if (!(p->abnd[t] > 0) || !std::isfinite(p->abnd[t]))
+                return ff::fail(FF_ERR_ARG, err, errlen,
+                                "sample %lld: abundance must be finite and > 0", (long long)s);
+        }
+    }
+    return FF_OK;
+}
+
+// Chooses the arithmetic and, for FIXED32, the binary scale and the integer branch lengths.
+struct Quant {
+    bool fixed_ok = false;
+    int e = 0;
+    int lengths_exact = 0;
+    std::vector<uint32_t> klen;  // unweighted: round(l_b * 2^e)
+    std::string why_not;
+};
+
+Quant choose_quant(const ff_problem *p, bool weighted)
+{
+    Quant q;
+    const int64_t B = p->n_branches, N = p->n_samples;
+    for (int64_t b = 0; b < B; ++b)
+        if (!std::isfinite(p->branch_len[b]) || p->branch_len[b] < 0) {
+            q.why_not = "negative or non-finite branch length";
+            return q;
+        }
+    const double LIMIT = 2147483647.0;  // every W_s must stay below 2^31 so that U < 2^32
+    if (weighted) {
+        double wmax = 0, wmin_pos = INFINITY;
+        int64_t nnz_max = 0;
+        for (int64_t s = 0; s < N; ++s) {
+            double w = 0;
+            for (int64_t t = p->indptr[s]; t < p->indptr[s + 1]; ++t)
+                w += p->branch_len[p->branch_id[t]] * p->abnd[t];
+            if (!std::isfinite(w)) {
+                q.why_not = "non-finite sample weight";
+                return q;
+            }
+            wmax = std::max(wmax, w);
+            if (w > 0) wmin_pos = std::min(wmin_pos, w);
+            nnz_max = std::max(nnz_max, p->indptr[s + 1] - p->indptr[s]);
+        }
+        if (wmax == 0) {  // every distance is 0/0
+            q.fixed_ok = true;
+            q.e = 0;
+            return q;
+        }
+        // a sample far lighter than the heaviest one would keep too few bits
+        if (wmin_pos < wmax * 0x1p-10) {
+            q.why_not = "sample weights span more than 2^10";
+            return q;
+        }
+        int ex;
+        std::frexp((LIMIT - (double)nnz_max - 2.0) / wmax, &ex);  // 2^(ex-1) <= ratio < 2^ex
+        q.e = ex - 1;
+        q.fixed_ok = true;
+        return q;
+    }
+    // unweighted: smallest e making every length an integer, if the total still fits
+    double total = 0;
+    int e_exact = -2000;
+    for (int64_t b = 0; b < B; ++b) {
+        double l = p->branch_len[b];
+        total += l;
+        if (l == 0) continue;
+        int ex;
+        double m = std::frexp(l, &ex);  // l = m * 2^ex, 0.5 <= m < 1
+        // lowest set bit of the 53-bit mantissa
+        uint64_t mi = (uint64_t)std::ldexp(m, 53);
+        int tz = __builtin_ctzll(mi);
+        int lowbit = ex - 53 + tz;  // l is a multiple of 2^lowbit
+        e_exact = std::max(e_exact, -lowbit);
+    }
+    q.klen.assign((size_t)B, 0);
+    if (total == 0) {
+        q.fixed_ok = true;
+        q.e = 0;
+        q.lengths_exact = 1;
+        return q;
+    }
+    if (e_exact > -2000 && e_exact < 1000 && std::ldexp(total, e_exact) <= LIMIT - 2.0) {
+        q.e = e_exact;
+        q.lengths_exact = 1;
+    } else {
+        int ex;
+        std::frexp((LIMIT - (double)B - 2.0) / total, &ex);
+        q.e = ex - 1;
+        q.lengths_exact = 0;
+    }
+    for (int64_t b = 0; b < B; ++b) q.klen[(size_t)b] = (uint32_t)std::llrint(std::ldexp(p->branch_len[b], q.e));
+    q.fixed_ok = true;
+    return q;
+}
+
+// Pair tiles of the shard, row-block major (consecutive tiles share their 32 rows).
+void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj,
+                 std::vector<std::pair<int32_t, int32_t>> *tiles)
+{
+    tiles->clear();
+    if (re <= rb) return;
+    for (int64_t i0 = rb / ti * ti; i0 < re; i0 += ti) {
+        const int64_t imax = std::min<int64_t>(i0 + ti, re) - 1;  // largest row of the tile in the shard
+        for (int64_t j0 = 0; j0 < imax && j0 < N; j0 += tj) tiles->push_back({(int32_t)i0, (int32_t)j0});
+    }
+}
+
+// Balances tiles over U persistent waves: whole tiles round-robin while at least U
+// remain (all waves then sweep the branches in step, which keeps the rows they read
+// hot in L2), and the remaining < U tiles cut into equal branch ranges, stream-K
+// style, so that every wave ends at the same time.  Items that share a tile add
+// their partial sums atomically (integer adds: the result does not depend on order).
+void build_schedule(const std::vector<std::pair<int32_t, int32_t>> &tiles, int64_t rows, int U,
+                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
+{
+    const int64_t T = (int64_t)tiles.size();
+    std::vector<std::vector<Item>> per((size_t)U);
+    const int64_t nfull = T / U;
+    for (int64_t t = 0; t < nfull * U; ++t) {
+        Item it{};
+        it.i0 = tiles[(size_t)t].first;
+        it.j0 = tiles[(size_t)t].second;
+        it.k0 = 0;
+        it.k1 = (int32_t)rows;
+        it.flags = 0;
+        per[(size_t)(t % U)].push_back(it);
+    }
+    const int64_t rem = T - nfull * U;
+    if (rem > 0 && rows > 0) {
+        const int64_t total = rem * rows;
+        int64_t share = round_up((total + U - 1) / U, KSTEP);
+        for (int u = 0; u < U; ++u) {
+            int64_t a = (int64_t)u * share, b = std::min(total, a + share);
+            while (a < b) {
+                const int64_t t = a / rows;
+                const int64_t k0 = a % rows;
+                const int64_t k1 = std::min<int64_t>(rows, k0 + (b - a));
+                Item it{};
+                it.i0 = tiles[(size_t)(nfull * U + t)].first;
+                it.j0 = tiles[(size_t)(nfull * U + t)].second;
+                it.k0 = (int32_t)k0;
+                it.k1 = (int32_t)k1;
+                it.flags = (k0 == 0 && k1 == rows) ? 0u : 1u;
+                per[(size_t)u].push_back(it);
+                a += k1 - k0;
+            }
+        }
+    }
+    items->clear();
+    item_ptr->assign((size_t)U + 1, 0);
+    double el = 0;
+    for (int u = 0; u < U; ++u) {
+        for (const Item &it : per[(size_t)u]) {
+            items->push_back(it);
+            el += (double)(it.k1 - it.k0) * TILE_I * TILE_J;
+        }
+        (*item_ptr)[(size_t)u + 1] = (int32_t)items->size();
+    }
+    *elements = el;
+}
+
+void plan_free_device(ff_plan *pl)
+{
+    if (!pl) return;
+    (void)hipFree(pl->d_QT);
+    (void)hipFree(pl->d_W);
+    (void)hipFree(pl->d_num);
+    (void)hipFree(pl->d_items);
+    (void)hipFree(pl->d_item_ptr);
+    (void)hipFree(pl->d_DT);
+    (void)hipFree(pl->d_len);
+    (void)hipFree(pl->d_xtiles);
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+}
+
+int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char *err, size_t errlen)
+{
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+        return ff::fail(FF_ERR_DEVICE, err, errlen,
+                        "no HIP device available (%s); this engine has no CPU path",
+                        he != hipSuccess ? hipGetErrorString(he) : "device count is 0");
+    if (o->device >= 0) {
+        if (o->device >= ndev) return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d of %d", o->device, ndev);
+        FF_HIP(hipSetDevice(o->device));
+    }
+    FF_HIP(hipGetDevice(&pl->device));
+    hipDeviceProp_t prop;
+    FF_HIP(hipGetDeviceProperties(&prop, pl->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("FF_ALLOW_ANY_ARCH"))
+        return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d is %s; this engine is built for gfx950 only",
+                        pl->device, prop.gcnArchName);
+    const int64_t N = p->n_samples, B = p->n_branches;
+    const bool weighted = o->weighted != 0;
+    pl->weighted = weighted;
+    ff_plan_info &inf = pl->info;
+    inf.n_samples = N;
+    inf.n_branches = B;
+    inf.n_compute_units = prop.multiProcessorCount;
+    int rc = ff_shard_rows(N, o->rank, o->world, &inf.row_begin, &inf.row_end);
+    if (rc) return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
+    inf.slot_begin = inf.row_begin * (inf.row_begin - 1) / 2;
+    inf.slot_end = inf.row_end * (inf.row_end - 1) / 2;
+    if (inf.row_begin == 0) inf.slot_begin = 0;
+    if (inf.row_end == 0) inf.slot_end = 0;
+    const int64_t n_slots = inf.slot_end - inf.slot_begin;
+
+    Quant q;
+    int prec = o->precision;
+    // AUTO: problems small enough that the binary64 walk costs about a millisecond
+    // get the reference's exact roundings (this covers all of the reference's own
+    // test data); everything larger takes the 6x faster fixed-point path.
+    if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)B <= 4294967296.0)
+        prec = FF_PRECISION_EXACT64;
+    if (prec != FF_PRECISION_EXACT64) {
+        q = choose_quant(p, weighted);
+        if (!q.fixed_ok) {
+            if (prec == FF_PRECISION_FIXED32)
+                return ff::fail(FF_ERR_ARG, err, errlen, "FIXED32 not applicable: %s", q.why_not.c_str());
+            prec = FF_PRECISION_EXACT64;
+        } else {
+            prec = FF_PRECISION_FIXED32;
+        }
+    }
+    inf.precision = prec;
+    const int64_t nnz = N > 0 ? p->indptr[N] : 0;
+
+    // CSR to the device (shared by both stagers)
+    int64_t *d_indptr = nullptr;
+    int32_t *d_ids = nullptr;
+    double *d_abnd = nullptr, *d_len = nullptr;
+    auto free_csr = [&] {
+        (void)hipFree(d_indptr);
+        (void)hipFree(d_ids);
+        (void)hipFree(d_abnd);
+    };
+    FF_HIP(hipMalloc(&d_indptr, sizeof(int64_t) * (size_t)(N + 1)));
+    FF_HIP(hipMalloc(&d_ids, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+    FF_HIP(hipMalloc(&d_abnd, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+    FF_HIP(hipMalloc(&d_len, sizeof(double) * (size_t)std::max<int64_t>(B, 1)));
+    pl->d_len = d_len;
+    if (N > 0) FF_HIP(hipMemcpy(d_indptr, p->indptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
+    else {
+        int64_t z = 0;
+        FF_HIP(hipMemcpy(d_indptr, &z, sizeof z, hipMemcpyHostToDevice));
+    }
+    if (nnz > 0) {
+        FF_HIP(hipMemcpy(d_ids, p->branch_id, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(d_abnd, p->abnd, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    if (B > 0) FF_HIP(hipMemcpy(d_len, p->branch_len, sizeof(double) * (size_t)B, hipMemcpyHostToDevice));
+
+    if (prec == FF_PRECISION_FIXED32) {
+        const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
+        const int64_t rows = round_up(B, KSTEP);
+        inf.ld = ld;
+        inf.rows_padded = rows;
+        inf.lengths_exact = weighted ? 0 : q.lengths_exact;
+        const size_t qt_bytes = sizeof(uint32_t) * (size_t)(rows + SLACK_ROWS) * (size_t)ld;
+        inf.staged_bytes = (double)qt_bytes;
+        FF_HIP(hipMalloc(&pl->d_QT, qt_bytes));
+        FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
+        uint32_t *d_klen = nullptr;
+        if (!weighted) {
+            FF_HIP(hipMalloc(&d_klen, sizeof(uint32_t) * (size_t)std::max<int64_t>(B, 1)));
+            if (B > 0) FF_HIP(hipMemcpy(d_klen, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+        }
+        std::vector<unsigned long long> hW((size_t)ld);
+        int e = q.e;
+        for (int attempt = 0;; ++attempt) {
+            FF_HIP(hipMemset(pl->d_QT, 0, qt_bytes));
+            FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
+            if (N > 0 && nnz > 0)
+                stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, d_klen,
+                                                                        weighted ? 1 : 0, e, pl->d_QT, ld);
+            if (rows > 0) {
+                const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
+                dim3 grid((unsigned)(ld / 64), (unsigned)((rows + rpb - 1) / rpb));
+                colsum_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, rpb, pl->d_W);
+            }
+            FF_HIP(hipGetLastError());
+            FF_HIP(hipMemcpy(hW.data(), pl->d_W, sizeof(unsigned long long) * (size_t)ld, hipMemcpyDeviceToHost));
+            unsigned long long wmax = 0;
+            for (auto w : hW) wmax = std::max(wmax, w);
+            if (wmax <= 2147483647ull) break;
+            if (!weighted || attempt >= 3) {
+                (void)hipFree(d_klen);
+                free_csr();
+                return ff::fail(FF_ERR_INTERNAL, err, errlen, "FIXED32 staging overflow (max column sum %llu)", wmax);
+            }
+            --e;  // rounding pushed a column over the bound: drop one bit
+        }
+        (void)hipFree(d_klen);
+        inf.scale_log2 = e;
+        // schedule
+        std::vector<std::pair<int32_t, int32_t>> tiles;
+        build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, &tiles);
+        inf.n_tiles = (int64_t)tiles.size();
+        int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
+        if (wgs_per_cu < 1) wgs_per_cu = 1;
+        if (wgs_per_cu > 2) wgs_per_cu = 2;
+        pl->n_workgroups = prop.multiProcessorCount * wgs_per_cu;
+        // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
+        pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
+        const int U = pl->n_workgroups * WAVES_PER_WG;
+        inf.n_wave_slots = U;
+        std::vector<Item> items;
+        std::vector<int32_t> item_ptr;
+        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements);
+        inf.n_items = (int64_t)items.size();
+        FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
+        FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
+        if (!items.empty())
+            FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    } else {
+        const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
+        inf.ld = ld;
+        inf.rows_padded = B;
+        const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(B, 1) * (size_t)ld;
+        inf.staged_bytes = (double)dt_bytes;
+        FF_HIP(hipMalloc(&pl->d_DT, dt_bytes));
+        FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
+        if (N > 0 && nnz > 0)
+            stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,
+                                                                    pl->d_DT, ld);
+        FF_HIP(hipGetLastError());
+        std::vector<std::pair<int32_t, int32_t>> tiles;
+        build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, &tiles);
+        inf.n_tiles = inf.n_items = (int64_t)tiles.size();
+        inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)B;
+        std::vector<XTile> xt(tiles.size());
+        for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].first, tiles[k].second};
+        pl->n_xtiles = (int)xt.size();
+        FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
+        if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
+        inf.n_wave_slots = (int64_t)xt.size();
+    }
+    FF_HIP(hipDeviceSynchronize());
+    free_csr();
+    FF_HIP(hipEventCreate(&pl->ev0));
+    FF_HIP(hipEventCreate(&pl->ev1));
+    return FF_OK;
+}
+
+int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *err, size_t errlen)
+{
+    const ff_plan_info &inf = pl->info;
+    const int64_t n_slots = inf.slot_end - inf.slot_begin;
+    pl->timed_valid = false;
+    if (n_slots <= 0) return FF_OK;
+    if (!d_out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    int cur = -1;
+    FF_HIP(hipGetDevice(&cur));
+    if (cur != pl->device) FF_HIP(hipSetDevice(pl->device));
+    if (inf.precision == FF_PRECISION_FIXED32) {
+        FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
+        if (timed) FF_HIP(hipEventRecord(pl->ev0, st));
+        if (inf.n_items > 0)
+            pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
+                pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
+                inf.slot_begin);
+        if (timed) FF_HIP(hipEventRecord(pl->ev1, st));
+        const unsigned nb = (unsigned)((n_slots + 255) / 256);
+        finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->d_W, pl->weighted, inf.slot_begin,
+                                                               n_slots, d_out);
+    } else {
+        if (timed) FF_HIP(hipEventRecord(pl->ev0, st));
+        if (pl->n_xtiles > 0) {
+            const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
+            if (pl->weighted)
+                pair_exact64_kernel<true><<<dim3(nb), dim3(256), 0, st>>>(
+                    pl->d_DT, inf.ld, pl->d_len, inf.n_branches, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
+                    inf.row_end, inf.slot_begin, d_out);
+            else
+                pair_exact64_kernel<false><<<dim3(nb), dim3(256), 0, st>>>(
+                    pl->d_DT, inf.ld, pl->d_len, inf.n_branches, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
+                    inf.row_end, inf.slot_begin, d_out);
+        }
+        if (timed) FF_HIP(hipEventRecord(pl->ev1, st));
+    }
+    FF_HIP(hipGetLastError());
+    pl->timed_valid = timed;
+    return FF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ff_plan_create(const ff_problem *p, const ff_options *o, ff_plan **plan, char *err, size_t errlen)
+{
+    if (!plan) return ff::fail(FF_ERR_ARG, err, errlen, "null plan pointer");
+    *plan = nullptr;
+    ff_options dflt;
+    ff_options_default(&dflt);
+    if (!o) o = &dflt;
+    if (o->world < 1 || o->rank < 0 || o->rank >= o->world)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
+    if (o->precision < FF_PRECISION_AUTO || o->precision > FF_PRECISION_EXACT64)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad precision %d", o->precision);
+    int rc = validate_problem(p, err, errlen);
+    if (rc) return rc;
+    auto *pl = new ff_plan();
+    rc = plan_create_impl(p, o, pl, err, errlen);
+    if (rc) {
+        plan_free_device(pl);
+        delete pl;
+        return rc;
+    }
+    *plan = pl;
+    return FF_OK;
+}
+
+void ff_plan_destroy(ff_plan *pl)
+{
+    if (!pl) return;
+    plan_free_device(pl);
+    delete pl;
+}
+
+int ff_plan_info_get(const ff_plan *pl, ff_plan_info *info)
+{
+    if (!pl || !info) return FF_ERR_ARG;
+    *info = pl->info;
+    return FF_OK;
+}
+
+int ff_plan_run(ff_plan *pl, void *stream, double *d_out, char *err, size_t errlen)
+{
+    if (!pl) return ff::fail(FF_ERR_ARG, err, errlen, "null plan");
+    return plan_run_impl(pl, (hipStream_t)stream, d_out, false, err, errlen);
+}
+
+int ff_plan_run_timed(ff_plan *pl, void *stream, double *d_out, char *err, size_t errlen)
+{
+    if (!pl) return ff::fail(FF_ERR_ARG, err, errlen, "null plan");
+    return plan_run_impl(pl, (hipStream_t)stream, d_out, true, err, errlen);
+}
+
+double ff_plan_last_kernel_ms(ff_plan *pl)
+{
+    if (!pl || !pl->timed_valid) return -1.0;
+    if (hipEventSynchronize(pl->ev1) != hipSuccess) return -1.0;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, pl->ev0, pl->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char *err, size_t errlen)
+{
+    if (!out && p && p->n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    ff_plan *pl = nullptr;
+    int rc = ff_plan_create(p, o, &pl, err, errlen);
+    if (rc) return rc;
+    const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
+    if (n_slots > 0) {
+        double *d_out = nullptr;
+        hipError_t he = hipMalloc(&d_out, sizeof(double) * (size_t)n_slots);
+        if (he != hipSuccess) {
+            ff_plan_destroy(pl);
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: hipMalloc(out) failed: %s", hipGetErrorString(he));
+        }
+        rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
+        if (rc == FF_OK) {
+            he = hipMemcpy(out + pl->info.slot_begin, d_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
+            if (he != hipSuccess)
+                rc = ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
+        }
+        (void)hipFree(d_out);
+    }
+    ff_plan_destroy(pl);
+    return rc;
+}
+
+}  // extern "C"

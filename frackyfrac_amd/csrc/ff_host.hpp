@@ -1,0 +1,74 @@
+// ff_host.hpp -- internal declarations shared by the host-side sources of
+// libfrackyfrac_amd (the C ABI is include/frackyfrac_amd.h).
+#pragma once
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "frackyfrac_amd.h"
+
+namespace ff {
+
+// Writes a printf-style message into the caller's err buffer; returns `code`.
+int fail(int code, char *err, size_t errlen, const char *fmt, ...)
+    __attribute__((format(printf, 4, 5)));
+
+// Go's %q for a string, Go's %v for a float64, Go's %f for a float64.
+std::string go_quote(const std::string &s);
+std::string go_v(double f);
+std::string go_f(double f);
+
+// strconv.ParseFloat(tok, 64): returns false and fills `why` ("invalid syntax" /
+// "value out of range") on failure.
+bool go_parse_float(const char *b, const char *e, double *out, const char **why);
+
+// Reads a whole file (path) or stdin (path == nullptr).
+int read_all(const char *path, std::string *out, char *err, size_t errlen);
+
+unsigned clamp_threads(int requested);
+
+// Runs fn(t, begin, end) over [0, n) split into contiguous chunks on `threads` threads.
+void parallel_for(int64_t n, unsigned threads,
+                  const std::function<void(unsigned, int64_t, int64_t)> &fn);
+
+}  // namespace ff
+
+// The tree in enumerateNodes' numbering (frcfrc/unifrac.go:127-133).
+struct ff_tree {
+    std::vector<std::string> name;
+    std::vector<double> dist;     // treeDists (unifrac.go:117-120)
+    std::vector<int64_t> parent;  // -1 for the root; parent[id] < id
+    std::vector<int64_t> size;    // nodes in the subtree rooted at id (1 = leaf)
+    // name -> ids of the LEAVES carrying it (abundance goes to leaves only:
+    // flatNodeOptimization, unifrac.go:18,38-43); built lazily.
+    std::unordered_map<std::string, std::vector<int64_t>> leaf_ids;
+    // every node name, internal ones and "" included (treeNames, unifrac.go:70-76)
+    std::unordered_map<std::string, int> all_names;
+    void index_names();
+};
+
+// []map[string]float64 (parser/parser.go): per sample, (species index, value) in
+// insertion order; a re-assigned key keeps its slot and takes the last value.
+struct ff_table {
+    std::vector<std::string> species;
+    std::unordered_map<std::string, int32_t> species_id;
+    std::vector<int64_t> ptr;  // [n_samples + 1]
+    std::vector<int32_t> key;  // species index
+    std::vector<double> val;
+    int32_t intern(const char *b, const char *e);
+};
+
+struct ff_flat {
+    int64_t n_samples = 0, n_branches = 0;
+    std::vector<double> branch_len;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> branch_id;
+    std::vector<double> abnd;
+};

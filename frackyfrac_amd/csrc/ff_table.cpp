@@ -1,0 +1,260 @@
+// ff_table.cpp -- dense and sparse abundance-table loaders.
+//
+// Replaces parser.ParseAbundance (parser/parser.go:21-57) and
+// parser.ParseSparseAbundance (parser/parser.go:85-100), with the validation
+// rules and error texts of parseRow (:59-81), parseSparseRow (:102-127),
+// splitSparse (:129-140) and iterRows (:142-155; 32 MiB maximum line).
+// Instead of one Go map per sample the table keeps one species dictionary and
+// CSR rows of (species index, value); a key assigned twice keeps its first
+// position and its last value, which is what a map assignment leaves behind.
+#include <cmath>
+
+#include "ff_host.hpp"
+
+int32_t ff_table::intern(const char *b, const char *e)
+{
+    std::string s(b, e);
+    auto it = species_id.find(s);
+    if (it != species_id.end()) return it->second;
+    int32_t id = (int32_t)species.size();
+    species.push_back(s);
+    species_id.emplace(std::move(s), id);
+    return id;
+}
+
+namespace {
+
+const size_t MAX_LINE = (size_t)1 << 25;  // sc.Buffer(nil, 1<<25), parser.go:145
+
+inline bool is_space(char c)
+{
+    // regexp \S+ (parser.go:17) splits on the RE2 \s class: \t \n \f \r and space
+    return c == ' ' || c == '\t' || c == '\n' || c == '\f' || c == '\r' || c == '\v';
+}
+
+// bufio.ScanLines: lines end at '\n', one trailing '\r' is dropped, a final
+// unterminated non-empty line counts.
+struct Lines {
+    const char *p, *e;
+    bool next(const char **b, const char **le)
+    {
+        if (p >= e) return false;
+        const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *end = q ? q : e;
+        *b = p;
+        *le = (end > p && end[-1] == '\r') ? end - 1 : end;
+        p = q ? q + 1 : e;
+        return true;
+    }
+};
+
+struct Row {  // one sample being assembled, with last-assignment-wins keys
+    std::vector<int32_t> key;
+    std::vector<double> val;
+    std::unordered_map<int32_t, size_t> pos;
+    void clear()
+    {
+        key.clear();
+        val.clear();
+        pos.clear();
+    }
+    void set(int32_t k, double v)
+    {
+        auto it = pos.find(k);
+        if (it != pos.end()) {
+            val[it->second] = v;
+            return;
+        }
+        pos.emplace(k, key.size());
+        key.push_back(k);
+        val.push_back(v);
+    }
+    void flush(ff_table *t)
+    {
+        t->key.insert(t->key.end(), key.begin(), key.end());
+        t->val.insert(t->val.end(), val.begin(), val.end());
+        t->ptr.push_back((int64_t)t->key.size());
+    }
+};
+
+int bad_value(int i, double f, char *err, size_t errlen)
+{
+    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: bad value: %s", i, ff::go_f(f).c_str());
+}
+
+int bad_float(int i, const char *b, const char *e, const char *why, char *err, size_t errlen)
+{
+    std::string tok(b, e);
+    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: strconv.ParseFloat: parsing %s: %s", i,
+                    ff::go_quote(tok).c_str(), why);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ff_table_parse_dense(const char *text, size_t len, ff_table **out, char *err, size_t errlen)
+{
+    if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse_dense: null argument");
+    auto *t = new ff_table();
+    t->ptr.push_back(0);
+    Lines ls{text, text + len};
+    const char *b, *e;
+    std::vector<int32_t> names;
+    bool have_header = false;
+    Row row;
+    while (ls.next(&b, &e)) {
+        if ((size_t)(e - b) > MAX_LINE) {
+            delete t;
+            return ff::fail(FF_ERR_PARSE, err, errlen, "bufio.Scanner: token too long");
+        }
+        if (!have_header) {  // parser.go:32-40
+            for (const char *p = b; p < e;) {
+                while (p < e && is_space(*p)) ++p;
+                const char *q = p;
+                while (q < e && !is_space(*q)) ++q;
+                if (q > p) names.push_back(t->intern(p, q));
+                p = q;
+            }
+            if (names.empty()) {
+                delete t;
+                return ff::fail(FF_ERR_PARSE, err, errlen, "row #1 has 0 values");
+            }
+            have_header = true;
+            continue;
+        }
+        // parseRow, parser.go:59-81: the count is checked before any value is parsed
+        size_t nparts = 0;
+        for (const char *p = b; p < e;) {
+            while (p < e && is_space(*p)) ++p;
+            const char *q = p;
+            while (q < e && !is_space(*q)) ++q;
+            if (q > p) ++nparts;
+            p = q;
+        }
+        if (nparts != names.size()) {
+            delete t;
+            return ff::fail(FF_ERR_PARSE, err, errlen, "has %zu values, expected %zu", nparts,
+                            names.size());
+        }
+        row.clear();
+        size_t i = 0;
+        for (const char *p = b; p < e;) {
+            while (p < e && is_space(*p)) ++p;
+            const char *q = p;
+            while (q < e && !is_space(*q)) ++q;
+            if (q > p) {
+                double f;
+                const char *why;
+                if (!ff::go_parse_float(p, q, &f, &why)) {
+                    int rc = bad_float((int)i + 1, p, q, why, err, errlen);
+                    delete t;
+                    return rc;
+                }
+                if (std::isnan(f) || std::isinf(f) || f < 0) {
+                    int rc = bad_value((int)i + 1, f, err, errlen);
+                    delete t;
+                    return rc;
+                }
+                if (f != 0) row.set(names[i], f);
+                ++i;
+            }
+            p = q;
+        }
+        row.flush(t);
+    }
+    *out = t;
+    return FF_OK;
+}
+
+int ff_table_parse_sparse(const char *text, size_t len, ff_table **out, char *err, size_t errlen)
+{
+    if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse_sparse: null argument");
+    auto *t = new ff_table();
+    t->ptr.push_back(0);
+    Lines ls{text, text + len};
+    const char *b, *e;
+    Row row;
+    while (ls.next(&b, &e)) {
+        if ((size_t)(e - b) > MAX_LINE) {
+            delete t;
+            return ff::fail(FF_ERR_PARSE, err, errlen, "bufio.Scanner: token too long");
+        }
+        row.clear();  // a blank line is an empty sample (parser_test.go:29-35)
+        int i = 0;
+        for (const char *p = b; p < e;) {
+            while (p < e && is_space(*p)) ++p;
+            const char *q = p;
+            while (q < e && !is_space(*q)) ++q;
+            if (q > p) {
+                ++i;
+                const char *colon = nullptr;  // splitSparse: the LAST colon (parser.go:129-140)
+                for (const char *c = q; c > p;)
+                    if (*--c == ':') {
+                        colon = c;
+                        break;
+                    }
+                if (!colon) {
+                    std::string tok(p, q);
+                    delete t;
+                    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: no colon in %s", i,
+                                    ff::go_quote(tok).c_str());
+                }
+                if (colon == p) {
+                    delete t;
+                    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: empty species name", i);
+                }
+                double f;
+                const char *why;
+                if (!ff::go_parse_float(colon + 1, q, &f, &why)) {
+                    int rc = bad_float(i, colon + 1, q, why, err, errlen);
+                    delete t;
+                    return rc;
+                }
+                if (std::isnan(f) || std::isinf(f) || f < 0) {
+                    int rc = bad_value(i, f, err, errlen);
+                    delete t;
+                    return rc;
+                }
+                if (f == 0) {
+                    delete t;
+                    return ff::fail(FF_ERR_PARSE, err, errlen,
+                                    "value #%d: zeros are not allowed in sparse format", i);
+                }
+                row.set(t->intern(p, colon), f);
+            }
+            p = q;
+        }
+        row.flush(t);
+    }
+    *out = t;
+    return FF_OK;
+}
+
+int ff_table_read_file(const char *path, int sparse, ff_table **table, char *err, size_t errlen)
+{
+    std::string text;
+    int rc = ff::read_all(path, &text, err, errlen);
+    if (rc) return rc;
+    return sparse ? ff_table_parse_sparse(text.data(), text.size(), table, err, errlen)
+                  : ff_table_parse_dense(text.data(), text.size(), table, err, errlen);
+}
+
+void ff_table_free(ff_table *t) { delete t; }
+int64_t ff_table_num_samples(const ff_table *t) { return t ? (int64_t)t->ptr.size() - 1 : 0; }
+int64_t ff_table_sample_size(const ff_table *t, int64_t s)
+{
+    if (!t || s < 0 || s + 1 >= (int64_t)t->ptr.size()) return -1;
+    return t->ptr[(size_t)s + 1] - t->ptr[(size_t)s];
+}
+int ff_table_sample_entry(const ff_table *t, int64_t s, int64_t k, const char **name, double *value)
+{
+    int64_t n = ff_table_sample_size(t, s);
+    if (n < 0 || k < 0 || k >= n) return FF_ERR_ARG;
+    size_t at = (size_t)(t->ptr[(size_t)s] + k);
+    if (name) *name = t->species[(size_t)t->key[at]].c_str();
+    if (value) *value = t->val[at];
+    return FF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+// ff_util.cpp -- error plumbing, Go-compatible number formatting/parsing, threads.
+#include <charconv>
+#include <cmath>
+#include <functional>
+#include <thread>
+
+#include "ff_host.hpp"
+
+namespace ff {
+
+int fail(int code, char *err, size_t errlen, const char *fmt, ...)
+{
+    if (err && errlen) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, errlen, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+std::string go_quote(const std::string &s)
+{
+    std::string o = "\"";
+    char tmp[8];
+    for (unsigned char c : s) {
+        switch (c) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\n': o += "\\n"; break;
+        case '\t': o += "\\t"; break;
+        case '\r': o += "\\r"; break;
+        default:
+            if (c < 0x20 || c == 0x7f) {
+                snprintf(tmp, sizeof tmp, "\\x%02x", c);
+                o += tmp;
+            } else {
+                o += (char)c;  // UTF-8 passes through as Go prints valid runes
+            }
+        }
+    }
+    o += '"';
+    return o;
+}
+
+std::string go_v(double f)
+{
+    char b[40];
+    int n = ff_format_float(f, b);
+    return std::string(b, (size_t)n);
+}
+
+std::string go_f(double f)
+{
+    if (std::isnan(f)) return "NaN";
+    if (std::isinf(f)) return f > 0 ? "+Inf" : "-Inf";
+    char b[400];
+    snprintf(b, sizeof b, "%f", f);
+    return b;
+}
+
+static bool ieq(const char *b, const char *e, const char *lit)
+{
+    size_t n = strlen(lit);
+    if ((size_t)(e - b) != n) return false;
+    for (size_t i = 0; i < n; ++i) {
+        char c = b[i];
+        if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+        if (c != lit[i]) return false;
+    }
+    return true;
+}
+
+// strconv.ParseFloat accepts: optional sign, decimal or 0x-hex mantissa with
+// optional exponent, and the words inf / infinity / nan (any case).  Out-of-range
+// magnitudes are an error (ErrRange), which parser.go turns into "value #k: ...".
+bool go_parse_float(const char *b, const char *e, double *out, const char **why)
+{
+    *why = "invalid syntax";
+    if (b == e) return false;
+    const char *p = b;
+    bool neg = false;
+    if (*p == '+' || *p == '-') {
+        neg = (*p == '-');
+        ++p;
+        if (p == e) return false;
+    }
+    if (ieq(p, e, "inf") || ieq(p, e, "infinity")) {
+        *out = neg ? -INFINITY : INFINITY;
+        return true;
+    }
+    if (ieq(p, e, "nan")) {
+        *out = NAN;
+        return true;
+    }
+    double v = 0;
+    std::from_chars_result r{};
+    if (e - p > 2 && p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) {
+        // Go requires a p-exponent on hex floats.
+        bool has_p = false;
+        for (const char *q = p + 2; q < e; ++q)
+            if (*q == 'p' || *q == 'P') has_p = true;
+        if (!has_p) return false;
+        r = std::from_chars(p + 2, e, v, std::chars_format::hex);
+    } else {
+        if (!((*p >= '0' && *p <= '9') || *p == '.')) return false;
+        r = std::from_chars(p, e, v, std::chars_format::general);
+    }
+    if (r.ec == std::errc::result_out_of_range) {
+        // from_chars leaves v unmodified; underflow is not an error in Go (gives 0
+        // or a denormal), overflow is.
+        std::string tmp(p, e);
+        double s = strtod(tmp.c_str(), nullptr);
+        if (std::isinf(s)) {
+            *why = "value out of range";
+            return false;
+        }
+        *out = neg ? -s : s;
+        return true;
+    }
+    if (r.ec != std::errc() || r.ptr != e) return false;
+    *out = neg ? -v : v;
+    return true;
+}
+
+int read_all(const char *path, std::string *out, char *err, size_t errlen)
+{
+    FILE *f = path ? fopen(path, "rb") : stdin;
+    if (!f) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+    out->clear();
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+    bool bad = ferror(f);
+    if (path) fclose(f);
+    if (bad) return fail(FF_ERR_IO, err, errlen, "read %s: %s", path ? path : "stdin", strerror(errno));
+    return FF_OK;
+}
+
+unsigned clamp_threads(int requested)
+{
+    if (requested < 1) requested = 1;
+    if (requested > 256) requested = 256;
+    return (unsigned)requested;
+}
+
+void parallel_for(int64_t n, unsigned threads,
+                  const std::function<void(unsigned, int64_t, int64_t)> &fn)
+{
+    if (threads <= 1 || n <= 1) {
+        fn(0, 0, n);
+        return;
+    }
+    if ((int64_t)threads > n) threads = (unsigned)n;
+    std::vector<std::thread> th;
+    th.reserve(threads);
+    for (unsigned t = 0; t < threads; ++t) {
+        int64_t b = n * t / threads, e = n * (t + 1) / threads;
+        th.emplace_back([&fn, t, b, e] { fn(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+}  // namespace ff
+
+extern "C" {
+
+const char *ff_version(void) { return "frackyfrac_amd " FF_VERSION_STRING " (gfx950)"; }
+
+void ff_options_default(ff_options *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->weighted = 0;
+    o->precision = FF_PRECISION_AUTO;
+    o->device = -1;
+    o->rank = 0;
+    o->world = 1;
+}
+
+int64_t ff_num_pairs(int64_t n) { return n < 2 ? 0 : n * (n - 1) / 2; }
+
+// Equal-pairs contiguous row shards: rows [0, r) hold r(r-1)/2 pairs, so shard
+// boundaries sit at N*sqrt(k/world), rounded to the 32-row tile height.
+int ff_shard_rows(int64_t n, int32_t rank, int32_t world, int64_t *rb, int64_t *re)
+{
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !rb || !re) return FF_ERR_ARG;
+    auto bound = [&](int32_t k) -> int64_t {
+        if (k <= 0) return 0;
+        if (k >= world) return n;
+        double x = (double)n * std::sqrt((double)k / (double)world);
+        int64_t r = (int64_t)std::llround(x / 32.0) * 32;
+        if (r < 0) r = 0;
+        if (r > n) r = n;
+        return r;
+    };
+    *rb = bound(rank);
+    *re = bound(rank + 1);
+    if (*re < *rb) *re = *rb;
+    return FF_OK;
+}
+
+// fmt.Fprintln(w, f) without the newline: strconv.FormatFloat(f, 'g', -1, 64).
+int ff_format_float(double f, char *buf)
+{
+    if (std::isnan(f)) {
+        memcpy(buf, "NaN", 3);
+        return 3;
+    }
+    if (std::isinf(f)) {
+        memcpy(buf, f > 0 ? "+Inf" : "-Inf", 4);
+        return 4;
+    }
+    char *o = buf;
+    if (std::signbit(f)) {
+        *o++ = '-';
+        f = -f;
+    }
+    if (f == 0) {
+        *o++ = '0';
+        return (int)(o - buf);
+    }
+    // shortest round-trip digits: d[.ddd]e[+-]XX
+    char s[40];
+    auto r = std::to_chars(s, s + sizeof s - 1, f, std::chars_format::scientific);
+    *r.ptr = 0;
+    const char *epos = s;
+    while (epos < r.ptr && *epos != 'e') ++epos;
+    char digs[24];
+    int nd = 0;
+    for (const char *p = s; p < epos; ++p)
+        if (*p != '.') digs[nd++] = *p;
+    int x = atoi(epos + 1);  // decimal exponent of the first digit
+    while (nd > 1 && digs[nd - 1] == '0') --nd;
+    if (x < -4 || x >= 6) {  // %e: strconv's shortest-%g rule (eprec = 6)
+        *o++ = digs[0];
+        if (nd > 1) {
+            *o++ = '.';
+            memcpy(o, digs + 1, (size_t)nd - 1);
+            o += nd - 1;
+        }
+        *o++ = 'e';
+        *o++ = x < 0 ? '-' : '+';
+        int ax = x < 0 ? -x : x;
+        if (ax < 10) {
+            *o++ = '0';
+            *o++ = (char)('0' + ax);
+        } else {
+            char t[8];
+            int n = snprintf(t, sizeof t, "%d", ax);
+            memcpy(o, t, (size_t)n);
+            o += n;
+        }
+        return (int)(o - buf);
+    }
+    int dp = x + 1;  // digits before the decimal point
+    if (dp <= 0) {
+        *o++ = '0';
+        *o++ = '.';
+        for (int i = 0; i < -dp; ++i) *o++ = '0';
+        memcpy(o, digs, (size_t)nd);
+        o += nd;
+    } else if (dp >= nd) {
+        memcpy(o, digs, (size_t)nd);
+        o += nd;
+        for (int i = nd; i < dp; ++i) *o++ = '0';
+    } else {
+        memcpy(o, digs, (size_t)dp);
+        o += dp;
+        *o++ = '.';
+        memcpy(o, digs + dp, (size_t)(nd - dp));
+        o += nd - dp;
+    }
+    return (int)(o - buf);
+}
+
+int ff_write_distances(const char *path, const double *d, int64_t n, int threads,
+                       char *err, size_t errlen)
+{
+    FILE *f = path ? fopen(path, "wb") : stdout;
+    if (!f) return ff::fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+    unsigned nt = ff::clamp_threads(threads);
+    const int64_t CHUNK = 1 << 20;  // values formatted per round (<= 26 B each)
+    std::vector<std::string> bufs(nt);
+    int rc = FF_OK;
+    for (int64_t base = 0; base < n && rc == FF_OK; base += CHUNK) {
+        int64_t m = std::min(CHUNK, n - base);
+        for (auto &s : bufs) s.clear();
+        ff::parallel_for(m, nt, [&](unsigned t, int64_t b, int64_t e) {
+            std::string &s = bufs[t];
+            s.reserve((size_t)(e - b) * 20);
+            char tmp[40];
+            for (int64_t i = b; i < e; ++i) {
+                int k = ff_format_float(d[base + i], tmp);
+                tmp[k] = '\n';
+                s.append(tmp, (size_t)k + 1);
+            }
+        });
+        for (unsigned t = 0; t < nt; ++t)
+            if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), f) != bufs[t].size()) {
+                rc = ff::fail(FF_ERR_IO, err, errlen, "write %s: %s", path ? path : "stdout",
+                              strerror(errno));
+                break;
+            }
+    }
+    if (path) {
+        if (fclose(f) != 0 && rc == FF_OK)
+            rc = ff::fail(FF_ERR_IO, err, errlen, "close %s: %s", path, strerror(errno));
+    } else {
+        fflush(stdout);
+    }
+    return rc;
+}
+
+}  // extern "C"

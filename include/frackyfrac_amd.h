@@ -1,0 +1,237 @@
+/*
+ * frackyfrac_amd.h -- C ABI of the MI355X-native UniFrac distance engine.
+ *
+ * This is the drop-in boundary for ONE path of fluhus/frackyfrac: the all-pairs
+ * UniFrac reduction of the `frcfrc` tool (frcfrc/unifrac.go), plus the thin host
+ * surface either side of it (Newick tree, dense/sparse abundance tables, the
+ * lower-triangle text output).  The reference has no FFI; its seams are Go
+ * function calls inside package main.  Each entry point below names the
+ * reference function it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - Every function that can fail returns 0 on success and a non-zero ff_status
+ *     otherwise, and writes a NUL-terminated message into err (if err != NULL and
+ *     errlen > 0).  The CLI prints it as "ERROR: <msg>" and exits 2, as
+ *     common.ExitIfError does (common/common.go:13-18).
+ *   - Plain pointers and sizes only; all host buffers are caller-owned and are
+ *     not retained after the call returns (cgo pointer-passing rule).
+ *   - The compute path is HIP on gfx950 only.  There is no CPU fallback: without
+ *     a usable GPU the compute entry points fail with FF_ERR_DEVICE.
+ *   - Pair order everywhere is common.IterPairs (common/common.go:21-31): slot
+ *     k = i*(i-1)/2 + j for sample indices i > j >= 0, i.e. numpy.tril_indices(N,-1).
+ */
+#ifndef FRACKYFRAC_AMD_H
+#define FRACKYFRAC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FF_VERSION_STRING "0.1.0"
+
+typedef enum ff_status {
+    FF_OK = 0,
+    FF_ERR_ARG = 1,     /* bad argument / malformed problem                        */
+    FF_ERR_PARSE = 2,   /* malformed tree or table text (message follows parser.go) */
+    FF_ERR_SPECIES = 3, /* validateSpecies failure                                  */
+    FF_ERR_DEVICE = 4,  /* no GPU, HIP error, out of device memory                  */
+    FF_ERR_IO = 5,      /* file open/read/write                                     */
+    FF_ERR_INTERNAL = 6
+} ff_status;
+
+/* ------------------------------------------------------------------------- *
+ * 1. The hot path: frcfrc/unifrac.go:209  unifracDists(nodes, treeDists, weighted)
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Inputs of unifracDists: N sorted sparse vectors of flat nodes
+ * (frcfrc/unifrac.go:137-140 `flatNode{id, abnd}`) in CSR form, and
+ * treeDists[B] (unifrac.go:117-120: the branch length of every node in
+ * enumerateNodes' pre-order numbering, root included).
+ */
+typedef struct ff_problem {
+    int64_t n_samples;          /* N                                                   */
+    int64_t n_branches;         /* B = number of tree nodes; ids are 0..B-1            */
+    const double *branch_len;   /* [B]   treeDists                                     */
+    const int64_t *indptr;      /* [N+1] sample s owns entries indptr[s]..indptr[s+1]  */
+    const int32_t *branch_id;   /* [nnz] flatNode.id, strictly ascending within a sample */
+    const double *abnd;         /* [nnz] flatNode.abnd, > 0                            */
+} ff_problem;
+
+/* How the pairwise sums are carried on the device (DESIGN.md "Arithmetic"). */
+typedef enum ff_precision {
+    FF_PRECISION_AUTO = 0,    /* EXACT64 when pairs*branches <= 2^32 (about a millisecond) or
+                                 when FIXED32 is not applicable, else FIXED32                 */
+    FF_PRECISION_FIXED32 = 1, /* 32-bit fixed point, integer sums: order-independent, exact
+                                 for unweighted whenever all branch lengths are k * 2^-e      */
+    FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
+                                 the reference for any finite input; about 6x slower          */
+} ff_precision;
+
+typedef struct ff_options {
+    int32_t weighted;     /* the `weighted bool` argument / the -w flag (frcfrc.go:22)        */
+    int32_t precision;    /* ff_precision                                                     */
+    int32_t device;       /* HIP device ordinal; -1 = current device                          */
+    int32_t rank;         /* pair-space shard: this process computes the rows of shard `rank` */
+    int32_t world;        /* of `world` equal-work shards (1 = everything); see ff_shard_rows */
+    int32_t reserved[3];  /* must be 0                                                        */
+} ff_options;
+
+/* Fills *o with the defaults: unweighted, AUTO, current device, rank 0 of 1. */
+void ff_options_default(ff_options *o);
+
+/* Number of output slots for n samples: n*(n-1)/2. */
+int64_t ff_num_pairs(int64_t n_samples);
+
+/*
+ * The row range [*row_begin, *row_end) of sample indices i whose pairs (i, j<i)
+ * shard `rank` of `world` owns.  Shards are contiguous in IterPairs order, so a
+ * shard's results are the contiguous output slots
+ * [row_begin*(row_begin-1)/2, row_end*(row_end-1)/2); boundaries are chosen so
+ * every shard holds the same number of pairs to within one 32-row block.
+ */
+int ff_shard_rows(int64_t n_samples, int32_t rank, int32_t world,
+                  int64_t *row_begin, int64_t *row_end);
+
+/*
+ * Replaces unifracDists (frcfrc/unifrac.go:209-228): computes the distances of
+ * this shard's pairs into out (host memory).  out has ff_num_pairs(N) slots and
+ * is indexed by the global slot number; slots outside the shard are untouched.
+ * Blocking.  Ordered delivery (ppln.Serial, unifrac.go:212) is the slot index;
+ * the reference's early-stop (yield == false, unifrac.go:222) has no
+ * counterpart: the whole shard is produced in one device pass.
+ */
+int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out,
+                     char *err, size_t errlen);
+
+/* -- The same path with the staged inputs resident in HBM (benchmarks, pipelines) -- */
+
+typedef struct ff_plan ff_plan; /* staged matrix + tile schedule on one device */
+
+/* What the staging decided; read back with ff_plan_info. */
+typedef struct ff_plan_info {
+    int32_t precision;        /* FF_PRECISION_FIXED32 or FF_PRECISION_EXACT64 actually used   */
+    int32_t scale_log2;       /* FIXED32: values are round(x * 2^scale_log2)                  */
+    int32_t lengths_exact;    /* FIXED32 unweighted: 1 if every branch length is an exact
+                                 multiple of 2^-scale_log2 (results then bit-exact)           */
+    int32_t n_compute_units;  /* CUs of the device                                            */
+    int64_t n_samples, n_branches;
+    int64_t ld;               /* staged matrix leading dimension (samples, padded)            */
+    int64_t rows_padded;      /* staged matrix rows (branches, padded)                        */
+    int64_t row_begin, row_end; /* shard                                                      */
+    int64_t slot_begin, slot_end; /* output slots this plan writes                            */
+    int64_t n_tiles;          /* pair tiles of the shard                                      */
+    int64_t n_items;          /* (tile, branch-range) work items after balancing              */
+    int64_t n_wave_slots;     /* persistent waves the main kernel runs                        */
+    double staged_bytes;      /* bytes of the staged matrix in HBM                            */
+    double elements;          /* sum over items of tile pairs * branches = |a-b| terms issued */
+} ff_plan_info;
+
+/* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM
+ * (DESIGN.md "Data layout"), build the tile schedule.  Synchronous. */
+int ff_plan_create(const ff_problem *p, const ff_options *o, ff_plan **plan,
+                   char *err, size_t errlen);
+void ff_plan_destroy(ff_plan *plan);
+int ff_plan_info_get(const ff_plan *plan, ff_plan_info *info);
+
+/*
+ * One pass of the hot path over the staged inputs: launches the pair kernels on
+ * `stream` (a hipStream_t; NULL = the null stream) and returns without
+ * synchronising.  d_out is DEVICE memory with room for slot_end - slot_begin
+ * doubles: d_out[k - slot_begin] receives the distance of global slot k.
+ */
+int ff_plan_run(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
+
+/*
+ * Like ff_plan_run but brackets the dominant kernel (the pair-tile reduction)
+ * with HIP events on `stream`; ff_plan_last_kernel_ms synchronises on them and
+ * returns that kernel's duration of the most recent timed run (ms, <0 if none).
+ */
+int ff_plan_run_timed(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
+double ff_plan_last_kernel_ms(ff_plan *plan);
+
+/* ------------------------------------------------------------------------- *
+ * 2. Host surface either side of the hot path
+ * ------------------------------------------------------------------------- */
+
+/* newick.Node tree as the path uses it (Name, Distance, Children), flattened in
+ * the numbering of enumerateNodes (frcfrc/unifrac.go:127-133). */
+typedef struct ff_tree ff_tree;
+
+/* Replaces readTree (frcfrc/frcfrc.go:109-114): first tree of a Newick text.
+ * "no tree in the given file" when the text holds none. */
+int ff_tree_parse(const char *text, size_t len, ff_tree **tree, char *err, size_t errlen);
+int ff_tree_read_file(const char *path, ff_tree **tree, char *err, size_t errlen);
+void ff_tree_free(ff_tree *tree);
+int64_t ff_tree_num_nodes(const ff_tree *tree);
+/* Borrowed views, valid until ff_tree_free: */
+const double *ff_tree_branch_len(const ff_tree *tree);   /* [B] treeDists             */
+const int64_t *ff_tree_parent(const ff_tree *tree);      /* [B] parent id, -1 = root  */
+const int64_t *ff_tree_subtree_size(const ff_tree *tree);/* [B] nodes under id, incl. */
+const char *ff_tree_name(const ff_tree *tree, int64_t id);
+
+/* []map[string]float64 as the loaders produce it: one species->value map per sample. */
+typedef struct ff_table ff_table;
+
+/* Replace parser.ParseAbundance (parser/parser.go:21) and
+ * parser.ParseSparseAbundance (parser/parser.go:85). */
+int ff_table_parse_dense(const char *text, size_t len, ff_table **table, char *err, size_t errlen);
+int ff_table_parse_sparse(const char *text, size_t len, ff_table **table, char *err, size_t errlen);
+int ff_table_read_file(const char *path /* NULL = stdin */, int sparse, ff_table **table,
+                       char *err, size_t errlen);
+void ff_table_free(ff_table *table);
+int64_t ff_table_num_samples(const ff_table *table);
+int64_t ff_table_sample_size(const ff_table *table, int64_t sample);
+/* k-th entry of a sample in insertion order (a duplicated key keeps its first
+ * position and its last value, as a Go map assignment would). */
+int ff_table_sample_entry(const ff_table *table, int64_t sample, int64_t k,
+                          const char **name, double *value);
+
+/* Replaces validateSpecies (frcfrc/unifrac.go:80-93). */
+int ff_validate_species(const ff_table *table, const ff_tree *tree, char *err, size_t errlen);
+
+/* Stage A (frcfrc/unifrac.go:32-67,99-116) on the host: abundanceToFlatNodes +
+ * normalizeFlatNodes for every sample, in the reference's order of float
+ * additions.  leave_unnormalized = the -l flag (frcfrc.go:25): lists are sorted
+ * but not divided (the reference also skips the sort, SURVEY.md Q2 -- a defect
+ * this engine does not reproduce). */
+typedef struct ff_flat ff_flat; /* owns the CSR arrays an ff_problem points into */
+int ff_flatten(const ff_table *table, const ff_tree *tree, int leave_unnormalized,
+               ff_flat **flat, char *err, size_t errlen);
+/* The same from leaf values given by node id (no names): sample s has values
+ * leaf_val[leaf_ptr[s]..leaf_ptr[s+1]) at leaf node ids leaf_idx[...]. */
+int ff_flatten_leaf_csr(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                        const int64_t *leaf_idx, const double *leaf_val,
+                        int leave_unnormalized, ff_flat **flat, char *err, size_t errlen);
+void ff_flat_free(ff_flat *flat);
+void ff_flat_problem(const ff_flat *flat, ff_problem *p); /* borrowed views */
+
+/* Replaces unifrac (frcfrc/unifrac.go:97-124): flatten + distances into out
+ * (host, ff_num_pairs(N) slots).  o->weighted selects the metric. */
+int ff_unifrac(const ff_table *table, const ff_tree *tree, const ff_options *o,
+               int leave_unnormalized, double *out, char *err, size_t errlen);
+
+/* fmt.Fprintln(w, f) for a float64 (frcfrc/frcfrc.go:59): Go's %v -- shortest
+ * round-trip digits, %e form when the decimal exponent is < -4 or >= 6
+ * (strconv's shortest-%g rule), "NaN", "+Inf".  Writes the
+ * text WITHOUT the newline, returns its length (buf must hold 32 bytes). */
+int ff_format_float(double f, char *buf);
+/* Writes `n` distances, one per line, to path (NULL = stdout), formatting row
+ * blocks in parallel on `threads` host threads. */
+int ff_write_distances(const char *path, const double *d, int64_t n, int threads,
+                       char *err, size_t errlen);
+
+/* Whole `frcfrc` command (frcfrc/frcfrc.go:29-67): argv as the reference's flags
+ * -i -o -t -w -s -p -l.  Returns the process exit code (0, or 2 after printing
+ * "ERROR: ..." to stderr). */
+int ff_frcfrc_main(int argc, char **argv);
+
+const char *ff_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRACKYFRAC_AMD_H */
