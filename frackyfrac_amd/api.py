@@ -278,8 +278,14 @@ class Plan:
         fn = L.lib().ff_plan_run_timed if timed else L.lib().ff_plan_run
         L.check(fn(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(d_out_ptr), err, L.ERRLEN), err)
 
-    def last_kernel_ms(self) -> float:
-        return float(L.lib().ff_plan_last_kernel_ms(self._h))
+    def timing_collect(self) -> Tuple[float, int]:
+        """(summed ms of the pair-tile kernel, launches) over the timed runs since the
+        last call; synchronises on their events."""
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        rc = L.lib().ff_plan_timing_collect(self._h, ctypes.byref(ms), ctypes.byref(n))
+        if rc:
+            raise FFError(rc, "ff_plan_timing_collect failed")
+        return ms.value, n.value
 
 
 def format_float(f: float) -> str:

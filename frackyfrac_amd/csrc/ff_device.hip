@@ -37,16 +37,16 @@
 namespace {
 
 constexpr int TILE_I = 32;    // rows of a wave's pair tile: samples held in SGPRs
-constexpr int TILE_J = 128;   // columns: 2 per lane
-constexpr int KSTEP = 8;      // branch rows per unrolled iteration = vector prefetch ring
-constexpr int SLACK_ROWS = 16;  // zero rows past the matrix, read by the prefetch
+constexpr int TILE_J = 256;   // columns: 4 per lane (one 16-byte load per lane and row)
+constexpr int KSTEP = 8;      // branch rows per vector buffer; the loop body covers 2*KSTEP rows
+constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefetch
 constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
 constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
 constexpr int X_TILE_J = 64;
 
 struct Item {        // one unit of work for a persistent wave: a pair tile over a
     int32_t i0, j0;  // branch range [k0, k1) (multiples of KSTEP)
-    int32_t k0, k1;
+    int32_t k0, k1;  // multiples of 2*KSTEP
     uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
     int32_t pad[3];
 };
@@ -116,94 +116,109 @@ __global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64
 }
 
 // The pair-tile reduction.  Persistent: wave slot w runs items[item_ptr[w] .. item_ptr[w+1]).
-// Per branch row a wave issues 1 coalesced 512-B vector load (2 samples per lane),
-// 2 scalar 64-B loads (32 samples, wave-uniform) and 64 v_sad_u32.
+// Per branch row a wave issues 1 coalesced 1-KiB vector load (4 samples per lane),
+// 2 scalar 64-B loads (32 samples, wave-uniform) and 128 v_sad_u32.  The tile shape
+// is set by the scalar path: it delivers a row's 32 operands about once per 500
+// cycles per wave, so each operand has to feed 4 lanes' worth of v_sad_u32 (16
+// cycles of SIMD time) for the vector ALU, not the scalar cache, to be the limit
+// (measured: 32x128 tiles 27 T, 32x256 tiles 34.7 T |a-b| terms/s).
 __global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
 void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                      const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
                      uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin)
+                     int64_t slot_begin, unsigned long long *__restrict__ stamps)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * WAVES_PER_WG + wave;
     const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
+    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
+    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
-        const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + 2 * lane;
-        const uint32_t *ps = QT + (int64_t)item.k0 * ld + item.i0;
-        uint32_t acc0[TILE_I], acc1[TILE_I];
+        const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + 4 * lane;
+        // constant address space: the staged matrix is read-only for the whole launch,
+        // and loads from it with a wave-uniform address become s_load (scalar cache)
+        // without depending on the compiler's clobber analysis
+        typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+        const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
+        uint32_t acc[4][TILE_I];
 #pragma unroll
-        for (int r = 0; r < TILE_I; ++r) {
-            acc0[r] = 0;
-            acc1[r] = 0;
-        }
-        // vector ring: slot d holds row k+d; prologue fills slots 0..KSTEP-2
-        uint2 vj[KSTEP];
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int d = 0; d < KSTEP - 1; ++d) vj[d] = *(const uint2 *)(pj + (int64_t)d * ld);
-        const uint32_t *pv = pj + (int64_t)(KSTEP - 1) * ld;
+            for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
+        // Two vector buffers of KSTEP rows each: while the rows of one are consumed the
+        // other is refilled in one burst, a full KSTEP steps ahead of its first use, so
+        // the loads still in flight at the loop's back edge are always old (the
+        // compiler drains vmcnt there).  The 32 scalars of the next row are fetched
+        // one step ahead into the idle one of two SGPR sets.
+        uint4 vA[KSTEP], vB[KSTEP];
+#pragma unroll
+        for (int d = 0; d < KSTEP; ++d) vA[d] = *(const uint4 *)(pj + (int64_t)d * ld);
+        const uint32_t *pv = pj + (int64_t)KSTEP * ld;
         uint32_t sA[TILE_I], sB[TILE_I];
 #pragma unroll
         for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
         const int nk = item.k1 - item.k0;
-        for (int k = 0; k < nk; k += KSTEP) {
+#define FF_STEP(SCUR, SNXT, V, PREFETCH)                                       \
+    {                                                                         \
+        acc[0][0] = sad_u32(SCUR[0], (V).x, acc[0][0]);                       \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        ps += ld;                                                             \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];   \
+        PREFETCH;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        acc[1][0] = sad_u32(SCUR[0], (V).y, acc[1][0]);                       \
+        acc[2][0] = sad_u32(SCUR[0], (V).z, acc[2][0]);                       \
+        acc[3][0] = sad_u32(SCUR[0], (V).w, acc[3][0]);                       \
+        _Pragma("unroll") for (int r = 1; r < TILE_I; ++r) {                  \
+            acc[0][r] = sad_u32(SCUR[r], (V).x, acc[0][r]);                   \
+            acc[1][r] = sad_u32(SCUR[r], (V).y, acc[1][r]);                   \
+            acc[2][r] = sad_u32(SCUR[r], (V).z, acc[2][r]);                   \
+            acc[3][r] = sad_u32(SCUR[r], (V).w, acc[3][r]);                   \
+        }                                                                     \
+    }
+#define FF_FILL(BUF)                                                           \
+    _Pragma("unroll") for (int q = 0; q < KSTEP; ++q) {                       \
+        BUF[q] = *(const uint4 *)pv;                                          \
+        pv += ld;                                                             \
+    }
+        for (int k = 0; k < nk; k += 2 * KSTEP) {
+            FF_STEP(sA, sB, vA[0], FF_FILL(vB))
 #pragma unroll
-            for (int d = 0; d < KSTEP; d += 2) {
-                // even step: consume sA and ring slot d; fetch the next row's 32
-                // scalars into sB and refill ring slot d-1 (free since last step)
-                acc0[0] = sad_u32(sA[0], vj[d].x, acc0[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    ps += ld;
+            for (int d = 1; d < KSTEP; d += 2) {
+                FF_STEP(sB, sA, vA[d], )
+                if (d + 1 < KSTEP) FF_STEP(sA, sB, vA[d + 1], )
+            }
+            FF_STEP(sA, sB, vB[0], FF_FILL(vA))
 #pragma unroll
-                    for (int r = 0; r < TILE_I; ++r) sB[r] = ps[r];
-                    vj[(d + KSTEP - 1) % KSTEP] = *(const uint2 *)pv;
-                    pv += ld;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc1[0] = sad_u32(sA[0], vj[d].y, acc1[0]);
-#pragma unroll
-                for (int r = 1; r < TILE_I; ++r) {
-                    acc0[r] = sad_u32(sA[r], vj[d].x, acc0[r]);
-                    acc1[r] = sad_u32(sA[r], vj[d].y, acc1[r]);
-                }
-                // odd step: roles of sA and sB swapped
-                acc0[0] = sad_u32(sB[0], vj[d + 1].x, acc0[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    ps += ld;
-#pragma unroll
-                    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
-                    vj[d] = *(const uint2 *)pv;
-                    pv += ld;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc1[0] = sad_u32(sB[0], vj[d + 1].y, acc1[0]);
-#pragma unroll
-                for (int r = 1; r < TILE_I; ++r) {
-                    acc0[r] = sad_u32(sB[r], vj[d + 1].x, acc0[r]);
-                    acc1[r] = sad_u32(sB[r], vj[d + 1].y, acc1[r]);
-                }
+            for (int d = 1; d < KSTEP; d += 2) {
+                FF_STEP(sB, sA, vB[d], )
+                if (d + 1 < KSTEP) FF_STEP(sA, sB, vB[d + 1], )
             }
         }
+#undef FF_STEP
+#undef FF_FILL
         // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
-        const int64_t j = item.j0 + 2 * lane;
+        const int64_t j = item.j0 + 4 * lane;
         const bool atomic = item.flags & 1u;
 #pragma unroll
         for (int r = 0; r < TILE_I; ++r) {
             const int64_t i = item.i0 + r;
             if (i < row_begin || i >= row_end) continue;
             const int64_t base = i * (i - 1) / 2 - slot_begin + j;
-            if (atomic) {
-                if (j < i && acc0[r]) atomicAdd(&num[base], acc0[r]);
-                if (j + 1 < i && acc1[r]) atomicAdd(&num[base + 1], acc1[r]);
-            } else {
-                if (j < i) num[base] = acc0[r];
-                if (j + 1 < i) num[base + 1] = acc1[r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (j + c >= i) continue;
+                if (atomic) {
+                    if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
+                } else {
+                    num[base + c] = acc[c][r];
+                }
             }
         }
     }
+    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj)
@@ -304,14 +319,15 @@ struct ff_plan {
     int32_t *d_item_ptr = nullptr;
     int n_workgroups = 0;
     size_t lds_bytes = 0;
+    unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
     XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
-    // timing
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed_valid = false;
+    // timing: one event pair per timed run since the last collect
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
 };
 
 namespace {
@@ -484,7 +500,7 @@ void build_schedule(const std::vector<std::pair<int32_t, int32_t>> &tiles, int64
     const int64_t rem = T - nfull * U;
     if (rem > 0 && rows > 0) {
         const int64_t total = rem * rows;
-        int64_t share = round_up((total + U - 1) / U, KSTEP);
+        int64_t share = round_up((total + U - 1) / U, 2 * KSTEP);
         for (int u = 0; u < U; ++u) {
             int64_t a = (int64_t)u * share, b = std::min(total, a + share);
             while (a < b) {
@@ -523,11 +539,14 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_num);
     (void)hipFree(pl->d_items);
     (void)hipFree(pl->d_item_ptr);
+    (void)hipFree(pl->d_stamps);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_xtiles);
-    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
-    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    for (auto &e : pl->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
 }
 
 int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char *err, size_t errlen)
@@ -610,7 +629,7 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
 
     if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
-        const int64_t rows = round_up(B, KSTEP);
+        const int64_t rows = round_up(B, 2 * KSTEP);
         inf.ld = ld;
         inf.rows_padded = rows;
         inf.lengths_exact = weighted ? 0 : q.lengths_exact;
@@ -672,6 +691,10 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
             FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
         FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
         FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
+        if (env_int("FF_STAMPS", 0)) {
+            FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
+            FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
+        }
         FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     } else {
@@ -699,8 +722,6 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
     }
     FF_HIP(hipDeviceSynchronize());
     free_csr();
-    FF_HIP(hipEventCreate(&pl->ev0));
-    FF_HIP(hipEventCreate(&pl->ev1));
     return FF_OK;
 }
 
@@ -708,25 +729,36 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
 {
     const ff_plan_info &inf = pl->info;
     const int64_t n_slots = inf.slot_end - inf.slot_begin;
-    pl->timed_valid = false;
     if (n_slots <= 0) return FF_OK;
     if (!d_out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
     int cur = -1;
     FF_HIP(hipGetDevice(&cur));
     if (cur != pl->device) FF_HIP(hipSetDevice(pl->device));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) {
+        if (pl->events_used == pl->events.size()) {
+            hipEvent_t a, b;
+            FF_HIP(hipEventCreate(&a));
+            FF_HIP(hipEventCreate(&b));
+            pl->events.push_back({a, b});
+        }
+        ev0 = pl->events[pl->events_used].first;
+        ev1 = pl->events[pl->events_used].second;
+        ++pl->events_used;
+    }
     if (inf.precision == FF_PRECISION_FIXED32) {
         FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
-        if (timed) FF_HIP(hipEventRecord(pl->ev0, st));
+        if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
-                inf.slot_begin);
-        if (timed) FF_HIP(hipEventRecord(pl->ev1, st));
+                inf.slot_begin, pl->d_stamps);
+        if (timed) FF_HIP(hipEventRecord(ev1, st));
         const unsigned nb = (unsigned)((n_slots + 255) / 256);
         finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->d_W, pl->weighted, inf.slot_begin,
                                                                n_slots, d_out);
     } else {
-        if (timed) FF_HIP(hipEventRecord(pl->ev0, st));
+        if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->n_xtiles > 0) {
             const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
             if (pl->weighted)
@@ -738,10 +770,9 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                     pl->d_DT, inf.ld, pl->d_len, inf.n_branches, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
                     inf.row_end, inf.slot_begin, d_out);
         }
-        if (timed) FF_HIP(hipEventRecord(pl->ev1, st));
+        if (timed) FF_HIP(hipEventRecord(ev1, st));
     }
     FF_HIP(hipGetLastError());
-    pl->timed_valid = timed;
     return FF_OK;
 }
 
@@ -799,13 +830,35 @@ int ff_plan_run_timed(ff_plan *pl, void *stream, double *d_out, char *err, size_
     return plan_run_impl(pl, (hipStream_t)stream, d_out, true, err, errlen);
 }
 
-double ff_plan_last_kernel_ms(ff_plan *pl)
+// Diagnostics, not part of the public header: copies the per-wave start/end stamps
+// of the last pair_sad_kernel launch (FF_STAMPS=1) into out[2 * n_wave_slots].
+int ff_debug_read_stamps(ff_plan *pl, unsigned long long *out)
 {
-    if (!pl || !pl->timed_valid) return -1.0;
-    if (hipEventSynchronize(pl->ev1) != hipSuccess) return -1.0;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, pl->ev0, pl->ev1) != hipSuccess) return -1.0;
-    return (double)ms;
+    if (!pl || !pl->d_stamps || !out) return FF_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return FF_ERR_DEVICE;
+    if (hipMemcpy(out, pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)pl->info.n_wave_slots,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return FF_ERR_DEVICE;
+    return FF_OK;
+}
+
+int ff_plan_timing_collect(ff_plan *pl, double *total_ms, int32_t *launches)
+{
+    if (!pl || !total_ms || !launches) return FF_ERR_ARG;
+    double sum = 0;
+    int32_t n = 0;
+    for (size_t k = 0; k < pl->events_used; ++k) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pl->events[k].second) != hipSuccess ||
+            hipEventElapsedTime(&ms, pl->events[k].first, pl->events[k].second) != hipSuccess)
+            return FF_ERR_DEVICE;
+        sum += (double)ms;
+        ++n;
+    }
+    pl->events_used = 0;
+    *total_ms = sum;
+    *launches = n;
+    return FF_OK;
 }
 
 int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char *err, size_t errlen)

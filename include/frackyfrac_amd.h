@@ -146,12 +146,14 @@ int ff_plan_info_get(const ff_plan *plan, ff_plan_info *info);
 int ff_plan_run(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
 
 /*
- * Like ff_plan_run but brackets the dominant kernel (the pair-tile reduction)
- * with HIP events on `stream`; ff_plan_last_kernel_ms synchronises on them and
- * returns that kernel's duration of the most recent timed run (ms, <0 if none).
+ * Like ff_plan_run but brackets the dominant kernel (the pair-tile reduction) with
+ * a fresh pair of HIP events on `stream`.  ff_plan_timing_collect synchronises on
+ * every pair recorded since the previous collect and returns the summed duration of
+ * that kernel (ms) and the number of launches, so a benchmark can time K steps
+ * without a host sync inside its timed region.
  */
 int ff_plan_run_timed(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
-double ff_plan_last_kernel_ms(ff_plan *plan);
+int ff_plan_timing_collect(ff_plan *plan, double *total_ms, int32_t *launches);
 
 /* ------------------------------------------------------------------------- *
  * 2. Host surface either side of the hot path
