@@ -288,6 +288,15 @@ class Plan:
         return ms.value, n.value
 
 
+    def refined_pairs(self) -> Tuple[int, int]:
+        """(pairs the last completed run re-computed exactly, queue capacity)."""
+        q, c = ctypes.c_int64(), ctypes.c_int64()
+        rc = L.lib().ff_plan_refined_pairs(self._h, ctypes.byref(q), ctypes.byref(c))
+        if rc:
+            raise FFError(rc, "ff_plan_refined_pairs failed")
+        return q.value, c.value
+
+
 def format_float(f: float) -> str:
     """fmt.Fprintln's rendering of a float64, without the newline."""
     buf = ctypes.create_string_buffer(40)

@@ -231,10 +231,23 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
 }
 
 // Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
+//
+// Rounding every staged value to an integer leaves U with an error of about
+// sqrt((k_i + k_j) / 12) units (k = flat nodes of the sample).  Where U is so small
+// that this could exceed REFINE_REL of U -- nearly identical samples -- the pair is
+// queued for refine_exact_kernel, which recomputes it with the reference's own
+// binary64 merge walk; all other pairs already meet the tolerance.
+constexpr double REFINE_REL = 0.5e-6;   // half of the 1e-6 relative bar of BASELINE.json
+constexpr double REFINE_SIGMAS = 6.0;
+
 __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
                                       const unsigned long long *__restrict__ W, int weighted,
                                       int64_t slot_begin, int64_t n_slots,
-                                      double *__restrict__ out)
+                                      double *__restrict__ out,
+                                      const int64_t *__restrict__ indptr,  // null: no refinement
+                                      unsigned long long *__restrict__ refine_list,
+                                      unsigned long long *__restrict__ refine_count,
+                                      unsigned long long refine_cap)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots) return;
@@ -250,6 +263,64 @@ __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         d = (double)u / (double)(u + common);      // result / (result + common)
     }
     out[t] = d;
+    if (indptr && w != 0) {
+        const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
+        const double err = REFINE_SIGMAS * sqrt(k * (1.0 / 12.0)) + 1.0;
+        if ((double)u * REFINE_REL < err) {
+            const unsigned long long at = atomicAdd(refine_count, 1ull);
+            if (at < refine_cap) refine_list[at] = (unsigned long long)t;
+        }
+    }
+}
+
+// The reference's merge walk (unifrac.go:144-205) for the queued pairs, one thread per
+// pair, in binary64 and in the reference's order: bit-for-bit the reference's value.
+__global__ void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,
+                                    const unsigned long long *__restrict__ refine_count,
+                                    unsigned long long refine_cap,
+                                    const int64_t *__restrict__ indptr,
+                                    const int32_t *__restrict__ branch_id,
+                                    const double *__restrict__ abnd,
+                                    const double *__restrict__ tree_dists, int weighted,
+                                    int64_t slot_begin, double *__restrict__ out)
+{
+    unsigned long long n = *refine_count;
+    if (n > refine_cap) n = refine_cap;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n;
+         q += (unsigned long long)gridDim.x * blockDim.x) {
+        const int64_t t = (int64_t)refine_list[q];
+        int64_t si, sj;
+        slot_to_pair(slot_begin + t, &si, &sj);
+        int64_t i = indptr[si], ie = indptr[si + 1];  // a = sample i (the higher index)
+        int64_t j = indptr[sj], je = indptr[sj + 1];  // b = sample j
+        double x = 0.0, y = 0.0;                      // numer/denom or result/common
+        while (i < ie && j < je) {
+            const int32_t ia = branch_id[i], ib = branch_id[j];
+            if (ia < ib) {
+                const double l = tree_dists[ia];
+                if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
+                ++i;
+            } else if (ia > ib) {
+                const double l = tree_dists[ib];
+                if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
+                ++j;
+            } else {
+                const double l = tree_dists[ia];
+                if (weighted) { x += l * fabs(abnd[i] - abnd[j]); y += l * (abnd[i] + abnd[j]); } else { y += l; }
+                ++i;
+                ++j;
+            }
+        }
+        for (; i < ie; ++i) {
+            const double l = tree_dists[branch_id[i]];
+            if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
+        }
+        for (; j < je; ++j) {
+            const double l = tree_dists[branch_id[j]];
+            if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
+        }
+        out[t] = weighted ? x / y : x / (x + y);
+    }
 }
 
 // EXACT64: each lane owns the pairs (i0..i0+15, j0+lane) and walks every branch in
@@ -320,6 +391,13 @@ struct ff_plan {
     int n_workgroups = 0;
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
+    // refinement of nearly-equal pairs: the flat nodes stay on the device
+    bool refine = false;
+    int64_t *d_indptr = nullptr;
+    int32_t *d_ids = nullptr;
+    double *d_abnd = nullptr;
+    unsigned long long *d_refine_list = nullptr, *d_refine_count = nullptr;
+    unsigned long long refine_cap = 0;
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -540,6 +618,11 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_items);
     (void)hipFree(pl->d_item_ptr);
     (void)hipFree(pl->d_stamps);
+    (void)hipFree(pl->d_indptr);
+    (void)hipFree(pl->d_ids);
+    (void)hipFree(pl->d_abnd);
+    (void)hipFree(pl->d_refine_list);
+    (void)hipFree(pl->d_refine_count);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_xtiles);
@@ -721,7 +804,21 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
         inf.n_wave_slots = (int64_t)xt.size();
     }
     FF_HIP(hipDeviceSynchronize());
-    free_csr();
+    // FIXED32 keeps the flat nodes resident for refine_exact_kernel unless the integer
+    // sums are exact already (unweighted with lengths on the binary grid)
+    if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && n_slots > 0 &&
+        env_int("FF_REFINE", 1)) {
+        pl->refine = true;
+        pl->d_indptr = d_indptr;
+        pl->d_ids = d_ids;
+        pl->d_abnd = d_abnd;
+        pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
+        FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)pl->refine_cap));
+        FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long)));
+        FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long)));
+    } else {
+        free_csr();
+    }
     return FF_OK;
 }
 
@@ -755,8 +852,14 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 inf.slot_begin, pl->d_stamps);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
         const unsigned nb = (unsigned)((n_slots + 255) / 256);
-        finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->d_W, pl->weighted, inf.slot_begin,
-                                                               n_slots, d_out);
+        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long), st));
+        finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(
+            pl->d_num, pl->d_W, pl->weighted, inf.slot_begin, n_slots, d_out, pl->refine ? pl->d_indptr : nullptr,
+            pl->d_refine_list, pl->d_refine_count, pl->refine_cap);
+        if (pl->refine)
+            refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * 8)), dim3(64), 0, st>>>(
+                pl->d_refine_list, pl->d_refine_count, pl->refine_cap, pl->d_indptr, pl->d_ids, pl->d_abnd,
+                pl->d_len, pl->weighted, inf.slot_begin, d_out);
     } else {
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->n_xtiles > 0) {
@@ -830,6 +933,18 @@ int ff_plan_run_timed(ff_plan *pl, void *stream, double *d_out, char *err, size_
     return plan_run_impl(pl, (hipStream_t)stream, d_out, true, err, errlen);
 }
 
+int ff_plan_refined_pairs(ff_plan *pl, int64_t *queued, int64_t *capacity)
+{
+    if (!pl || !queued || !capacity) return FF_ERR_ARG;
+    *queued = 0;
+    *capacity = (int64_t)pl->refine_cap;
+    if (!pl->refine) return FF_OK;
+    unsigned long long n = 0;
+    if (hipMemcpy(&n, pl->d_refine_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
+    *queued = (int64_t)n;
+    return FF_OK;
+}
+
 // Diagnostics, not part of the public header: copies the per-wave start/end stamps
 // of the last pair_sad_kernel launch (FF_STAMPS=1) into out[2 * n_wave_slots].
 int ff_debug_read_stamps(ff_plan *pl, unsigned long long *out)
@@ -876,6 +991,23 @@ int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char
             return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: hipMalloc(out) failed: %s", hipGetErrorString(he));
         }
         rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
+        int64_t queued = 0, cap = 0;
+        if (rc == FF_OK && ff_plan_refined_pairs(pl, &queued, &cap) == FF_OK && queued > cap) {
+            // more nearly-equal pairs than the refinement queue holds: the data set is
+            // mostly replicates -- run the whole shard in binary64 instead
+            ff_plan_destroy(pl);
+            pl = nullptr;
+            ff_options o2;
+            if (o) o2 = *o; else ff_options_default(&o2);
+            o2.precision = FF_PRECISION_EXACT64;
+            rc = ff_plan_create(p, &o2, &pl, err, errlen);
+            if (rc == FF_OK) rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
+            if (rc != FF_OK) {
+                (void)hipFree(d_out);
+                ff_plan_destroy(pl);
+                return rc;
+            }
+        }
         if (rc == FF_OK) {
             he = hipMemcpy(out + pl->info.slot_begin, d_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
             if (he != hipSuccess)

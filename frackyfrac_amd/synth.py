@@ -51,7 +51,7 @@ class SynthTree:
             if st == 0:
                 if size[nd] == 1:
                     out.append(names[nd])
-                    if nd != 0:
+                    if nd != 0 or blen[nd] != 0:
                         out.append(":%s" % _fmt_len(blen[nd]))
                 else:
                     out.append("(")
@@ -71,7 +71,7 @@ class SynthTree:
             else:
                 out.append(")")
                 out.append(names[nd])
-                if nd != 0:
+                if nd != 0 or blen[nd] != 0:
                     out.append(":%s" % _fmt_len(blen[nd]))
         out.append(";\n")
         return "".join(out)

@@ -155,6 +155,15 @@ int ff_plan_run(ff_plan *plan, void *stream, double *d_out, char *err, size_t er
 int ff_plan_run_timed(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
 int ff_plan_timing_collect(ff_plan *plan, double *total_ms, int32_t *launches);
 
+/*
+ * FIXED32 re-computes the few pairs whose integer sum is too small for the 1e-6
+ * relative bar (nearly identical samples) with the reference's binary64 merge walk
+ * on the device.  After a run has completed: how many pairs the last run queued and
+ * the queue's capacity; queued > capacity means the surplus kept its fixed-point
+ * value (ff_unifrac_dists then repeats the shard in EXACT64 by itself).
+ */
+int ff_plan_refined_pairs(ff_plan *plan, int64_t *queued, int64_t *capacity);
+
 /* ------------------------------------------------------------------------- *
  * 2. Host surface either side of the hot path
  * ------------------------------------------------------------------------- */

@@ -53,10 +53,21 @@ def _go_float(tok: str) -> float:
         if t.lower().lstrip("+-") in ("inf", "infinity", "nan"):
             return float(t)
         if t.lower().lstrip("+-").startswith("0x"):
+            if "p" not in t.lower():  # Go: hexadecimal mantissa requires a 'p' exponent
+                raise ValueError(tok)
             return float.fromhex(t)
         return float(t)
     except ValueError:
         raise OracleError('strconv.ParseFloat: parsing "%s": invalid syntax' % tok)
+
+
+def _go_f(f: float) -> str:
+    """Go's %f."""
+    if math.isnan(f):
+        return "NaN"
+    if math.isinf(f):
+        return "+Inf" if f > 0 else "-Inf"
+    return "%f" % f
 
 
 def _iter_rows(text: str) -> List[str]:
@@ -80,7 +91,7 @@ def _parse_row(row: str, names: Sequence[str]) -> Dict[str, float]:
         except OracleError as e:
             raise OracleError("value #%d: %s" % (i + 1, e))
         if math.isnan(f) or math.isinf(f) or f < 0:
-            raise OracleError("value #%d: bad value: %f" % (i + 1, f))
+            raise OracleError("value #%d: bad value: %s" % (i + 1, _go_f(f)))
         if f == 0:
             continue
         m[names[i]] = f
@@ -126,7 +137,7 @@ def _parse_sparse_row(row: str) -> Dict[str, float]:
         except OracleError as e:
             raise OracleError("value #%d: %s" % (i + 1, e))
         if math.isnan(f) or math.isinf(f) or f < 0:
-            raise OracleError("value #%d: bad value: %f" % (i + 1, f))
+            raise OracleError("value #%d: bad value: %s" % (i + 1, _go_f(f)))
         if f == 0:
             raise OracleError("value #%d: zeros are not allowed in sparse format" % (i + 1))
         m[species] = f
@@ -408,6 +419,7 @@ def format_go_float(f: float) -> str:
     prints as 1e+06 and 0.0001 stays fixed); the exponent has at least two
     digits.  Distances lie in [0, 1] or are NaN, so only the small-exponent
     branch matters for output files; the large one shows in error messages."""
+    f = float(f)
     if math.isnan(f):
         return "NaN"
     if math.isinf(f):

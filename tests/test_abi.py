@@ -1,0 +1,45 @@
+"""The C ABI: the shared library loads, exports every symbol include/*.h declares, and
+the ctypes table binds exactly that set.  No compute calls."""
+import os
+import re
+import subprocess
+
+from frackyfrac_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "frackyfrac_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ff_[a-z0-9_]+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = header_functions()
+    assert len(declared) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    missing = declared - exported
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header():
+    assert set(L.SIGNATURES) == header_functions()
+    lib = L.lib()
+    for name in L.SIGNATURES:
+        assert getattr(lib, name) is not None
+    assert lib.ff_version().decode().startswith("frackyfrac_amd")
+    assert lib.ff_num_pairs(4096) == 8386560
+
+
+def test_struct_layouts():
+    import ctypes
+    assert ctypes.sizeof(L.ff_problem) == 48
+    assert ctypes.sizeof(L.ff_options) == 32
+    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16
+
+
+def test_frcfrc_binary_links_the_library():
+    out = subprocess.run(["ldd", L.FRCFRC_PATH], capture_output=True, text=True).stdout
+    assert "libfrackyfrac_amd.so" in out and "not found" not in out

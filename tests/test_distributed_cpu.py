@@ -1,0 +1,70 @@
+"""The N > 1 path on CPU: two gloo ranks shard the pair space (ff_shard_rows), each
+computes its slice, the slices are gathered to rank 0 with point-to-point send/recv
+(frackyfrac_amd/distributed.py) and must reproduce the single-process result.  The
+per-rank reduction is injected (the oracle's merge walk) because there is no GPU
+here; the sharding, slot arithmetic and gather are the product's."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_samples, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import frackyfrac_amd as ff
+    from frackyfrac_amd import synth
+    from frackyfrac_amd.distributed import unifrac_dists_sharded
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tree, ptr, idx, val = synth.make(n_samples, 60, 0.2, 99)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    onodes = np.zeros(len(nodes.branch_id), dtype=O.FLATNODE)
+    onodes["id"], onodes["abnd"] = nodes.branch_id, nodes.abnd
+
+    def compute(nd, weighted, r, w):
+        a, b = ff.shard_slots(nd.n_samples, r, w)
+        return torch.from_numpy(O.unifrac_dists(nd.indptr, onodes, nd.branch_len, weighted, 1, a, b).copy())
+
+    res = unifrac_dists_sharded(nodes, True, compute=compute)
+    if rank == 0:
+        want = O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, True)
+        q.put(bool(np.array_equal(res, want)) and len(res) == n_samples * (n_samples - 1) // 2)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_samples", [70, 5])
+def test_two_rank_gather_gloo(n_samples):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_samples, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

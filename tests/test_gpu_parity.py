@@ -1,0 +1,358 @@
+"""Parity of the HIP path (through the C ABI) with the oracle.  Needs an MI355X:
+run with `pytest -m gpu`.
+
+Bars: bit-exact for EXACT64 (any input) and for FIXED32 unweighted when the branch
+lengths are multiples of a power of two; FIXED32 weighted within 1e-6 relative
+(BASELINE.json north_star); golden .want files byte for byte."""
+import math
+import subprocess
+
+import numpy as np
+import pytest
+
+import frackyfrac_amd as ff
+from conftest import GOLDEN, read_golden
+from frackyfrac_amd import _lib as L
+from frackyfrac_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+WEIGHTED_RTOL = 1e-6  # north_star: "within 1e-6 relative for weighted"
+
+
+def rel_err(got, want):
+    m = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    denom = np.where(want[m] == 0, 1.0, np.abs(want[m]))
+    return float(np.max(np.abs(got[m] - want[m]) / denom)) if m.any() else 0.0
+
+
+def synth_problem(ns, nl, dens, seed, leave=False):
+    tree, ptr, idx, val = synth.make(ns, nl, dens, seed)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val, leave_unnormalized=leave)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 2 if leave else 0)
+    return nodes, ip, on, ft
+
+
+# ---------------------------------------------------------------- golden vectors
+
+@pytest.mark.parametrize("name,weighted", [("uwtd1", False), ("uwtd2", False), ("wtd", True)])
+@pytest.mark.parametrize("ext", [".dense", ".sparse"])
+@pytest.mark.parametrize("precision", ["auto", "exact64", "fixed32"])
+def test_golden_want(name, weighted, ext, precision):
+    tree = ff.Tree.read_file(GOLDEN + "/" + name + ".tree")
+    table = (ff.parse_sparse_abundance if ext == ".sparse" else ff.parse_abundance)(read_golden(name + ext))
+    ff.validate_species(table, tree)
+    got = ff.unifrac(table, tree, weighted, precision=precision)
+    want_text = read_golden(name + ".want")
+    want = np.array([float(x) for x in want_text.split()])
+    if precision == "fixed32" and weighted:
+        assert rel_err(got, want) <= WEIGHTED_RTOL
+    else:
+        assert "".join(ff.format_float(x) + "\n" for x in got) == want_text
+
+
+def test_unifrac_test_go_values():
+    """frcfrc/unifrac_test.go:12-74: exact float64 equality (reflect.DeepEqual)."""
+    cases = [("(s2:3,s1:1,s3:5);", "s1:1 s2:1\ns3:1 s2:1\n", False, [6.0 / 9.0]),
+             ("((s1:1,s2:3,s3:5):3,(s4:2,s5:2,s6:2):4,(s7:3,s8:2,s9:1):5);",
+              "s1:1 s2:1 s5:1 s9:1\ns3:1 s4:1 s5:1 s6:1\ns7:1 s9:1\n", False, [19.0 / 28.0, 16.0 / 22.0, 1.0]),
+             ("((s1:1,s2:3):2,(s3:2,s4:5):1);", "s1:4 s2:1\ns3:3 s2:2\n", True, [22.0 / 36.0])]
+    for tree, table, weighted, want in cases:
+        got = ff.unifrac(ff.parse_sparse_abundance(table), ff.parse_newick(tree), weighted)
+        assert got.tolist() == want
+
+
+def test_cli_run_sh(tmp_path):
+    """testdata/run.sh:3-18 with the built frcfrc: both loaders, diff against .want."""
+    for name, flags in (("uwtd1", []), ("uwtd2", []), ("wtd", ["-w"])):
+        for ext, extra in ((".dense", []), (".sparse", ["-s"])):
+            out = tmp_path / (name + ext + ".got")
+            r = subprocess.run([L.FRCFRC_PATH, *flags, *extra, "-i", GOLDEN + "/" + name + ext, "-t",
+                                GOLDEN + "/" + name + ".tree", "-o", str(out)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert out.read_text() == read_golden(name + ".want")
+            assert r.stderr.startswith("Reading tree\nLoading abundances\nValidating\nConverting abundances\n"
+                                       "Calculating distances\nTook ")
+            assert r.stderr.endswith("Done\n")
+    # stdin -> stdout, -p threads
+    r = subprocess.run([L.FRCFRC_PATH, "-w", "-p", "4", "-t", GOLDEN + "/wtd.tree"], input=read_golden("wtd.dense"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == read_golden("wtd.want")
+
+
+# ---------------------------------------------------------------- synthetic, full comparison
+
+def test_c2_unweighted_bit_exact():
+    """BASELINE configs[1]: 512 samples x 2k-leaf tree, unweighted, every pair, both paths."""
+    cfg = synth.CONFIGS["C2"]
+    nodes, ip, on, ft = synth_problem(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=8)
+    for precision in ("fixed32", "exact64", "auto"):
+        got = ff.unifrac_dists(nodes, False, precision=precision)
+        assert np.array_equal(got, want), precision
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.lengths_exact == 1 and plan.info.scale_log2 == 10
+    plan.close()
+
+
+def test_weighted_512_within_tolerance_and_exact64_bit_exact():
+    nodes, ip, on, ft = synth_problem(512, 2000, 0.1, 11)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=8)
+    got = ff.unifrac_dists(nodes, True, precision="fixed32")
+    err = rel_err(got, want)
+    assert err <= WEIGHTED_RTOL, err
+    assert err <= 1e-7, err  # measured ~1e-9; guards against silently losing bits
+    assert np.array_equal(ff.unifrac_dists(nodes, True, precision="exact64"), want)
+
+
+@pytest.mark.parametrize("ns,nl,dens,seed", [(1, 10, 0.5, 1), (2, 10, 0.5, 2), (3, 4, 1.0, 3), (33, 40, 0.3, 4),
+                                             (257, 100, 0.05, 5), (300, 3, 0.7, 6), (129, 700, 0.01, 7)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ragged_sizes(ns, nl, dens, seed, weighted):
+    """Sample counts and branch counts that do not fill tiles (N = 1, 2, 33, 257 ...)."""
+    nodes, ip, on, ft = synth_problem(ns, nl, dens, seed)
+    want = O.unifrac_dists(ip, on, ft.dist, weighted)
+    assert len(want) == ns * (ns - 1) // 2
+    got64 = ff.unifrac_dists(nodes, weighted, precision="exact64")
+    assert np.array_equal(got64, want, equal_nan=True)
+    got32 = ff.unifrac_dists(nodes, weighted, precision="fixed32")
+    if weighted:
+        assert rel_err(got32, want) <= WEIGHTED_RTOL
+    else:
+        assert np.array_equal(got32, want, equal_nan=True)
+
+
+def test_empty_samples_nan_and_one():
+    """both empty -> NaN, one empty -> 1 (unifrac.go:169,204); identical -> 0."""
+    tree = ff.parse_newick("((a:1,b:2):3,c:4);")
+    table = ff.parse_sparse_abundance("\n\na:1\na:1\nb:2 c:1\n")
+    otree, oab = O.parse_newick("((a:1,b:2):3,c:4);"), O.parse_sparse_abundance("\n\na:1\na:1\nb:2 c:1\n")
+    for weighted in (False, True):
+        want = O.unifrac(oab, otree, weighted)
+        assert math.isnan(want[0]) and want[1] == 1.0 and want[5] == 0.0
+        for precision in ("fixed32", "exact64"):
+            got = ff.unifrac(table, tree, weighted, precision=precision)
+            special = np.isnan(want) | (want == 0.0) | (want == 1.0)
+            assert np.array_equal(got[special], want[special], equal_nan=True), (weighted, precision)
+            if weighted and precision == "fixed32":
+                assert rel_err(got, want) <= WEIGHTED_RTOL
+            else:
+                assert np.array_equal(got, want, equal_nan=True), (weighted, precision)
+    # all samples empty / all branch lengths zero: every distance is 0/0
+    got = ff.unifrac(ff.parse_sparse_abundance("\n\n\n"), tree, True)
+    assert np.isnan(got).all() and len(got) == 3
+    ztree = ff.parse_newick("((a:0,b:0):0,c:0);")
+    for precision in ("fixed32", "exact64"):
+        got = ff.unifrac(ff.parse_sparse_abundance("a:1\nb:1\n"), ztree, False, precision=precision)
+        assert np.isnan(got).all()
+
+
+def test_general_branch_lengths():
+    """Lengths that are not multiples of a power of two: EXACT64 stays bit-exact (it
+    sums in the reference's order); FIXED32 quantises and reports lengths_exact = 0."""
+    rng = np.random.default_rng(3)
+    tree, ptr, idx, val = synth.make(96, 300, 0.15, 21)
+    tree.branch_len = np.round(rng.random(tree.n) * 3, 3)  # decimals like 1.234
+    tree.branch_len[0] = 0.25                               # a root with a length (Q3)
+    T = ff.parse_newick(tree.newick())
+    assert np.array_equal(T.branch_len, tree.branch_len)
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    for weighted in (False, True):
+        want = O.unifrac_dists(ip, on, ft.dist, weighted)
+        assert np.array_equal(ff.unifrac_dists(nodes, weighted, precision="exact64"), want)
+        assert rel_err(ff.unifrac_dists(nodes, weighted, precision="fixed32"), want) <= WEIGHTED_RTOL
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.lengths_exact == 0
+    plan.close()
+
+
+def test_nearly_identical_samples_are_refined():
+    """FIXED32's absolute error (~1e-8) is too coarse for distances near zero; such
+    pairs are re-computed on the device with the reference's merge walk, so the 1e-6
+    RELATIVE bar holds for replicate-like samples too."""
+    import torch
+    rng = np.random.default_rng(17)
+    tree, ptr, idx, val = synth.make(40, 400, 0.2, 51)
+    # samples 1..39 := sample 0 with a few counts nudged -> distances of 1e-6 .. 1e-2
+    base_i, base_v = idx[ptr[0]:ptr[1]], val[ptr[0]:ptr[1]]
+    rows = [(base_i, base_v)]
+    for s in range(1, 40):
+        v = base_v.copy()
+        k = rng.integers(0, len(v), size=1 + s // 8)
+        v[k] += rng.integers(1, 3, size=len(k)) * (1 if s % 2 else 1000)
+        rows.append((base_i, v))
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx, val = np.concatenate([r[0] for r in rows]), np.concatenate([r[1] for r in rows])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    assert 0 < want.min() < 1e-4
+    got = ff.unifrac_dists(nodes, True, precision="fixed32")
+    assert rel_err(got, want) <= WEIGHTED_RTOL
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    plan.run(out.data_ptr())
+    torch.cuda.synchronize()
+    queued, cap = plan.refined_pairs()
+    assert 0 < queued <= cap
+    small = want < 1e-3
+    assert np.array_equal(out.cpu().numpy()[small], want[small])   # refined pairs are bit-exact
+    plan.close()
+
+
+def test_refinement_queue_overflow_falls_back_to_exact64():
+    """A data set made of replicates overflows the refinement queue; the blocking entry
+    point then repeats the shard in EXACT64 (bit-exact)."""
+    tree, ptr, idx, val = synth.make(1, 20, 0.5, 61)
+    n = 1600                                             # 1.28 M pairs > queue capacity 2^20
+    ptr = np.arange(n + 1, dtype=np.int64) * len(idx)
+    val = np.tile(val, n)
+    val[:: len(idx)] += np.arange(n) % 3                 # three groups of identical samples
+    idx = np.tile(idx, n)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=8)
+    got = ff.unifrac_dists(nodes, True, precision="fixed32")
+    assert np.array_equal(got, want)
+
+
+def test_negative_branch_length_falls_back_to_exact64():
+    tree = ff.parse_newick("((a:1,b:-0.5):3,c:4);")
+    table = ff.parse_sparse_abundance("a:1 b:2\nb:1 c:5\na:3 c:1\n")
+    otree, oab = O.parse_newick("((a:1,b:-0.5):3,c:4);"), O.parse_sparse_abundance("a:1 b:2\nb:1 c:5\na:3 c:1\n")
+    for weighted in (False, True):
+        assert np.array_equal(ff.unifrac(table, tree, weighted), O.unifrac(oab, otree, weighted))
+        with pytest.raises(ff.FFError) as e:
+            ff.unifrac(table, tree, weighted, precision="fixed32")
+        assert "FIXED32 not applicable" in str(e.value)
+
+
+def test_leave_unnormalized_flag():
+    """-l (frcfrc.go:25): raw counts, lists sorted (the reference skips the sort --
+    SURVEY Q2 -- which this engine deliberately does not reproduce)."""
+    nodes, ip, on, ft = synth_problem(64, 120, 0.2, 31, leave=True)
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    assert np.array_equal(ff.unifrac_dists(nodes, True, precision="exact64"), want)
+    assert rel_err(ff.unifrac_dists(nodes, True, precision="fixed32"), want) <= WEIGHTED_RTOL
+
+
+def test_bad_problems_are_rejected():
+    nodes, *_ = synth_problem(4, 8, 0.5, 1)
+    bad = ff.FlatNodes(nodes.indptr, nodes.branch_id[::-1].copy(), nodes.abnd, nodes.branch_len)
+    with pytest.raises(ff.FFError) as e:
+        ff.unifrac_dists(bad, True)
+    assert e.value.code == 1
+    bad = ff.FlatNodes(nodes.indptr, nodes.branch_id, -nodes.abnd, nodes.branch_len)
+    with pytest.raises(ff.FFError):
+        ff.unifrac_dists(bad, True)
+    with pytest.raises(ff.FFError):
+        ff.unifrac_dists(nodes, True, rank=3, world=2)
+
+
+# ---------------------------------------------------------------- shards
+
+@pytest.mark.parametrize("precision", ["fixed32", "exact64"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_tile_the_pair_space(precision, world):
+    nodes, ip, on, ft = synth_problem(200, 150, 0.1, 41)
+    full = ff.unifrac_dists(nodes, True, precision=precision)
+    out = np.full(ff.num_pairs(200), np.nan)
+    for r in range(world):
+        before = out.copy()
+        ff.unifrac_dists(nodes, True, precision=precision, rank=r, world=world, out=out)
+        a, b = ff.shard_slots(200, r, world)
+        changed = np.flatnonzero(~((out == before) | (np.isnan(out) & np.isnan(before))))
+        assert len(changed) == 0 or (changed.min() >= a and changed.max() < b)
+    assert np.array_equal(out, full)  # shards reproduce the single-device result bit for bit
+
+
+# ---------------------------------------------------------------- full size, properties
+
+def test_c3_full_size_properties_and_sampled_parity():
+    """BASELINE configs[2] (headline): 4096 samples x 10k-leaf tree, weighted, FIXED32.
+    Size-independent checks over all 8.4 M pairs + oracle comparison on 4 slot ranges."""
+    import torch
+
+    cfg = synth.CONFIGS["C3"]
+    tree, ptr, idx, val = synth.make(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+    n = cfg["n_samples"]
+    # plant structure the result must show: sample 7 := sample 3 (distance exactly 0) and
+    # samples 11 / 12 supported on disjoint leaf sets under different root children
+    # (distance exactly 1)
+    def row(s):
+        return idx[ptr[s]:ptr[s + 1]], val[ptr[s]:ptr[s + 1]]
+    rows = [row(s) for s in range(n)]
+    rows[7] = rows[3]
+    first_child_end = 1 + tree.size[1]                      # nodes under the root's first child
+    li, lv = rows[11]
+    rows[11] = (li[li < first_child_end], lv[li < first_child_end])
+    li, lv = rows[12]
+    rows[12] = (li[li >= first_child_end], lv[li >= first_child_end])
+    assert len(rows[11][0]) and len(rows[12][0])
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx = np.concatenate([r[0] for r in rows])
+    val = np.concatenate([r[1] for r in rows])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.precision == 1 and plan.n_slots == ff.num_pairs(n)
+    out1 = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    out2 = torch.full((plan.n_slots,), -1.0, dtype=torch.float64, device="cuda")
+    plan.run(out1.data_ptr())
+    plan.run(out2.data_ptr(), timed=True)
+    torch.cuda.synchronize()
+    ms, launches = plan.timing_collect()
+    assert launches == 1 and 0.5 < ms < 100
+    d = out1.cpu().numpy()
+    assert np.array_equal(d, out2.cpu().numpy())            # idempotent, deterministic
+    assert not np.isnan(d).any() and d.min() >= 0.0 and d.max() <= 1.0
+    slot = lambda i, j: i * (i - 1) // 2 + j
+    assert d[slot(7, 3)] == 0.0
+    assert d[slot(12, 11)] == 1.0
+    # row 7 and row 3 are the same sample: equal distances to everyone else
+    others = [j for j in range(n) if j not in (3, 7)]
+    d3 = np.array([d[slot(max(3, j), min(3, j))] for j in others])
+    d7 = np.array([d[slot(max(7, j), min(7, j))] for j in others])
+    assert np.array_equal(d3, d7)
+    # sampled parity against the oracle: four contiguous slot ranges across the triangle
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    P = ff.num_pairs(n)
+    worst = 0.0
+    for a in (0, P // 3, 2 * P // 3, P - 3000):
+        want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=8, pair_begin=a, pair_end=a + 3000)
+        worst = max(worst, rel_err(d[a:a + 3000], want))
+    assert worst <= WEIGHTED_RTOL, worst
+    # two shards of the same problem reproduce the single-device bits (checksum of checksums)
+    parts = []
+    for r in range(2):
+        p2 = ff.Plan(nodes, True, precision="fixed32", rank=r, world=2)
+        o = torch.empty(p2.n_slots, dtype=torch.float64, device="cuda")
+        p2.run(o.data_ptr())
+        torch.cuda.synchronize()
+        parts.append(o.cpu().numpy())
+        p2.close()
+    assert np.array_equal(np.concatenate(parts), d)
+    plan.close()
+
+
+def test_c3_unweighted_full_size_bit_exact_on_ranges():
+    """Unweighted at headline size: integer path, so sampled ranges must match the
+    oracle exactly (dyadic lengths)."""
+    cfg = synth.CONFIGS["C3"]
+    nodes, ip, on, ft = synth_problem(2048, cfg["n_leaves"], cfg["density"], cfg["seed"])
+    got = ff.unifrac_dists(nodes, False, precision="fixed32")
+    P = ff.num_pairs(2048)
+    for a in (0, P // 2, P - 2000):
+        want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=8, pair_begin=a, pair_end=a + 2000)
+        assert np.array_equal(got[a:a + 2000], want)

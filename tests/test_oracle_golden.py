@@ -1,0 +1,199 @@
+"""The oracle pinned on every golden vector / known-answer test the reference holds
+for the UniFrac path.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import read_golden
+from oracle import oracle as O
+
+CASES = [("uwtd1", False), ("uwtd2", False), ("wtd", True)]
+
+
+@pytest.mark.parametrize("name,weighted", CASES)
+@pytest.mark.parametrize("loader,ext", [(O.parse_abundance, ".dense"), (O.parse_sparse_abundance, ".sparse")])
+def test_want_files_byte_exact(name, weighted, loader, ext):
+    """testdata/run.sh:3-18: both loaders, output diffed byte for byte against .want."""
+    tree = O.parse_newick(read_golden(name + ".tree"))
+    abnd = loader(read_golden(name + ext))
+    O.validate_species(abnd, tree)
+    want = read_golden(name + ".want")
+    assert O.format_output(O.unifrac_py(abnd, tree, weighted)) == want
+    assert O.format_output(O.unifrac(abnd, tree, weighted)) == want
+    assert O.format_output(O.unifrac(abnd, tree, weighted, nthreads=3)) == want
+
+
+def test_unifrac_test_go_simple():
+    """frcfrc/unifrac_test.go:12-31."""
+    tree = O.parse_newick("(s2:3,s1:1,s3:5);")
+    abnd = [{"s1": 1, "s2": 1}, {"s3": 1, "s2": 1}]
+    assert O.unifrac_py(abnd, tree, False) == [6.0 / 9.0]
+    assert O.unifrac(abnd, tree, False).tolist() == [6.0 / 9.0]
+
+
+def test_unifrac_test_go_complex():
+    """frcfrc/unifrac_test.go:33-53 (also pins the pair order)."""
+    tree = O.parse_newick("((s1:1,s2:3,s3:5):3,(s4:2,s5:2,s6:2):4,(s7:3,s8:2,s9:1):5);")
+    abnd = [{"s1": 1, "s2": 1, "s5": 1, "s9": 1}, {"s3": 1, "s4": 1, "s5": 1, "s6": 1}, {"s7": 1, "s9": 1}]
+    want = [19.0 / 28.0, 16.0 / 22.0, 1.0]
+    assert O.unifrac_py(abnd, tree, False) == want
+    assert O.unifrac(abnd, tree, False).tolist() == want
+
+
+def test_unifrac_test_go_weighted():
+    """frcfrc/unifrac_test.go:55-74."""
+    tree = O.parse_newick("((s1:1,s2:3):2,(s3:2,s4:5):1);")
+    abnd = [{"s1": 4, "s2": 1}, {"s3": 3, "s2": 2}]
+    assert O.unifrac_py(abnd, tree, True) == [22.0 / 36.0]
+    assert O.unifrac(abnd, tree, True).tolist() == [22.0 / 36.0]
+
+
+def test_iter_pairs_order():
+    """common/common_test.go:8-18."""
+    s = [1, 2, 4, 8]
+    assert [(s[i], s[j]) for i, j in O.iter_pairs(4)] == [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]
+    # slot index k = i(i-1)/2 + j  (trtr/dist.go:87-95 ijToN, same formula)
+    for k, (i, j) in enumerate(O.iter_pairs(7)):
+        assert k == i * (i - 1) // 2 + j
+
+
+def test_parse_abundance():
+    """parser/parser_test.go:9-26."""
+    got = O.parse_abundance("   aa  bbbb    \n1\t2\n 3  \t  4 \t\n")
+    assert got == [{"aa": 1, "bbbb": 2}, {"aa": 3, "bbbb": 4}]
+
+
+def test_parse_abundance_sparse():
+    """parser/parser_test.go:28-47: a blank line is an empty sample."""
+    got = O.parse_sparse_abundance("a:11 b:222  \n  b:32 c:7\n\nd:1\tc:4\ta:10\n")
+    assert got == [{"a": 11, "b": 222}, {"b": 32, "c": 7}, {}, {"d": 1, "c": 4, "a": 10}]
+
+
+def test_split_sparse():
+    """parser/parser_test.go:48-80."""
+    for s, a, b in [("a:b", "a", "b"), ("c:d:e::f", "c:d:e:", "f"), (":", "", ""), ("a:", "a", ""), (":b", "", "b")]:
+        assert O.split_sparse(s) == (a, b)
+    for s in ["", "a", "aaa"]:
+        with pytest.raises(O.OracleError):
+            O.split_sparse(s)
+
+
+def test_loader_errors():
+    """Messages of parser/parser.go:35,62,69,72,108-122,137."""
+    cases = [
+        (O.parse_abundance, "\n1 2\n", "row #1 has 0 values"),
+        (O.parse_abundance, "a b\n1\n", "has 1 values, expected 2"),
+        (O.parse_abundance, "a b\n1 x\n", 'value #2: strconv.ParseFloat: parsing "x": invalid syntax'),
+        (O.parse_abundance, "a b\n1 -2\n", "value #2: bad value: -2.000000"),
+        (O.parse_abundance, "a b\n1 2\n\n", "has 0 values, expected 2"),
+        (O.parse_sparse_abundance, "a:1 b\n", 'value #2: no colon in "b"'),
+        (O.parse_sparse_abundance, ":1\n", "value #1: empty species name"),
+        (O.parse_sparse_abundance, "a:0\n", "value #1: zeros are not allowed in sparse format"),
+        (O.parse_sparse_abundance, "a:nan\n", "value #1: bad value: NaN"),
+    ]
+    for fn, text, msg in cases:
+        with pytest.raises(O.OracleError) as e:
+            fn(text)
+        assert str(e.value) == msg
+
+
+def test_validate_species_message():
+    """frcfrc/unifrac.go:80-93; internal names and "" count as tree names (:70-76)."""
+    tree = O.parse_newick("((a:1,b:1)in:1,c:2);")
+    O.validate_species([{"a": 1, "in": 2, "": 3}], tree)
+    with pytest.raises(O.OracleError) as e:
+        O.validate_species([{"a": 1}, {"zz": 2.5}], tree)
+    assert str(e.value) == 'sample #2 has value 2.5 for species "zz" which is not in the tree'
+
+
+def test_go_float_format():
+    """fmt.Fprintln of a float64 (frcfrc/frcfrc.go:59): the three .want spellings plus Q6."""
+    cases = {0.0: "0", 1.0: "1", 0.5: "0.5", 0.0001: "0.0001", 0.00001234: "1.234e-05", 2 / 3: "0.6666666666666666",
+             19 / 28: "0.6785714285714286", 16 / 22: "0.7272727272727273", 22 / 36: "0.6111111111111112",
+             1e6: "1e+06", 123456.0: "123456", 1e-5: "1e-05", 5e-324: "5e-324", 0.1: "0.1", 1e21: "1e+21",
+             2.5: "2.5", 100.0: "100", 1234567.0: "1.234567e+06"}
+    for f, s in cases.items():
+        assert O.format_go_float(f) == s
+    assert O.format_go_float(math.nan) == "NaN"
+    assert O.format_go_float(math.inf) == "+Inf"
+
+
+def test_nan_and_one_cases():
+    """both samples empty -> 0/0 = NaN; one empty -> 1 (unifrac.go:169,204)."""
+    tree = O.parse_newick("((a:1,b:2):3,c:4);")
+    abnd = [{}, {}, {"a": 1}]
+    for weighted in (False, True):
+        for impl in (O.unifrac_py, O.unifrac):
+            d = list(impl(abnd, tree, weighted))
+            assert math.isnan(d[0]) and d[1] == 1.0 and d[2] == 1.0
+
+
+def test_normaliser_quirk_q1():
+    """the divisor is the sum over ALL flat nodes (unifrac.go:60-66), not
+    the sample total.  Checked against an independent dense evaluation of both
+    normalisations on a tree with unequal leaf depths."""
+    tree = O.parse_newick("(((a:1,b:2):3,c:4):1,(d:2,e:1):2,f:7);")
+    ft = O.flatten_tree(tree)
+    abnd = [{"a": 5, "c": 1, "f": 2}, {"b": 1, "d": 4}, {"a": 1, "e": 1, "f": 1}, {"c": 3}]
+    leaf = {nm: k for k, nm in enumerate(ft.names) if ft.size[k] == 1}
+
+    def dense(total_norm):
+        S = np.zeros((len(abnd), ft.n))
+        for s, m in enumerate(abnd):
+            for nm, v in m.items():
+                k = leaf[nm]
+                while k >= 0:
+                    S[s, k] += v
+                    k = ft.parent[k]
+        div = S[:, 0:1] if total_norm else S.sum(axis=1, keepdims=True)  # root holds the sample total
+        P = S / div
+        out = []
+        for i, j in O.iter_pairs(len(abnd)):
+            out.append((ft.dist * np.abs(P[i] - P[j])).sum() / (ft.dist * (P[i] + P[j])).sum())
+        return np.array(out)
+
+    got = O.unifrac(abnd, tree, True)
+    assert np.array_equal(got, np.array(O.unifrac_py(abnd, tree, True)))
+    assert np.allclose(got, dense(False), rtol=1e-13, atol=0)
+    assert np.max(np.abs(dense(False) - dense(True))) > 1e-3  # the quirk is visible here
+
+
+def test_c_layer_matches_python_layer_random():
+    """C restatement == literal Python restatement, bit for bit, on seeded random inputs
+    (multifurcating trees, unequal depths, duplicate leaf names, zero-length branches)."""
+    rng = np.random.default_rng(1234)
+    for trial in range(25):
+        # random tree text
+        leaves = ["L%d" % k for k in range(rng.integers(2, 12))]
+        if trial % 5 == 0:
+            leaves[-1] = leaves[0]  # duplicate leaf name: both leaves receive the abundance
+        nodes = ["%s:%s" % (nm, rng.integers(0, 9)) for nm in leaves]
+        while len(nodes) > 1:
+            k = int(rng.integers(2, min(4, len(nodes)) + 1))
+            pick = [nodes.pop(int(rng.integers(0, len(nodes)))) for _ in range(k)]
+            lab = "" if len(nodes) == 0 else ":%s" % (rng.integers(0, 50) / 8)
+            nodes.append("(" + ",".join(pick) + ")" + lab)
+        tree = O.parse_newick(nodes[0] + ";")
+        abnd = []
+        for s in range(rng.integers(2, 7)):
+            m = {nm: float(rng.integers(1, 20)) for nm in set(leaves) if rng.random() < 0.5}
+            abnd.append(m)
+        for weighted in (False, True):
+            a = np.array(O.unifrac_py(abnd, tree, weighted))
+            b = O.unifrac(abnd, tree, weighted)
+            assert np.array_equal(a, b, equal_nan=True), (trial, weighted)
+        # -l: the reference skips the sort (Q2); the oracle can reproduce that too
+        a = np.array(O.unifrac_py(abnd, tree, True, nnorm=True))
+        b = O.unifrac(abnd, tree, True, nnorm=True, reference_l_quirk=True)
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_prefix_and_threads():
+    from frackyfrac_amd import synth
+    tree, ptr, idx, val = synth.make(40, 60, 0.2, 7)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, nodes = O.flatten_samples(ft, ptr, idx, val, 0)
+    full = O.unifrac_dists(ip, nodes, ft.dist, True, 1)
+    assert np.array_equal(full, O.unifrac_dists(ip, nodes, ft.dist, True, 5))
+    assert np.array_equal(full[100:333], O.unifrac_dists(ip, nodes, ft.dist, True, 3, 100, 333))
