@@ -48,6 +48,7 @@ struct Item {        // one unit of work for a persistent wave: a pair tile over
     int32_t i0, j0;  // branch range [k0, k1) (multiples of KSTEP)
     int32_t k0, k1;  // multiples of 2*KSTEP
     uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
+                     // bit 1: all waves of the workgroup run an item of this length now
     int32_t pad[3];
 };
 static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
 void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                      const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
                      uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin, unsigned long long *__restrict__ stamps)
+                     int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,7 +184,17 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
         BUF[q] = *(const uint4 *)pv;                                          \
         pv += ld;                                                             \
     }
+        const int sync_every = (item.flags & 2u) ? sync_trips : 0;
+        int trips_left = sync_every;
         for (int k = 0; k < nk; k += 2 * KSTEP) {
+            // Items of a main round have the same length on all 8 waves of the workgroup
+            // (flag bit 1): a barrier every few trips keeps them on the same rows, so the
+            // older wave of each SIMD (which wins VALU arbitration) cannot run ahead and
+            // the vector rows the waves share stay hot in L1/L2.
+            if (sync_every && --trips_left == 0) {
+                __builtin_amdgcn_s_barrier();
+                trips_left = sync_every;
+            }
             FF_STEP(sA, sB, vA[0], FF_FILL(vB))
 #pragma unroll
             for (int d = 1; d < KSTEP; d += 2) {
@@ -391,6 +402,7 @@ struct ff_plan {
     int n_workgroups = 0;
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
+    int sync_trips = 0;                      // workgroup barrier every this many loop trips (0 = never)
     // refinement of nearly-equal pairs: the flat nodes stay on the device
     bool refine = false;
     int64_t *d_indptr = nullptr;
@@ -555,44 +567,68 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj,
     }
 }
 
-// Balances tiles over U persistent waves: whole tiles round-robin while at least U
-// remain (all waves then sweep the branches in step, which keeps the rows they read
-// hot in L2), and the remaining < U tiles cut into equal branch ranges, stream-K
-// style, so that every wave ends at the same time.  Items that share a tile add
-// their partial sums atomically (integer adds: the result does not depend on order).
+// Balances tiles over U persistent waves.
+//
+//  * Main rounds.  Each tile is cut into S equal branch ranges, S = ceil(U / T) (1 when
+//    there are at least U tiles), and U/S tiles are handed out per round, one range per
+//    wave.  All waves of a round then sweep the branches in step on S fronts, so the
+//    rows they read are shared through L2 (each XCD's 256 waves read the same few rows;
+//    measured: without this alignment 88 % of the loads miss L2).
+//  * Remainder.  The last < U/S tiles are cut stream-K style into U equal ranges so that
+//    every wave ends at the same time.
+//
+// Ranges that share a tile add their partial sums atomically; the sums are integers, so
+// the result does not depend on the order.
 void build_schedule(const std::vector<std::pair<int32_t, int32_t>> &tiles, int64_t rows, int U,
                     std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
 {
     const int64_t T = (int64_t)tiles.size();
     std::vector<std::vector<Item>> per((size_t)U);
-    const int64_t nfull = T / U;
-    for (int64_t t = 0; t < nfull * U; ++t) {
+    auto push = [&](int u, int64_t t, int64_t k0, int64_t k1) {
+        if (k1 <= k0) return;
         Item it{};
         it.i0 = tiles[(size_t)t].first;
         it.j0 = tiles[(size_t)t].second;
-        it.k0 = 0;
-        it.k1 = (int32_t)rows;
-        it.flags = 0;
-        per[(size_t)(t % U)].push_back(it);
-    }
-    const int64_t rem = T - nfull * U;
-    if (rem > 0 && rows > 0) {
-        const int64_t total = rem * rows;
-        int64_t share = round_up((total + U - 1) / U, 2 * KSTEP);
-        for (int u = 0; u < U; ++u) {
-            int64_t a = (int64_t)u * share, b = std::min(total, a + share);
-            while (a < b) {
-                const int64_t t = a / rows;
-                const int64_t k0 = a % rows;
-                const int64_t k1 = std::min<int64_t>(rows, k0 + (b - a));
-                Item it{};
-                it.i0 = tiles[(size_t)(nfull * U + t)].first;
-                it.j0 = tiles[(size_t)(nfull * U + t)].second;
-                it.k0 = (int32_t)k0;
-                it.k1 = (int32_t)k1;
-                it.flags = (k0 == 0 && k1 == rows) ? 0u : 1u;
-                per[(size_t)u].push_back(it);
-                a += k1 - k0;
+        it.k0 = (int32_t)k0;
+        it.k1 = (int32_t)k1;
+        it.flags = (k0 == 0 && k1 == rows) ? 0u : 1u;
+        per[(size_t)u].push_back(it);
+    };
+    int64_t done = 0;  // tiles fully scheduled
+    if (T > 0 && rows > 0) {
+        int64_t S = T >= U ? 1 : (U + T - 1) / T;
+        const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
+        S = std::min(S, max_split);
+        const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
+        const int64_t per_round = U / S / WAVES_PER_WG * WAVES_PER_WG;  // tiles per main round;
+        // a multiple of the workgroup size, so the 8 waves of a workgroup hold the same
+        // range index and hence equally long items (they may then barrier together)
+        const int64_t rounds = per_round > 0 ? T / per_round : 0;
+        for (int64_t r = 0; r < rounds; ++r)
+            for (int64_t q = 0; q < per_round; ++q) {
+                const int64_t t = r * per_round + q;
+                for (int64_t sidx = 0; sidx < S; ++sidx) {
+                    // the S ranges of a tile go to waves U/S apart: neighbouring waves keep
+                    // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
+                    const int u = (int)(sidx * per_round + q);
+                    push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
+                    if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
+                        per[(size_t)u].back().flags |= 2u;
+                }
+            }
+        done = rounds * per_round;
+        const int64_t rem = T - done;
+        if (rem > 0) {
+            const int64_t total = rem * rows;
+            const int64_t share = round_up((total + U - 1) / U, 2 * KSTEP);
+            for (int u = 0; u < U; ++u) {
+                int64_t a = (int64_t)u * share, b = std::min(total, a + share);
+                while (a < b) {
+                    const int64_t t = a / rows, k0 = a % rows;
+                    const int64_t k1 = std::min<int64_t>(rows, k0 + (b - a));
+                    push(u, done + t, k0, k1);
+                    a += k1 - k0;
+                }
             }
         }
     }
@@ -760,6 +796,7 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
         if (wgs_per_cu < 1) wgs_per_cu = 1;
         if (wgs_per_cu > 2) wgs_per_cu = 2;
         pl->n_workgroups = prop.multiProcessorCount * wgs_per_cu;
+        pl->sync_trips = env_int("FF_SYNC_TRIPS", 16);
         // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
         pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
         const int U = pl->n_workgroups * WAVES_PER_WG;
@@ -849,7 +886,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
-                inf.slot_begin, pl->d_stamps);
+                inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
         const unsigned nb = (unsigned)((n_slots + 255) / 256);
         if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long), st));

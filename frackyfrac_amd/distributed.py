@@ -32,18 +32,20 @@ def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, f
             full = torch.empty(P, dtype=local.dtype, device=local.device)
         a, b = api.shard_slots(n_samples, root, world)
         full[a:b].copy_(local)
-        reqs = []
+        ops = []
         for r in range(world):
             if r == root:
                 continue
             a, b = api.shard_slots(n_samples, r, world)
             if b > a:
-                reqs.append(dist.irecv(full[a:b], src=r, group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
+        # one group call: the 7 incoming transfers run concurrently, one per xGMI link
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return full
     if local.numel() > 0:
-        dist.send(local, dst=root, group=group)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]):
+            q.wait()
     return None
 
 
