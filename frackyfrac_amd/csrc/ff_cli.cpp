@@ -182,9 +182,17 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
 
     char err[1024];
     auto t0 = std::chrono::steady_clock::now();
+    auto last = t0;
+    double phase[6] = {0, 0, 0, 0, 0, 0};  // tree, load, validate, convert, distances, write
+    auto lap = [&](int k) {
+        auto now = std::chrono::steady_clock::now();
+        phase[k] = std::chrono::duration<double>(now - last).count();
+        last = now;
+    };
     fputs("Reading tree\n", stderr);
     ff_tree *tree = nullptr;
     if (ff_tree_read_file(f.tree.c_str(), &tree, err, sizeof err)) return die(err);
+    lap(0);
 
     fputs("Loading abundances\n", stderr);
     ff_table *table = nullptr;
@@ -192,6 +200,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         ff_tree_free(tree);
         return die(err);
     }
+    lap(1);
 
     fputs("Validating\n", stderr);
     if (ff_validate_species(table, tree, err, sizeof err)) {
@@ -199,6 +208,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         ff_tree_free(tree);
         return die(err);
     }
+    lap(2);
 
     fputs("Converting abundances\n", stderr);  // unifrac.go:101
     ff_flat *flat = nullptr;
@@ -210,32 +220,31 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     const int64_t n = ff_table_num_samples(table);
     ff_table_free(table);
     ff_tree_free(tree);
+    lap(3);
 
     fputs("Calculating distances\n", stderr);  // unifrac.go:122
     ff_problem p;
     ff_flat_problem(flat, &p);
     std::vector<double> out((size_t)ff_num_pairs(n));
-    ff_plan *plan = nullptr;
     ff_plan_info info{};
-    rc = ff_plan_create(&p, &opt, &plan, err, sizeof err);
-    if (rc == FF_OK) {
-        ff_plan_info_get(plan, &info);
-        ff_plan_destroy(plan);
-        rc = ff_unifrac_dists(&p, &opt, out.data(), err, sizeof err);
-    }
+    rc = ff::unifrac_dists_info(&p, &opt, out.data(), &info, err, sizeof err);
     ff_flat_free(flat);
     if (rc) return die(err);
-    if (f.stats)
-        fprintf(stderr,
-                "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"tiles\": %lld, "
-                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f}\n",
-                info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
-                info.lengths_exact, (long long)info.n_tiles, (long long)info.n_items,
-                (long long)info.n_wave_slots, info.staged_bytes);
+    lap(4);
 
     if (ff_write_distances(f.out.empty() ? nullptr : f.out.c_str(), out.data(), (int64_t)out.size(), (int)f.nt, err,
                            sizeof err))
         return die(err);
+    lap(5);
+    if (f.stats)
+        fprintf(stderr,
+                "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"tiles\": %lld, "
+                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"seconds\": {\"tree\": %.3f, "
+                "\"load\": %.3f, \"validate\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f}}\n",
+                info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
+                info.lengths_exact, (long long)info.n_tiles, (long long)info.n_items,
+                (long long)info.n_wave_slots, info.staged_bytes, phase[0], phase[1], phase[2], phase[3], phase[4],
+                phase[5]);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Took %s\n", go_duration(sec).c_str());
     fputs("Done\n", stderr);

@@ -49,6 +49,7 @@ struct Item {        // one unit of work for a persistent wave: a pair tile over
     int32_t k0, k1;  // multiples of 2*KSTEP
     uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
                      // bit 1: all waves of the workgroup run an item of this length now
+                     // bit 2: half-width tile (32 x 128)
     int32_t pad[3];
 };
 static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
@@ -116,6 +117,116 @@ __global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64
     if (acc) atomicAdd(&W[s], acc);
 }
 
+// NC 32-bit values per lane of one branch row: one 16-byte (NC = 4) or 8-byte (NC = 2) load.
+template <int NC> struct RowVec { uint32_t v[NC]; };
+template <int NC> __device__ __forceinline__ RowVec<NC> load_row(const uint32_t *p)
+{
+    RowVec<NC> r;
+    if constexpr (NC == 4) {
+        const uint4 t = *(const uint4 *)p;
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        const uint2 t = *(const uint2 *)p;
+        r.v[0] = t.x; r.v[1] = t.y;
+    }
+    return r;
+}
+
+// One work item: a 32 x (64*NC) pair tile over the branch rows [k0, k1).
+template <int NC>
+__device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
+                                         uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                                         int64_t slot_begin, int sync_trips, int lane)
+{
+    const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + NC * lane;
+    // constant address space: the staged matrix is read-only for the whole launch, and
+    // loads from it with a wave-uniform address become s_load (scalar cache) without
+    // depending on the compiler's clobber analysis
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+    const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
+    uint32_t acc[NC][TILE_I];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
+    // Two vector buffers of KSTEP rows each: while the rows of one are consumed the other
+    // is refilled in one burst, a full KSTEP steps ahead of its first use, so the loads
+    // still in flight at the loop's back edge are always old (the compiler drains vmcnt
+    // there).  The 32 scalars of the next row are fetched one step ahead into the idle
+    // one of two SGPR sets.
+    RowVec<NC> vA[KSTEP], vB[KSTEP];
+#pragma unroll
+    for (int d = 0; d < KSTEP; ++d) vA[d] = load_row<NC>(pj + (int64_t)d * ld);
+    const uint32_t *pv = pj + (int64_t)KSTEP * ld;
+    uint32_t sA[TILE_I], sB[TILE_I];
+#pragma unroll
+    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
+    const int nk = item.k1 - item.k0;
+#define FF_STEP(SCUR, SNXT, V, PREFETCH)                                        \
+    {                                                                          \
+        acc[0][0] = sad_u32(SCUR[0], (V).v[0], acc[0][0]);                     \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ps += ld;                                                              \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];    \
+        PREFETCH;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
+                if (r || c) acc[c][r] = sad_u32(SCUR[r], (V).v[c], acc[c][r]); \
+            }                                                                  \
+        }                                                                      \
+    }
+#define FF_FILL(BUF)                                                            \
+    _Pragma("unroll") for (int q = 0; q < KSTEP; ++q) {                        \
+        BUF[q] = load_row<NC>(pv);                                             \
+        pv += ld;                                                              \
+    }
+    const int sync_every = (item.flags & 2u) ? sync_trips : 0;
+    int trips_left = sync_every;
+    for (int k = 0; k < nk; k += 2 * KSTEP) {
+        // Items of a main round have the same length on all 8 waves of the workgroup
+        // (flag bit 1): a barrier every few trips keeps them on the same rows, so the
+        // older wave of each SIMD (which wins VALU arbitration) cannot run ahead and the
+        // vector rows the waves share stay hot in L1/L2.
+        if (sync_every && --trips_left == 0) {
+            __builtin_amdgcn_s_barrier();
+            trips_left = sync_every;
+        }
+        FF_STEP(sA, sB, vA[0], FF_FILL(vB))
+#pragma unroll
+        for (int d = 1; d < KSTEP; d += 2) {
+            FF_STEP(sB, sA, vA[d], )
+            if (d + 1 < KSTEP) FF_STEP(sA, sB, vA[d + 1], )
+        }
+        FF_STEP(sA, sB, vB[0], FF_FILL(vA))
+#pragma unroll
+        for (int d = 1; d < KSTEP; d += 2) {
+            FF_STEP(sB, sA, vB[d], )
+            if (d + 1 < KSTEP) FF_STEP(sA, sB, vB[d + 1], )
+        }
+    }
+#undef FF_STEP
+#undef FF_FILL
+    // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
+    const int64_t j = item.j0 + NC * lane;
+    const bool atomic = item.flags & 1u;
+#pragma unroll
+    for (int r = 0; r < TILE_I; ++r) {
+        const int64_t i = item.i0 + r;
+        if (i < row_begin || i >= row_end) continue;
+        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (j + c >= i) continue;
+            if (atomic) {
+                if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
+            } else {
+                num[base + c] = acc[c][r];
+            }
+        }
+    }
+}
+
 // The pair-tile reduction.  Persistent: wave slot w runs items[item_ptr[w] .. item_ptr[w+1]).
 // Per branch row a wave issues 1 coalesced 1-KiB vector load (4 samples per lane),
 // 2 scalar 64-B loads (32 samples, wave-uniform) and 128 v_sad_u32.  The tile shape
@@ -123,6 +234,7 @@ __global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64
 // cycles per wave, so each operand has to feed 4 lanes' worth of v_sad_u32 (16
 // cycles of SIMD time) for the vector ALU, not the scalar cache, to be the limit
 // (measured: 32x128 tiles 27 T, 32x256 tiles 34.7 T |a-b| terms/s).
+// Tiles that overhang the diagonal by more than half run as 32x128 (flag bit 2).
 __global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
 void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                      const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
@@ -137,97 +249,10 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
-        const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + 4 * lane;
-        // constant address space: the staged matrix is read-only for the whole launch,
-        // and loads from it with a wave-uniform address become s_load (scalar cache)
-        // without depending on the compiler's clobber analysis
-        typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-        const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
-        uint32_t acc[4][TILE_I];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
-        // Two vector buffers of KSTEP rows each: while the rows of one are consumed the
-        // other is refilled in one burst, a full KSTEP steps ahead of its first use, so
-        // the loads still in flight at the loop's back edge are always old (the
-        // compiler drains vmcnt there).  The 32 scalars of the next row are fetched
-        // one step ahead into the idle one of two SGPR sets.
-        uint4 vA[KSTEP], vB[KSTEP];
-#pragma unroll
-        for (int d = 0; d < KSTEP; ++d) vA[d] = *(const uint4 *)(pj + (int64_t)d * ld);
-        const uint32_t *pv = pj + (int64_t)KSTEP * ld;
-        uint32_t sA[TILE_I], sB[TILE_I];
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
-        const int nk = item.k1 - item.k0;
-#define FF_STEP(SCUR, SNXT, V, PREFETCH)                                       \
-    {                                                                         \
-        acc[0][0] = sad_u32(SCUR[0], (V).x, acc[0][0]);                       \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-        ps += ld;                                                             \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];   \
-        PREFETCH;                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-        acc[1][0] = sad_u32(SCUR[0], (V).y, acc[1][0]);                       \
-        acc[2][0] = sad_u32(SCUR[0], (V).z, acc[2][0]);                       \
-        acc[3][0] = sad_u32(SCUR[0], (V).w, acc[3][0]);                       \
-        _Pragma("unroll") for (int r = 1; r < TILE_I; ++r) {                  \
-            acc[0][r] = sad_u32(SCUR[r], (V).x, acc[0][r]);                   \
-            acc[1][r] = sad_u32(SCUR[r], (V).y, acc[1][r]);                   \
-            acc[2][r] = sad_u32(SCUR[r], (V).z, acc[2][r]);                   \
-            acc[3][r] = sad_u32(SCUR[r], (V).w, acc[3][r]);                   \
-        }                                                                     \
-    }
-#define FF_FILL(BUF)                                                           \
-    _Pragma("unroll") for (int q = 0; q < KSTEP; ++q) {                       \
-        BUF[q] = *(const uint4 *)pv;                                          \
-        pv += ld;                                                             \
-    }
-        const int sync_every = (item.flags & 2u) ? sync_trips : 0;
-        int trips_left = sync_every;
-        for (int k = 0; k < nk; k += 2 * KSTEP) {
-            // Items of a main round have the same length on all 8 waves of the workgroup
-            // (flag bit 1): a barrier every few trips keeps them on the same rows, so the
-            // older wave of each SIMD (which wins VALU arbitration) cannot run ahead and
-            // the vector rows the waves share stay hot in L1/L2.
-            if (sync_every && --trips_left == 0) {
-                __builtin_amdgcn_s_barrier();
-                trips_left = sync_every;
-            }
-            FF_STEP(sA, sB, vA[0], FF_FILL(vB))
-#pragma unroll
-            for (int d = 1; d < KSTEP; d += 2) {
-                FF_STEP(sB, sA, vA[d], )
-                if (d + 1 < KSTEP) FF_STEP(sA, sB, vA[d + 1], )
-            }
-            FF_STEP(sA, sB, vB[0], FF_FILL(vA))
-#pragma unroll
-            for (int d = 1; d < KSTEP; d += 2) {
-                FF_STEP(sB, sA, vB[d], )
-                if (d + 1 < KSTEP) FF_STEP(sA, sB, vB[d + 1], )
-            }
-        }
-#undef FF_STEP
-#undef FF_FILL
-        // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
-        const int64_t j = item.j0 + 4 * lane;
-        const bool atomic = item.flags & 1u;
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) {
-            const int64_t i = item.i0 + r;
-            if (i < row_begin || i >= row_end) continue;
-            const int64_t base = i * (i - 1) / 2 - slot_begin + j;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (j + c >= i) continue;
-                if (atomic) {
-                    if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
-                } else {
-                    num[base + c] = acc[c][r];
-                }
-            }
-        }
+        if (item.flags & 4u)
+            run_item<2>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
+        else
+            run_item<4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
     }
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -555,79 +580,101 @@ Quant choose_quant(const ff_problem *p, bool weighted)
     return q;
 }
 
-// Pair tiles of the shard, row-block major (consecutive tiles share their 32 rows).
-void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj,
-                 std::vector<std::pair<int32_t, int32_t>> *tiles)
+struct Tile {
+    int32_t i0, j0;
+    int32_t narrow;  // 1: 32 x 128 (the tile overhangs the diagonal by more than half)
+};
+
+// Pair tiles of the shard, row-block major (consecutive tiles share their rows).  tj is
+// the full tile width; with allow_narrow the last tile of a row block is half as wide
+// when at most tj/2 of its columns lie below the diagonal.
+void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles)
 {
     tiles->clear();
     if (re <= rb) return;
     for (int64_t i0 = rb / ti * ti; i0 < re; i0 += ti) {
-        const int64_t imax = std::min<int64_t>(i0 + ti, re) - 1;  // largest row of the tile in the shard
-        for (int64_t j0 = 0; j0 < imax && j0 < N; j0 += tj) tiles->push_back({(int32_t)i0, (int32_t)j0});
+        const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + ti, re) - 1, N);  // valid columns: j < w
+        for (int64_t j0 = 0; j0 < w; j0 += tj) {
+            const bool narrow = allow_narrow && (w - j0) <= tj / 2;
+            tiles->push_back({(int32_t)i0, (int32_t)j0, narrow ? 1 : 0});
+        }
     }
 }
 
 // Balances tiles over U persistent waves.
 //
-//  * Main rounds.  Each tile is cut into S equal branch ranges, S = ceil(U / T) (1 when
-//    there are at least U tiles), and U/S tiles are handed out per round, one range per
-//    wave.  All waves of a round then sweep the branches in step on S fronts, so the
-//    rows they read are shared through L2 (each XCD's 256 waves read the same few rows;
-//    measured: without this alignment 88 % of the loads miss L2).
-//  * Remainder.  The last < U/S tiles are cut stream-K style into U equal ranges so that
-//    every wave ends at the same time.
+//  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
+//    S = ceil(U / T) (1 when there are at least U tiles), and U/S tiles are handed out per
+//    round, one range per wave.  All waves of a round then sweep the branches in step on
+//    S fronts, so the rows they read are shared through L2 (each XCD's 256 waves read the
+//    same few rows; measured: without this alignment 88 % of the loads miss L2).
+//  * Remainder.  The last < U/S full tiles and all half-width tiles are cut stream-K
+//    style into U ranges of equal cost (a half-width row costs half) so that every wave
+//    ends at the same time.
 //
 // Ranges that share a tile add their partial sums atomically; the sums are integers, so
 // the result does not depend on the order.
-void build_schedule(const std::vector<std::pair<int32_t, int32_t>> &tiles, int64_t rows, int U,
+void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                     std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
 {
-    const int64_t T = (int64_t)tiles.size();
+    std::vector<Tile> wide, rest;
+    for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
+    const int64_t T = (int64_t)wide.size();
     std::vector<std::vector<Item>> per((size_t)U);
-    auto push = [&](int u, int64_t t, int64_t k0, int64_t k1) {
+    auto push = [&](int u, const Tile &t, int64_t k0, int64_t k1) {
         if (k1 <= k0) return;
         Item it{};
-        it.i0 = tiles[(size_t)t].first;
-        it.j0 = tiles[(size_t)t].second;
+        it.i0 = t.i0;
+        it.j0 = t.j0;
         it.k0 = (int32_t)k0;
         it.k1 = (int32_t)k1;
-        it.flags = (k0 == 0 && k1 == rows) ? 0u : 1u;
+        it.flags = ((k0 == 0 && k1 == rows) ? 0u : 1u) | (t.narrow ? 4u : 0u);
         per[(size_t)u].push_back(it);
     };
-    int64_t done = 0;  // tiles fully scheduled
-    if (T > 0 && rows > 0) {
-        int64_t S = T >= U ? 1 : (U + T - 1) / T;
-        const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
-        S = std::min(S, max_split);
-        const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
-        const int64_t per_round = U / S / WAVES_PER_WG * WAVES_PER_WG;  // tiles per main round;
-        // a multiple of the workgroup size, so the 8 waves of a workgroup hold the same
-        // range index and hence equally long items (they may then barrier together)
-        const int64_t rounds = per_round > 0 ? T / per_round : 0;
-        for (int64_t r = 0; r < rounds; ++r)
-            for (int64_t q = 0; q < per_round; ++q) {
-                const int64_t t = r * per_round + q;
-                for (int64_t sidx = 0; sidx < S; ++sidx) {
-                    // the S ranges of a tile go to waves U/S apart: neighbouring waves keep
-                    // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
-                    const int u = (int)(sidx * per_round + q);
-                    push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
-                    if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
-                        per[(size_t)u].back().flags |= 2u;
+    if (rows > 0) {
+        int64_t done = 0;  // full-width tiles scheduled in main rounds
+        if (T > 0) {
+            int64_t S = T >= U ? 1 : (U + T - 1) / T;
+            const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
+            S = std::min(S, max_split);
+            const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
+            // tiles per main round: a multiple of the workgroup size, so the 8 waves of a
+            // workgroup hold the same range index and hence equally long items (they may
+            // then barrier together)
+            const int64_t per_round = U / S / WAVES_PER_WG * WAVES_PER_WG;
+            const int64_t rounds = per_round > 0 ? T / per_round : 0;
+            for (int64_t r = 0; r < rounds; ++r)
+                for (int64_t q = 0; q < per_round; ++q) {
+                    const Tile &t = wide[(size_t)(r * per_round + q)];
+                    for (int64_t sidx = 0; sidx < S; ++sidx) {
+                        // the S ranges of a tile go to waves U/S apart: neighbouring waves keep
+                        // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
+                        const int u = (int)(sidx * per_round + q);
+                        push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
+                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
+                            per[(size_t)u].back().flags |= 2u;
+                    }
                 }
-            }
-        done = rounds * per_round;
-        const int64_t rem = T - done;
-        if (rem > 0) {
-            const int64_t total = rem * rows;
-            const int64_t share = round_up((total + U - 1) / U, 2 * KSTEP);
+            done = rounds * per_round;
+        }
+        rest.insert(rest.begin(), wide.begin() + done, wide.end());  // leftover full tiles first
+        if (!rest.empty()) {
+            // cost units: a full-width row = 2, a half-width row = 1
+            std::vector<int64_t> start(rest.size() + 1, 0);
+            for (size_t t = 0; t < rest.size(); ++t) start[t + 1] = start[t] + rows * (rest[t].narrow ? 1 : 2);
+            const int64_t total = start.back();
+            const int64_t share = round_up((total + U - 1) / U, 4 * KSTEP);  // 32 units: 16 wide or 32 narrow rows
+            size_t t = 0;
             for (int u = 0; u < U; ++u) {
-                int64_t a = (int64_t)u * share, b = std::min(total, a + share);
+                int64_t a = (int64_t)u * share;
+                const int64_t b = std::min(total, a + share);
                 while (a < b) {
-                    const int64_t t = a / rows, k0 = a % rows;
-                    const int64_t k1 = std::min<int64_t>(rows, k0 + (b - a));
-                    push(u, done + t, k0, k1);
-                    a += k1 - k0;
+                    while (start[t + 1] <= a) ++t;
+                    const int64_t unit = rest[t].narrow ? 1 : 2;
+                    const int64_t k0 = (a - start[t]) / unit;
+                    const int64_t k1 = std::min<int64_t>(rows, (std::min(b, start[t + 1]) - start[t]) / unit);
+                    push(u, rest[t], k0, k1);
+                    a = start[t] + k1 * unit;
                 }
             }
         }
@@ -638,7 +685,7 @@ void build_schedule(const std::vector<std::pair<int32_t, int32_t>> &tiles, int64
     for (int u = 0; u < U; ++u) {
         for (const Item &it : per[(size_t)u]) {
             items->push_back(it);
-            el += (double)(it.k1 - it.k0) * TILE_I * TILE_J;
+            el += (double)(it.k1 - it.k0) * TILE_I * ((it.flags & 4u) ? TILE_J / 2 : TILE_J);
         }
         (*item_ptr)[(size_t)u + 1] = (int32_t)items->size();
     }
@@ -789,8 +836,8 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
         (void)hipFree(d_klen);
         inf.scale_log2 = e;
         // schedule
-        std::vector<std::pair<int32_t, int32_t>> tiles;
-        build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, &tiles);
+        std::vector<Tile> tiles;
+        build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
         inf.n_tiles = (int64_t)tiles.size();
         int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
         if (wgs_per_cu < 1) wgs_per_cu = 1;
@@ -829,12 +876,12 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
             stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,
                                                                     pl->d_DT, ld);
         FF_HIP(hipGetLastError());
-        std::vector<std::pair<int32_t, int32_t>> tiles;
-        build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, &tiles);
+        std::vector<Tile> tiles;
+        build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
         inf.n_tiles = inf.n_items = (int64_t)tiles.size();
         inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)B;
         std::vector<XTile> xt(tiles.size());
-        for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].first, tiles[k].second};
+        for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
         pl->n_xtiles = (int)xt.size();
         FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
         if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
@@ -1015,6 +1062,15 @@ int ff_plan_timing_collect(ff_plan *pl, double *total_ms, int32_t *launches)
 
 int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char *err, size_t errlen)
 {
+    return ff::unifrac_dists_info(p, o, out, nullptr, err, errlen);
+}
+
+}  // extern "C"
+
+// ff_unifrac_dists that also reports what the staging decided (used by the CLI's -stats).
+int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info_out,
+                           char *err, size_t errlen)
+{
     if (!out && p && p->n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
     ff_plan *pl = nullptr;
     int rc = ff_plan_create(p, o, &pl, err, errlen);
@@ -1052,8 +1108,7 @@ int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char
         }
         (void)hipFree(d_out);
     }
+    if (info_out && pl) *info_out = pl->info;
     ff_plan_destroy(pl);
     return rc;
 }
-
-}  // extern "C"

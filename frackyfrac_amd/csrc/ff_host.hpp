@@ -38,6 +38,10 @@ unsigned clamp_threads(int requested);
 void parallel_for(int64_t n, unsigned threads,
                   const std::function<void(unsigned, int64_t, int64_t)> &fn);
 
+// ff_unifrac_dists + the plan's info (info may be null).
+int unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info,
+                       char *err, size_t errlen);
+
 }  // namespace ff
 
 // The tree in enumerateNodes' numbering (frcfrc/unifrac.go:127-133).
