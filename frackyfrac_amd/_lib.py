@@ -80,6 +80,10 @@ SIGNATURES = {
     "ff_flatten": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_flatten_leaf_csr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                     POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_flatten_device": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                  POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_plan_create_from_leaves": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                           POINTER(ff_options), POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_flat_free": (None, [c_void_p]),
     "ff_flat_problem": (None, [c_void_p, POINTER(ff_problem)]),
     "ff_unifrac": (c_int, [c_void_p, c_void_p, POINTER(ff_options), c_int, c_void_p, c_char_p, c_size_t]),

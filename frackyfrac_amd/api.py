@@ -226,6 +226,18 @@ def flatten_leaf_csr(tree: Tree, leaf_ptr, leaf_idx, leaf_val, leave_unnormalize
     return FlatNodes._from_handle(h)
 
 
+def flatten_device(tree: Tree, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized: bool = False) -> FlatNodes:
+    """Stage A on the GPU (ff_flatten_device); returns the flat nodes on the host."""
+    leaf_ptr = np.ascontiguousarray(leaf_ptr, dtype=np.int64)
+    leaf_idx = np.ascontiguousarray(leaf_idx, dtype=np.int64)
+    leaf_val = np.ascontiguousarray(leaf_val, dtype=np.float64)
+    h, err = ctypes.c_void_p(), L.errbuf()
+    L.check(L.lib().ff_flatten_device(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data, leaf_idx.ctypes.data,
+                                      leaf_val.ctypes.data, 1 if leave_unnormalized else 0,
+                                      ctypes.byref(h), err, L.ERRLEN), err)
+    return FlatNodes._from_handle(h)
+
+
 def unifrac_dists(nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1,
                   rank: int = 0, world: int = 1, out: Optional[np.ndarray] = None) -> np.ndarray:
     """unifracDists (frcfrc/unifrac.go:209): all pair distances of this shard in
@@ -252,13 +264,30 @@ def unifrac(table: Table, tree: Tree, weighted: bool, leave_unnormalized: bool =
 class Plan:
     """Staged inputs resident in HBM + tile schedule (ff_plan)."""
 
-    def __init__(self, nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1,
-                 rank: int = 0, world: int = 1):
-        p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
-        self._h = ctypes.c_void_p()
-        L.check(L.lib().ff_plan_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(self._h), err, L.ERRLEN), err)
+    def __init__(self, nodes: Optional[FlatNodes], weighted: bool, precision="auto", device: int = -1,
+                 rank: int = 0, world: int = 1, _handle=None):
+        if _handle is None:
+            p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+            self._h = ctypes.c_void_p()
+            L.check(L.lib().ff_plan_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(self._h), err, L.ERRLEN), err)
+        else:
+            self._h = _handle
         self.info = ff_plan_info()
         L.lib().ff_plan_info_get(self._h, ctypes.byref(self.info))
+
+    @classmethod
+    def from_leaves(cls, tree: "Tree", leaf_ptr, leaf_idx, leaf_val, weighted: bool, leave_unnormalized: bool = False,
+                    precision="auto", device: int = -1, rank: int = 0, world: int = 1) -> "Plan":
+        """Stage A on the device, then staging (ff_plan_create_from_leaves)."""
+        leaf_ptr = np.ascontiguousarray(leaf_ptr, dtype=np.int64)
+        leaf_idx = np.ascontiguousarray(leaf_idx, dtype=np.int64)
+        leaf_val = np.ascontiguousarray(leaf_val, dtype=np.float64)
+        o, err, h = _opts(weighted, precision, device, rank, world), L.errbuf(), ctypes.c_void_p()
+        L.check(L.lib().ff_plan_create_from_leaves(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data,
+                                                   leaf_idx.ctypes.data, leaf_val.ctypes.data,
+                                                   1 if leave_unnormalized else 0, ctypes.byref(o),
+                                                   ctypes.byref(h), err, L.ERRLEN), err)
+        return cls(None, weighted, _handle=h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -211,24 +211,20 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     lap(2);
 
     fputs("Converting abundances\n", stderr);  // unifrac.go:101
-    ff_flat *flat = nullptr;
-    if (ff_flatten(table, tree, f.nnorm, &flat, err, sizeof err)) {
-        ff_table_free(table);
-        ff_tree_free(tree);
-        return die(err);
-    }
+    std::vector<int64_t> leaf_ptr, leaf_idx;
+    std::vector<double> leaf_val;
+    ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val);
     const int64_t n = ff_table_num_samples(table);
     ff_table_free(table);
-    ff_tree_free(tree);
     lap(3);
 
     fputs("Calculating distances\n", stderr);  // unifrac.go:122
-    ff_problem p;
-    ff_flat_problem(flat, &p);
     std::vector<double> out((size_t)ff_num_pairs(n));
     ff_plan_info info{};
-    rc = ff::unifrac_dists_info(&p, &opt, out.data(), &info, err, sizeof err);
-    ff_flat_free(flat);
+    // stage A (abundanceToFlatNodes + normalizeFlatNodes) runs on the device, then stage B
+    rc = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0, &opt,
+                                 out.data(), &info, err, sizeof err);
+    ff_tree_free(tree);
     if (rc) return die(err);
     lap(4);
 

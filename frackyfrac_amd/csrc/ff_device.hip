@@ -266,6 +266,92 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
     *pj = k - i * (i - 1) / 2;
 }
 
+// ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
+//
+// S[b][s] (binary64, branch-major) starts as the leaf values.  Internal nodes are then
+// filled level by level from the deepest level up; a node adds its children's sums in
+// ascending child order, which is the order of the reference's recursion (:35-37), so
+// every sum carries the reference's roundings.
+
+__global__ void stage_a_scatter_kernel(const int64_t *__restrict__ leaf_ptr,
+                                       const int64_t *__restrict__ leaf_idx,
+                                       const double *__restrict__ leaf_val,
+                                       const int64_t *__restrict__ size, double *__restrict__ S,
+                                       int64_t ld)
+{
+    const int64_t s = blockIdx.x;
+    for (int64_t t = leaf_ptr[s] + threadIdx.x; t < leaf_ptr[s + 1]; t += blockDim.x) {
+        const int64_t id = leaf_idx[t];
+        const double a = leaf_val[t];
+        if (size[id] == 1 && a > 0) S[id * ld + s] = a;  // leaves only, if a > 0 (:39-42)
+    }
+}
+
+// One tree level: nodes[level_begin .. level_end) are the internal nodes of that level.
+__global__ void stage_a_level_kernel(const int32_t *__restrict__ nodes, int level_begin, int level_end,
+                                     const int64_t *__restrict__ child_ptr,
+                                     const int32_t *__restrict__ child_idx, double *__restrict__ S,
+                                     int64_t ld, int64_t n_samples)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = level_begin + blockIdx.y;
+    if (s >= n_samples || n >= level_end) return;
+    const int32_t id = nodes[n];
+    double sum = 0.0;
+    for (int64_t c = child_ptr[id]; c < child_ptr[id + 1]; ++c) sum += S[(int64_t)child_idx[c] * ld + s];
+    S[(int64_t)id * ld + s] = sum;
+}
+
+// Per sample: number of flat nodes (sum > 0, :49) and normalizeFlatNodes' divisor: the sum
+// of ALL flat-node abundances in ascending id (:60-63).
+__global__ void stage_a_count_kernel(const double *__restrict__ S, int64_t ld, int64_t n_branches,
+                                     int64_t n_samples, int64_t *__restrict__ count,
+                                     double *__restrict__ divisor)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_samples) return;
+    double total = 0.0;
+    int64_t k = 0;
+#pragma unroll 8
+    for (int64_t b = 0; b < n_branches; ++b) {
+        const double v = S[b * ld + s];
+        if (v > 0) {
+            total += v;
+            ++k;
+        }
+    }
+    count[s] = k;
+    divisor[s] = total;
+}
+
+// Dense sums -> CSR flat nodes in ascending id, normalised (:64-66) unless -l; also the
+// sample's weight sum_b l_b * x_s(b), which only steers the choice of the fixed-point scale.
+__global__ void stage_a_fill_kernel(const double *__restrict__ S, int64_t ld, int64_t n_branches,
+                                    int64_t n_samples, const int64_t *__restrict__ indptr,
+                                    const double *__restrict__ divisor, int normalize,
+                                    const double *__restrict__ branch_len,
+                                    int32_t *__restrict__ ids, double *__restrict__ abnd,
+                                    double *__restrict__ weight)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_samples) return;
+    int64_t pos = indptr[s];
+    const double d = divisor[s];
+    double w = 0.0;
+#pragma unroll 8
+    for (int64_t b = 0; b < n_branches; ++b) {
+        const double v = S[b * ld + s];
+        if (v > 0) {
+            const double x = normalize ? v / d : v;
+            ids[pos] = (int32_t)b;
+            abnd[pos] = x;
+            w += branch_len[b] * x;
+            ++pos;
+        }
+    }
+    weight[s] = w;
+}
+
 // Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
 //
 // Rounding every staged value to an integer leaves U with an error of about
@@ -494,6 +580,31 @@ int validate_problem(const ff_problem *p, char *err, size_t errlen)
     return FF_OK;
 }
 
+// The inputs of unifracDists resident on the device, plus the small host-side facts the
+// staging decisions need.  Filled either from a host ff_problem (csr_from_host) or by
+// stage A on the device (csr_from_leaves).
+struct DeviceCsr {
+    int64_t N = 0, B = 0, nnz = 0;
+    int64_t *d_indptr = nullptr;
+    int32_t *d_ids = nullptr;
+    double *d_abnd = nullptr;
+    double *d_len = nullptr;
+    std::vector<int64_t> h_indptr;  // [N+1]
+    std::vector<double> h_len;      // [B] treeDists
+    std::vector<double> h_weight;   // [N] sum_b l_b * x_s(b)
+    void release()
+    {
+        (void)hipFree(d_indptr);
+        (void)hipFree(d_ids);
+        (void)hipFree(d_abnd);
+        (void)hipFree(d_len);
+        d_indptr = nullptr;
+        d_ids = nullptr;
+        d_abnd = nullptr;
+        d_len = nullptr;
+    }
+};
+
 // Chooses the arithmetic and, for FIXED32, the binary scale and the integer branch lengths.
 struct Quant {
     bool fixed_ok = false;
@@ -503,12 +614,12 @@ struct Quant {
     std::string why_not;
 };
 
-Quant choose_quant(const ff_problem *p, bool weighted)
+Quant choose_quant(const DeviceCsr &c, bool weighted)
 {
     Quant q;
-    const int64_t B = p->n_branches, N = p->n_samples;
+    const int64_t B = c.B, N = c.N;
     for (int64_t b = 0; b < B; ++b)
-        if (!std::isfinite(p->branch_len[b]) || p->branch_len[b] < 0) {
+        if (!std::isfinite(c.h_len[(size_t)b]) || c.h_len[(size_t)b] < 0) {
             q.why_not = "negative or non-finite branch length";
             return q;
         }
@@ -517,16 +628,14 @@ Quant choose_quant(const ff_problem *p, bool weighted)
         double wmax = 0, wmin_pos = INFINITY;
         int64_t nnz_max = 0;
         for (int64_t s = 0; s < N; ++s) {
-            double w = 0;
-            for (int64_t t = p->indptr[s]; t < p->indptr[s + 1]; ++t)
-                w += p->branch_len[p->branch_id[t]] * p->abnd[t];
+            const double w = c.h_weight[(size_t)s];
             if (!std::isfinite(w)) {
                 q.why_not = "non-finite sample weight";
                 return q;
             }
             wmax = std::max(wmax, w);
             if (w > 0) wmin_pos = std::min(wmin_pos, w);
-            nnz_max = std::max(nnz_max, p->indptr[s + 1] - p->indptr[s]);
+            nnz_max = std::max(nnz_max, c.h_indptr[(size_t)s + 1] - c.h_indptr[(size_t)s]);
         }
         if (wmax == 0) {  // every distance is 0/0
             q.fixed_ok = true;
@@ -548,15 +657,14 @@ Quant choose_quant(const ff_problem *p, bool weighted)
     double total = 0;
     int e_exact = -2000;
     for (int64_t b = 0; b < B; ++b) {
-        double l = p->branch_len[b];
+        const double l = c.h_len[(size_t)b];
         total += l;
         if (l == 0) continue;
         int ex;
-        double m = std::frexp(l, &ex);  // l = m * 2^ex, 0.5 <= m < 1
-        // lowest set bit of the 53-bit mantissa
-        uint64_t mi = (uint64_t)std::ldexp(m, 53);
-        int tz = __builtin_ctzll(mi);
-        int lowbit = ex - 53 + tz;  // l is a multiple of 2^lowbit
+        const double m = std::frexp(l, &ex);  // l = m * 2^ex, 0.5 <= m < 1
+        const uint64_t mi = (uint64_t)std::ldexp(m, 53);
+        const int tz = __builtin_ctzll(mi);
+        const int lowbit = ex - 53 + tz;  // l is a multiple of 2^lowbit
         e_exact = std::max(e_exact, -lowbit);
     }
     q.klen.assign((size_t)B, 0);
@@ -575,7 +683,8 @@ Quant choose_quant(const ff_problem *p, bool weighted)
         q.e = ex - 1;
         q.lengths_exact = 0;
     }
-    for (int64_t b = 0; b < B; ++b) q.klen[(size_t)b] = (uint32_t)std::llrint(std::ldexp(p->branch_len[b], q.e));
+    for (int64_t b = 0; b < B; ++b)
+        q.klen[(size_t)b] = (uint32_t)std::llrint(std::ldexp(c.h_len[(size_t)b], q.e));
     q.fixed_ok = true;
     return q;
 }
@@ -715,7 +824,9 @@ void plan_free_device(ff_plan *pl)
     }
 }
 
-int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char *err, size_t errlen)
+// Picks the device (it must be a gfx950) and fills the shard geometry.
+int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDeviceProp_t *prop, char *err,
+               size_t errlen)
 {
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -728,25 +839,197 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
         FF_HIP(hipSetDevice(o->device));
     }
     FF_HIP(hipGetDevice(&pl->device));
-    hipDeviceProp_t prop;
-    FF_HIP(hipGetDeviceProperties(&prop, pl->device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("FF_ALLOW_ANY_ARCH"))
+    FF_HIP(hipGetDeviceProperties(prop, pl->device));
+    if (strncmp(prop->gcnArchName, "gfx950", 6) != 0 && !getenv("FF_ALLOW_ANY_ARCH"))
         return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d is %s; this engine is built for gfx950 only",
-                        pl->device, prop.gcnArchName);
-    const int64_t N = p->n_samples, B = p->n_branches;
-    const bool weighted = o->weighted != 0;
-    pl->weighted = weighted;
+                        pl->device, prop->gcnArchName);
+    pl->weighted = o->weighted != 0;
     ff_plan_info &inf = pl->info;
     inf.n_samples = N;
     inf.n_branches = B;
-    inf.n_compute_units = prop.multiProcessorCount;
+    inf.n_compute_units = prop->multiProcessorCount;
     int rc = ff_shard_rows(N, o->rank, o->world, &inf.row_begin, &inf.row_end);
     if (rc) return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
-    inf.slot_begin = inf.row_begin * (inf.row_begin - 1) / 2;
-    inf.slot_end = inf.row_end * (inf.row_end - 1) / 2;
-    if (inf.row_begin == 0) inf.slot_begin = 0;
-    if (inf.row_end == 0) inf.slot_end = 0;
+    inf.slot_begin = inf.row_begin > 0 ? inf.row_begin * (inf.row_begin - 1) / 2 : 0;
+    inf.slot_end = inf.row_end > 0 ? inf.row_end * (inf.row_end - 1) / 2 : 0;
+    return FF_OK;
+}
+
+// Host flat nodes -> device (the inner-seam entry: ff_plan_create / ff_unifrac_dists).
+int csr_from_host(const ff_problem *p, DeviceCsr *c, char *err, size_t errlen)
+{
+    const int64_t N = p->n_samples, B = p->n_branches;
+    c->N = N;
+    c->B = B;
+    c->nnz = N > 0 ? p->indptr[N] : 0;
+    c->h_indptr.assign((size_t)N + 1, 0);
+    if (N > 0) memcpy(c->h_indptr.data(), p->indptr, sizeof(int64_t) * (size_t)(N + 1));
+    c->h_len.assign(p->branch_len, p->branch_len + B);
+    c->h_weight.assign((size_t)N, 0.0);
+    for (int64_t s = 0; s < N; ++s) {
+        double w = 0;
+        for (int64_t t = p->indptr[s]; t < p->indptr[s + 1]; ++t) w += p->branch_len[p->branch_id[t]] * p->abnd[t];
+        c->h_weight[(size_t)s] = w;
+    }
+    FF_HIP(hipMalloc(&c->d_indptr, sizeof(int64_t) * (size_t)(N + 1)));
+    FF_HIP(hipMalloc(&c->d_ids, sizeof(int32_t) * (size_t)std::max<int64_t>(c->nnz, 1)));
+    FF_HIP(hipMalloc(&c->d_abnd, sizeof(double) * (size_t)std::max<int64_t>(c->nnz, 1)));
+    FF_HIP(hipMalloc(&c->d_len, sizeof(double) * (size_t)std::max<int64_t>(B, 1)));
+    FF_HIP(hipMemcpy(c->d_indptr, c->h_indptr.data(), sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
+    if (c->nnz > 0) {
+        FF_HIP(hipMemcpy(c->d_ids, p->branch_id, sizeof(int32_t) * (size_t)c->nnz, hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(c->d_abnd, p->abnd, sizeof(double) * (size_t)c->nnz, hipMemcpyHostToDevice));
+    }
+    if (B > 0) FF_HIP(hipMemcpy(c->d_len, p->branch_len, sizeof(double) * (size_t)B, hipMemcpyHostToDevice));
+    return FF_OK;
+}
+
+// Stage A on the device: leaf values -> flat nodes.  Returns
+// FF_ERR_INTERNAL + *too_deep when the tree has more levels than it is worth launching
+// kernels for (a caterpillar); the caller then flattens on the host.
+int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const int64_t *leaf_idx,
+                    const double *leaf_val, bool normalize, DeviceCsr *c, bool *too_deep, char *err,
+                    size_t errlen)
+{
+    *too_deep = false;
+    const int64_t B = (int64_t)t->size.size();
+    c->N = N;
+    c->B = B;
+    c->h_len = t->dist;
+    // levels: depth of every node; internal nodes grouped by level, deepest first
+    std::vector<int32_t> depth((size_t)B, 0);
+    int32_t max_depth = 0;
+    for (int64_t id = 1; id < B; ++id) {
+        depth[(size_t)id] = depth[(size_t)t->parent[(size_t)id]] + 1;
+        max_depth = std::max(max_depth, depth[(size_t)id]);
+    }
+    if (max_depth > 4096) {
+        *too_deep = true;
+        return FF_ERR_INTERNAL;
+    }
+    std::vector<int64_t> child_ptr((size_t)B + 1, 0);
+    std::vector<int32_t> child_idx;
+    child_idx.reserve((size_t)B);
+    std::vector<std::vector<int32_t>> by_level((size_t)max_depth + 1);
+    for (int64_t id = 0; id < B; ++id) {
+        const int64_t end = id + t->size[(size_t)id];
+        for (int64_t ch = id + 1; ch < end; ch += t->size[(size_t)ch]) child_idx.push_back((int32_t)ch);  // ascending
+        child_ptr[(size_t)id + 1] = (int64_t)child_idx.size();
+        if (t->size[(size_t)id] > 1) by_level[(size_t)depth[(size_t)id]].push_back((int32_t)id);
+    }
+    std::vector<int32_t> order;
+    std::vector<int> level_ptr{0};
+    for (int32_t L = max_depth; L >= 0; --L) {
+        order.insert(order.end(), by_level[(size_t)L].begin(), by_level[(size_t)L].end());
+        level_ptr.push_back((int)order.size());
+    }
+    const int64_t n_leafvals = leaf_ptr[N];
+    for (int64_t k = 0; k < n_leafvals; ++k)
+        if (leaf_idx[k] < 0 || leaf_idx[k] >= B)
+            return ff::fail(FF_ERR_ARG, err, errlen, "leaf index %lld out of range", (long long)leaf_idx[k]);
+    const int64_t ld = round_up(std::max<int64_t>(N, 1), 64);
+    double *d_S = nullptr, *d_lval = nullptr, *d_div = nullptr, *d_weight = nullptr;
+    int64_t *d_lptr = nullptr, *d_lidx = nullptr, *d_size = nullptr, *d_cptr = nullptr, *d_count = nullptr;
+    int32_t *d_cidx = nullptr, *d_order = nullptr;
+    auto cleanup = [&] {
+        (void)hipFree(d_S); (void)hipFree(d_lval); (void)hipFree(d_div); (void)hipFree(d_weight);
+        (void)hipFree(d_lptr); (void)hipFree(d_lidx); (void)hipFree(d_size); (void)hipFree(d_cptr);
+        (void)hipFree(d_count); (void)hipFree(d_cidx); (void)hipFree(d_order);
+    };
+#define FF_HIP_C(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            cleanup();                                                                          \
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: %s failed: %s", #call,             \
+                            hipGetErrorString(e_));                                             \
+        }                                                                                       \
+    } while (0)
+    const size_t s_bytes = sizeof(double) * (size_t)std::max<int64_t>(B, 1) * (size_t)ld;
+    FF_HIP_C(hipMalloc(&d_S, s_bytes));
+    FF_HIP_C(hipMemset(d_S, 0, s_bytes));
+    FF_HIP_C(hipMalloc(&d_lptr, sizeof(int64_t) * (size_t)(N + 1)));
+    FF_HIP_C(hipMalloc(&d_lidx, sizeof(int64_t) * (size_t)std::max<int64_t>(n_leafvals, 1)));
+    FF_HIP_C(hipMalloc(&d_lval, sizeof(double) * (size_t)std::max<int64_t>(n_leafvals, 1)));
+    FF_HIP_C(hipMalloc(&d_size, sizeof(int64_t) * (size_t)std::max<int64_t>(B, 1)));
+    FF_HIP_C(hipMalloc(&d_cptr, sizeof(int64_t) * (size_t)(B + 1)));
+    FF_HIP_C(hipMalloc(&d_cidx, sizeof(int32_t) * std::max<size_t>(child_idx.size(), 1)));
+    FF_HIP_C(hipMalloc(&d_order, sizeof(int32_t) * std::max<size_t>(order.size(), 1)));
+    FF_HIP_C(hipMalloc(&d_count, sizeof(int64_t) * (size_t)std::max<int64_t>(N, 1)));
+    FF_HIP_C(hipMalloc(&d_div, sizeof(double) * (size_t)std::max<int64_t>(N, 1)));
+    FF_HIP_C(hipMalloc(&d_weight, sizeof(double) * (size_t)std::max<int64_t>(N, 1)));
+    FF_HIP_C(hipMalloc(&c->d_len, sizeof(double) * (size_t)std::max<int64_t>(B, 1)));
+    FF_HIP_C(hipMemcpy(d_lptr, leaf_ptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
+    if (n_leafvals > 0) {
+        FF_HIP_C(hipMemcpy(d_lidx, leaf_idx, sizeof(int64_t) * (size_t)n_leafvals, hipMemcpyHostToDevice));
+        FF_HIP_C(hipMemcpy(d_lval, leaf_val, sizeof(double) * (size_t)n_leafvals, hipMemcpyHostToDevice));
+    }
+    if (B > 0) {
+        FF_HIP_C(hipMemcpy(d_size, t->size.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice));
+        FF_HIP_C(hipMemcpy(c->d_len, t->dist.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice));
+    }
+    FF_HIP_C(hipMemcpy(d_cptr, child_ptr.data(), sizeof(int64_t) * (size_t)(B + 1), hipMemcpyHostToDevice));
+    if (!child_idx.empty())
+        FF_HIP_C(hipMemcpy(d_cidx, child_idx.data(), sizeof(int32_t) * child_idx.size(), hipMemcpyHostToDevice));
+    if (!order.empty())
+        FF_HIP_C(hipMemcpy(d_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+    if (N > 0 && B > 0) {
+        if (n_leafvals > 0)
+            stage_a_scatter_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_lptr, d_lidx, d_lval, d_size, d_S, ld);
+        const unsigned sblocks = (unsigned)((N + 255) / 256);
+        for (size_t L = 0; L + 1 < level_ptr.size(); ++L) {
+            int b0 = level_ptr[L], b1 = level_ptr[L + 1];
+            while (b0 < b1) {  // grid.y is limited to 65535
+                const int chunk = std::min(b1 - b0, 65535);
+                stage_a_level_kernel<<<dim3(sblocks, (unsigned)chunk), dim3(256)>>>(d_order, b0, b0 + chunk, d_cptr,
+                                                                                    d_cidx, d_S, ld, N);
+                b0 += chunk;
+            }
+        }
+        stage_a_count_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, B, N, d_count, d_div);
+    }
+    FF_HIP_C(hipGetLastError());
+    std::vector<int64_t> cnt((size_t)N, 0);
+    if (N > 0 && B > 0) FF_HIP_C(hipMemcpy(cnt.data(), d_count, sizeof(int64_t) * (size_t)N, hipMemcpyDeviceToHost));
+    c->h_indptr.assign((size_t)N + 1, 0);
+    for (int64_t s2 = 0; s2 < N; ++s2) c->h_indptr[(size_t)s2 + 1] = c->h_indptr[(size_t)s2] + cnt[(size_t)s2];
+    c->nnz = c->h_indptr[(size_t)N];
+    FF_HIP_C(hipMalloc(&c->d_indptr, sizeof(int64_t) * (size_t)(N + 1)));
+    FF_HIP_C(hipMalloc(&c->d_ids, sizeof(int32_t) * (size_t)std::max<int64_t>(c->nnz, 1)));
+    FF_HIP_C(hipMalloc(&c->d_abnd, sizeof(double) * (size_t)std::max<int64_t>(c->nnz, 1)));
+    FF_HIP_C(hipMemcpy(c->d_indptr, c->h_indptr.data(), sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
+    c->h_weight.assign((size_t)N, 0.0);
+    if (N > 0 && B > 0) {
+        stage_a_fill_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, B, N, c->d_indptr, d_div,
+                                                                           normalize ? 1 : 0, c->d_len, c->d_ids,
+                                                                           c->d_abnd, d_weight);
+        FF_HIP_C(hipGetLastError());
+        FF_HIP_C(hipMemcpy(c->h_weight.data(), d_weight, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+    }
+#undef FF_HIP_C
+    cleanup();
+    return FF_OK;
+}
+
+// Stages the device-resident flat nodes and builds the schedule.  Takes ownership of *c.
+int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, ff_plan *pl, char *err,
+               size_t errlen)
+{
+    const int64_t N = c->N, B = c->B, nnz = c->nnz;
+    const bool weighted = pl->weighted != 0;
+    ff_plan_info &inf = pl->info;
     const int64_t n_slots = inf.slot_end - inf.slot_begin;
+    pl->d_len = c->d_len;  // the plan owns the device arrays from here on
+    pl->d_indptr = c->d_indptr;
+    pl->d_ids = c->d_ids;
+    pl->d_abnd = c->d_abnd;
+    c->d_len = nullptr;
+    c->d_indptr = nullptr;
+    c->d_ids = nullptr;
+    c->d_abnd = nullptr;
+    int64_t *d_indptr = pl->d_indptr;
+    int32_t *d_ids = pl->d_ids;
+    double *d_abnd = pl->d_abnd, *d_len = pl->d_len;
 
     Quant q;
     int prec = o->precision;
@@ -756,7 +1039,7 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
     if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)B <= 4294967296.0)
         prec = FF_PRECISION_EXACT64;
     if (prec != FF_PRECISION_EXACT64) {
-        q = choose_quant(p, weighted);
+        q = choose_quant(*c, weighted);
         if (!q.fixed_ok) {
             if (prec == FF_PRECISION_FIXED32)
                 return ff::fail(FF_ERR_ARG, err, errlen, "FIXED32 not applicable: %s", q.why_not.c_str());
@@ -766,32 +1049,6 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
         }
     }
     inf.precision = prec;
-    const int64_t nnz = N > 0 ? p->indptr[N] : 0;
-
-    // CSR to the device (shared by both stagers)
-    int64_t *d_indptr = nullptr;
-    int32_t *d_ids = nullptr;
-    double *d_abnd = nullptr, *d_len = nullptr;
-    auto free_csr = [&] {
-        (void)hipFree(d_indptr);
-        (void)hipFree(d_ids);
-        (void)hipFree(d_abnd);
-    };
-    FF_HIP(hipMalloc(&d_indptr, sizeof(int64_t) * (size_t)(N + 1)));
-    FF_HIP(hipMalloc(&d_ids, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
-    FF_HIP(hipMalloc(&d_abnd, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
-    FF_HIP(hipMalloc(&d_len, sizeof(double) * (size_t)std::max<int64_t>(B, 1)));
-    pl->d_len = d_len;
-    if (N > 0) FF_HIP(hipMemcpy(d_indptr, p->indptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
-    else {
-        int64_t z = 0;
-        FF_HIP(hipMemcpy(d_indptr, &z, sizeof z, hipMemcpyHostToDevice));
-    }
-    if (nnz > 0) {
-        FF_HIP(hipMemcpy(d_ids, p->branch_id, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-        FF_HIP(hipMemcpy(d_abnd, p->abnd, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
-    }
-    if (B > 0) FF_HIP(hipMemcpy(d_len, p->branch_len, sizeof(double) * (size_t)B, hipMemcpyHostToDevice));
 
     if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
@@ -828,7 +1085,6 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
             if (wmax <= 2147483647ull) break;
             if (!weighted || attempt >= 3) {
                 (void)hipFree(d_klen);
-                free_csr();
                 return ff::fail(FF_ERR_INTERNAL, err, errlen, "FIXED32 staging overflow (max column sum %llu)", wmax);
             }
             --e;  // rounding pushed a column over the bound: drop one bit
@@ -893,17 +1149,31 @@ int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char
     if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && n_slots > 0 &&
         env_int("FF_REFINE", 1)) {
         pl->refine = true;
-        pl->d_indptr = d_indptr;
-        pl->d_ids = d_ids;
-        pl->d_abnd = d_abnd;
         pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
         FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)pl->refine_cap));
         FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long)));
         FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long)));
     } else {
-        free_csr();
+        (void)hipFree(pl->d_indptr);
+        (void)hipFree(pl->d_ids);
+        (void)hipFree(pl->d_abnd);
+        pl->d_indptr = nullptr;
+        pl->d_ids = nullptr;
+        pl->d_abnd = nullptr;
     }
     return FF_OK;
+}
+
+int plan_create_impl(const ff_problem *p, const ff_options *o, ff_plan *pl, char *err, size_t errlen)
+{
+    hipDeviceProp_t prop;
+    int rc = plan_begin(o, p->n_samples, p->n_branches, pl, &prop, err, errlen);
+    if (rc) return rc;
+    DeviceCsr c;
+    rc = csr_from_host(p, &c, err, errlen);
+    if (rc == FF_OK) rc = plan_build(o, &c, prop, pl, err, errlen);
+    c.release();
+    return rc;
 }
 
 int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *err, size_t errlen)
@@ -1065,16 +1335,111 @@ int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char
     return ff::unifrac_dists_info(p, o, out, nullptr, err, errlen);
 }
 
+int ff_flatten_device(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr, const int64_t *leaf_idx,
+                      const double *leaf_val, int leave_unnormalized, ff_flat **flat, char *err, size_t errlen)
+{
+    if (!tree || !leaf_ptr || !flat || n_samples < 0 || (leaf_ptr[n_samples] > 0 && (!leaf_idx || !leaf_val)))
+        return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten_device: bad argument");
+    ff_options o;
+    ff_options_default(&o);
+    ff_plan tmp;  // only to run the device checks of plan_begin
+    hipDeviceProp_t prop;
+    int rc = plan_begin(&o, n_samples, (int64_t)tree->size.size(), &tmp, &prop, err, errlen);
+    if (rc) return rc;
+    DeviceCsr c;
+    bool too_deep = false;
+    rc = csr_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized, &c, &too_deep, err,
+                         errlen);
+    if (too_deep) {
+        c.release();
+        return ff_flatten_leaf_csr(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, flat, err,
+                                   errlen);
+    }
+    if (rc) {
+        c.release();
+        return rc;
+    }
+    auto *f = new ff_flat();
+    f->n_samples = c.N;
+    f->n_branches = c.B;
+    f->branch_len = c.h_len;
+    f->indptr = c.h_indptr;
+    f->branch_id.resize((size_t)c.nnz);
+    f->abnd.resize((size_t)c.nnz);
+    hipError_t he = hipSuccess;
+    if (c.nnz > 0) {
+        he = hipMemcpy(f->branch_id.data(), c.d_ids, sizeof(int32_t) * (size_t)c.nnz, hipMemcpyDeviceToHost);
+        if (he == hipSuccess)
+            he = hipMemcpy(f->abnd.data(), c.d_abnd, sizeof(double) * (size_t)c.nnz, hipMemcpyDeviceToHost);
+    }
+    c.release();
+    if (he != hipSuccess) {
+        delete f;
+        return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: download of flat nodes failed: %s", hipGetErrorString(he));
+    }
+    *flat = f;
+    return FF_OK;
+}
+
+int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                               const int64_t *leaf_idx, const double *leaf_val, int leave_unnormalized,
+                               const ff_options *o, ff_plan **plan, char *err, size_t errlen)
+{
+    if (!plan) return ff::fail(FF_ERR_ARG, err, errlen, "null plan pointer");
+    *plan = nullptr;
+    if (!tree || !leaf_ptr || n_samples < 0 || (leaf_ptr[n_samples] > 0 && (!leaf_idx || !leaf_val)))
+        return ff::fail(FF_ERR_ARG, err, errlen, "ff_plan_create_from_leaves: bad argument");
+    ff_options dflt;
+    ff_options_default(&dflt);
+    if (!o) o = &dflt;
+    if (o->world < 1 || o->rank < 0 || o->rank >= o->world)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
+    if (o->precision < FF_PRECISION_AUTO || o->precision > FF_PRECISION_EXACT64)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad precision %d", o->precision);
+    const int64_t B = (int64_t)tree->size.size();
+    if (B > (int64_t)INT32_MAX - 64 || n_samples > (int64_t)1 << 22)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad problem size N=%lld B=%lld", (long long)n_samples, (long long)B);
+    auto *pl = new ff_plan();
+    hipDeviceProp_t prop;
+    int rc = plan_begin(o, n_samples, B, pl, &prop, err, errlen);
+    DeviceCsr c;
+    if (rc == FF_OK) {
+        bool too_deep = false;
+        rc = csr_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized, &c, &too_deep, err,
+                             errlen);
+        if (too_deep) {  // a caterpillar: flatten on the host instead
+            c.release();
+            ff_flat *flat = nullptr;
+            rc = ff_flatten_leaf_csr(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, &flat, err,
+                                     errlen);
+            if (rc == FF_OK) {
+                ff_problem p;
+                ff_flat_problem(flat, &p);
+                rc = csr_from_host(&p, &c, err, errlen);
+                ff_flat_free(flat);
+            }
+        }
+    }
+    if (rc == FF_OK) rc = plan_build(o, &c, prop, pl, err, errlen);
+    c.release();
+    if (rc) {
+        plan_free_device(pl);
+        delete pl;
+        return rc;
+    }
+    *plan = pl;
+    return FF_OK;
+}
+
 }  // extern "C"
 
-// ff_unifrac_dists that also reports what the staging decided (used by the CLI's -stats).
-int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info_out,
-                           char *err, size_t errlen)
+// Runs a freshly created plan, copies the shard's slots into out (host) and destroys the
+// plan.  If FIXED32's refinement queue overflowed, `recreate` builds an EXACT64 plan and
+// the shard is repeated with it.
+int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
+                         ff_plan_info *info_out, char *err, size_t errlen)
 {
-    if (!out && p && p->n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
-    ff_plan *pl = nullptr;
-    int rc = ff_plan_create(p, o, &pl, err, errlen);
-    if (rc) return rc;
+    int rc = FF_OK;
     const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
     if (n_slots > 0) {
         double *d_out = nullptr;
@@ -1090,16 +1455,8 @@ int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out
             // mostly replicates -- run the whole shard in binary64 instead
             ff_plan_destroy(pl);
             pl = nullptr;
-            ff_options o2;
-            if (o) o2 = *o; else ff_options_default(&o2);
-            o2.precision = FF_PRECISION_EXACT64;
-            rc = ff_plan_create(p, &o2, &pl, err, errlen);
+            rc = recreate_exact64(&pl);
             if (rc == FF_OK) rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
-            if (rc != FF_OK) {
-                (void)hipFree(d_out);
-                ff_plan_destroy(pl);
-                return rc;
-            }
         }
         if (rc == FF_OK) {
             he = hipMemcpy(out + pl->info.slot_begin, d_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
@@ -1111,4 +1468,41 @@ int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out
     if (info_out && pl) *info_out = pl->info;
     ff_plan_destroy(pl);
     return rc;
+}
+
+// ff_unifrac_dists that also reports what the staging decided (used by the CLI's -stats).
+int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info_out,
+                           char *err, size_t errlen)
+{
+    if (!out && p && p->n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    ff_plan *pl = nullptr;
+    int rc = ff_plan_create(p, o, &pl, err, errlen);
+    if (rc) return rc;
+    auto again = [&](ff_plan **np) {
+        ff_options o2;
+        if (o) o2 = *o; else ff_options_default(&o2);
+        o2.precision = FF_PRECISION_EXACT64;
+        return ff_plan_create(p, &o2, np, err, errlen);
+    };
+    return ff::run_plan_to_host(pl, again, out, info_out, err, errlen);
+}
+
+// unifrac() with stage A on the device (used by ff_unifrac and the CLI).
+int ff::unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                            const int64_t *leaf_idx, const double *leaf_val, int leave_unnormalized,
+                            const ff_options *o, double *out, ff_plan_info *info_out, char *err, size_t errlen)
+{
+    if (!out && n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    ff_plan *pl = nullptr;
+    int rc = ff_plan_create_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, o, &pl,
+                                        err, errlen);
+    if (rc) return rc;
+    auto again = [&](ff_plan **np) {
+        ff_options o2;
+        if (o) o2 = *o; else ff_options_default(&o2);
+        o2.precision = FF_PRECISION_EXACT64;
+        return ff_plan_create_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, &o2, np,
+                                          err, errlen);
+    };
+    return ff::run_plan_to_host(pl, again, out, info_out, err, errlen);
 }

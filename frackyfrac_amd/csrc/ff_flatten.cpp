@@ -102,6 +102,38 @@ int flatten_impl(const ff_tree &t, int64_t ns, const int64_t *leaf_ptr, const in
 
 }  // namespace
 
+namespace ff {
+
+// abnd[tree.Name] for leaves only (unifrac.go:38-43): species -> leaf ids resolved once;
+// a name carried by several leaves feeds each of them; a key naming an internal node is
+// never looked up.
+void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
+                    std::vector<int64_t> *idx, std::vector<double> *val)
+{
+    std::vector<const std::vector<int64_t> *> where(tb.species.size(), nullptr);
+    for (size_t k = 0; k < tb.species.size(); ++k) {
+        auto it = tr.leaf_ids.find(tb.species[k]);
+        if (it != tr.leaf_ids.end()) where[k] = &it->second;
+    }
+    const int64_t ns = (int64_t)tb.ptr.size() - 1;
+    ptr->assign((size_t)ns + 1, 0);
+    idx->clear();
+    val->clear();
+    for (int64_t s = 0; s < ns; ++s) {
+        for (int64_t k = tb.ptr[(size_t)s]; k < tb.ptr[(size_t)s + 1]; ++k) {
+            const auto *ids = where[(size_t)tb.key[(size_t)k]];
+            if (!ids) continue;
+            for (int64_t id : *ids) {
+                idx->push_back(id);
+                val->push_back(tb.val[(size_t)k]);
+            }
+        }
+        (*ptr)[(size_t)s + 1] = (int64_t)idx->size();
+    }
+}
+
+}  // namespace ff
+
 extern "C" {
 
 int ff_validate_species(const ff_table *tb, const ff_tree *tr, char *err, size_t errlen)
@@ -136,29 +168,11 @@ int ff_flatten(const ff_table *tb, const ff_tree *tr, int leave_unnormalized, ff
                char *err, size_t errlen)
 {
     if (!tb || !tr || !flat) return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten: null argument");
-    // abnd[tree.Name] for leaves only (unifrac.go:38-43): resolve species -> leaf ids
-    // once; a name carried by several leaves feeds each of them.
-    std::vector<const std::vector<int64_t> *> where(tb->species.size(), nullptr);
-    for (size_t k = 0; k < tb->species.size(); ++k) {
-        auto it = tr->leaf_ids.find(tb->species[k]);
-        if (it != tr->leaf_ids.end()) where[k] = &it->second;
-    }
-    const int64_t ns = (int64_t)tb->ptr.size() - 1;
-    std::vector<int64_t> ptr((size_t)ns + 1, 0), idx;
+    std::vector<int64_t> ptr, idx;
     std::vector<double> val;
-    for (int64_t s = 0; s < ns; ++s) {
-        for (int64_t k = tb->ptr[(size_t)s]; k < tb->ptr[(size_t)s + 1]; ++k) {
-            const auto *ids = where[(size_t)tb->key[(size_t)k]];
-            if (!ids) continue;  // names an internal node: never looked up (Q4)
-            for (int64_t id : *ids) {
-                idx.push_back(id);
-                val.push_back(tb->val[(size_t)k]);
-            }
-        }
-        ptr[(size_t)s + 1] = (int64_t)idx.size();
-    }
-    return ff_flatten_leaf_csr(tr, ns, ptr.data(), idx.data(), val.data(), leave_unnormalized, flat,
-                               err, errlen);
+    ff::table_leaf_csr(*tb, *tr, &ptr, &idx, &val);
+    return ff_flatten_leaf_csr(tr, (int64_t)ptr.size() - 1, ptr.data(), idx.data(), val.data(), leave_unnormalized,
+                               flat, err, errlen);
 }
 
 void ff_flat_free(ff_flat *f) { delete f; }
@@ -177,14 +191,12 @@ void ff_flat_problem(const ff_flat *f, ff_problem *p)
 int ff_unifrac(const ff_table *table, const ff_tree *tree, const ff_options *o,
                int leave_unnormalized, double *out, char *err, size_t errlen)
 {
-    ff_flat *flat = nullptr;
-    int rc = ff_flatten(table, tree, leave_unnormalized, &flat, err, errlen);
-    if (rc) return rc;
-    ff_problem p;
-    ff_flat_problem(flat, &p);
-    rc = ff_unifrac_dists(&p, o, out, err, errlen);
-    ff_flat_free(flat);
-    return rc;
+    if (!table || !tree) return ff::fail(FF_ERR_ARG, err, errlen, "ff_unifrac: null argument");
+    std::vector<int64_t> ptr, idx;
+    std::vector<double> val;
+    ff::table_leaf_csr(*table, *tree, &ptr, &idx, &val);
+    return ff::unifrac_leaves_info(tree, (int64_t)ptr.size() - 1, ptr.data(), idx.data(), val.data(),
+                                   leave_unnormalized, o, out, nullptr, err, errlen);
 }
 
 }  // extern "C"

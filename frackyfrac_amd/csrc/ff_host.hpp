@@ -41,6 +41,15 @@ void parallel_for(int64_t n, unsigned threads,
 // ff_unifrac_dists + the plan's info (info may be null).
 int unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info,
                        char *err, size_t errlen);
+// The same from leaf values: stage A runs on the device.
+int unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                        const int64_t *leaf_idx, const double *leaf_val, int leave_unnormalized,
+                        const ff_options *o, double *out, ff_plan_info *info, char *err, size_t errlen);
+int run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
+                     ff_plan_info *info, char *err, size_t errlen);
+// abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
+void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
+                    std::vector<int64_t> *idx, std::vector<double> *val);
 
 }  // namespace ff
 

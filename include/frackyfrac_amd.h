@@ -110,6 +110,7 @@ int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out,
 /* -- The same path with the staged inputs resident in HBM (benchmarks, pipelines) -- */
 
 typedef struct ff_plan ff_plan; /* staged matrix + tile schedule on one device */
+typedef struct ff_tree ff_tree; /* section 2 */
 
 /* What the staging decided; read back with ff_plan_info. */
 typedef struct ff_plan_info {
@@ -134,6 +135,12 @@ typedef struct ff_plan_info {
  * (DESIGN.md "Data layout"), build the tile schedule.  Synchronous. */
 int ff_plan_create(const ff_problem *p, const ff_options *o, ff_plan **plan,
                    char *err, size_t errlen);
+/* The same from leaf values: stage A runs on the device and the flat nodes never leave
+ * it (this is what ff_unifrac and the frcfrc command use). */
+int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                               const int64_t *leaf_idx, const double *leaf_val,
+                               int leave_unnormalized, const ff_options *o, ff_plan **plan,
+                               char *err, size_t errlen);
 void ff_plan_destroy(ff_plan *plan);
 int ff_plan_info_get(const ff_plan *plan, ff_plan_info *info);
 
@@ -170,7 +177,7 @@ int ff_plan_refined_pairs(ff_plan *plan, int64_t *queued, int64_t *capacity);
 
 /* newick.Node tree as the path uses it (Name, Distance, Children), flattened in
  * the numbering of enumerateNodes (frcfrc/unifrac.go:127-133). */
-typedef struct ff_tree ff_tree;
+/* (typedef struct ff_tree ff_tree; is declared above, next to ff_plan) */
 
 /* Replaces readTree (frcfrc/frcfrc.go:109-114): first tree of a Newick text.
  * "no tree in the given file" when the text holds none. */
@@ -217,11 +224,18 @@ int ff_flatten(const ff_table *table, const ff_tree *tree, int leave_unnormalize
 int ff_flatten_leaf_csr(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
                         const int64_t *leaf_idx, const double *leaf_val,
                         int leave_unnormalized, ff_flat **flat, char *err, size_t errlen);
+/* Stage A on the DEVICE: the same flat nodes, bit for bit (a node
+ * adds its children in ascending order, as the reference's recursion does), computed
+ * level by level over a dense branch-major matrix in HBM.  Trees deeper than 4096
+ * levels are flattened on the host instead. */
+int ff_flatten_device(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
+                      const int64_t *leaf_idx, const double *leaf_val,
+                      int leave_unnormalized, ff_flat **flat, char *err, size_t errlen);
 void ff_flat_free(ff_flat *flat);
 void ff_flat_problem(const ff_flat *flat, ff_problem *p); /* borrowed views */
 
-/* Replaces unifrac (frcfrc/unifrac.go:97-124): flatten + distances into out
- * (host, ff_num_pairs(N) slots).  o->weighted selects the metric. */
+/* Replaces unifrac (frcfrc/unifrac.go:97-124): stage A on the device + distances into
+ * out (host, ff_num_pairs(N) slots).  o->weighted selects the metric. */
 int ff_unifrac(const ff_table *table, const ff_tree *tree, const ff_options *o,
                int leave_unnormalized, double *out, char *err, size_t errlen);
 

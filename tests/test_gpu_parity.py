@@ -259,6 +259,75 @@ def test_bad_problems_are_rejected():
         ff.unifrac_dists(nodes, True, rank=3, world=2)
 
 
+# ---------------------------------------------------------------- stage A on the device
+
+@pytest.mark.parametrize("seed,ns,nl,dens", [(1, 64, 200, 0.1), (2, 33, 1000, 0.02), (3, 8, 50, 0.9), (4, 300, 3000, 0.05)])
+@pytest.mark.parametrize("leave", [False, True])
+def test_stage_a_device_bit_exact(seed, ns, nl, dens, leave):
+    """abundanceToFlatNodes + normalizeFlatNodes on the GPU give the
+    oracle's flat nodes bit for bit (ids, values, order)."""
+    tree, ptr, idx, val = synth.make(ns, nl, dens, seed)
+    T = ff.parse_newick(tree.newick())
+    got = ff.flatten_device(T, ptr, idx, val, leave_unnormalized=leave)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 2 if leave else 0)
+    assert np.array_equal(got.indptr, ip)
+    assert np.array_equal(got.branch_id, on["id"])
+    assert np.array_equal(got.abnd, on["abnd"])
+    assert np.array_equal(got.branch_len, ft.dist)
+
+
+def test_stage_a_device_quirks_and_deep_tree():
+    # multifurcations (order of additions), duplicate leaf names, internal-node keys,
+    # empty samples, zero-length branches
+    tree_text = "((a:1,b:0,c:3,a:2)in:1.5,(d:1e-3,(e:7,f:0.1):2)x:0,g:5)r:9;"
+    table_text = "a:0.1 b:0.7 c:1e-9 in:5\n\ne:3 f:1e10 g:2.5\nd:1\n"
+    T = ff.parse_newick(tree_text)
+    ft = O.flatten_tree(O.parse_newick(tree_text))
+    ptr, idx, val = O.leaf_csr(O.parse_sparse_abundance(table_text), ft)
+    for leave in (False, True):
+        got = ff.flatten_device(T, ptr, idx, val, leave_unnormalized=leave)
+        ip, on = O.flatten_samples(ft, ptr, idx, val, 2 if leave else 0)
+        assert np.array_equal(got.indptr, ip) and np.array_equal(got.branch_id, on["id"])
+        assert np.array_equal(got.abnd, on["abnd"])
+    # a 5000-deep caterpillar exceeds the level limit: the engine flattens on the host
+    n = 5000
+    text = "(" * n + "t0:1" + "".join(",t%d:%d):1" % (k, 1 + k % 3) for k in range(1, n + 1)) + ";"
+    T = ff.parse_newick(text)
+    ft = O.FlatTree(T.names, T.branch_len, T.subtree_size, T.parent)
+    leaves = np.flatnonzero(T.subtree_size == 1)
+    ptr = np.array([0, 3, 5], dtype=np.int64)
+    idx = leaves[[0, 10, 4000, 10, 4999]].astype(np.int64)
+    val = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    got = ff.flatten_device(T, ptr, idx, val)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    assert np.array_equal(got.indptr, ip) and np.array_equal(got.abnd, on["abnd"])
+    plan = ff.Plan.from_leaves(T, ptr, idx, val, True, precision="exact64")
+    import torch
+    out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    plan.run(out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.unifrac_dists(ip, on, ft.dist, True))
+    plan.close()
+
+
+@pytest.mark.parametrize("precision", ["fixed32", "exact64"])
+def test_plan_from_leaves_equals_plan_from_flat_nodes(precision):
+    import torch
+    tree, ptr, idx, val = synth.make(300, 2000, 0.1, 77)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    outs = []
+    for plan in (ff.Plan(nodes, True, precision=precision),
+                 ff.Plan.from_leaves(T, ptr, idx, val, True, precision=precision)):
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        plan.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------- shards
 
 @pytest.mark.parametrize("precision", ["fixed32", "exact64"])
