@@ -72,6 +72,8 @@ SIGNATURES = {
     "ff_table_parse_dense": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_table_parse_sparse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_table_read_file": (c_int, [c_char_p, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_table_parse_mt": (c_int, [c_char_p, c_size_t, c_int, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_table_read_file_mt": (c_int, [c_char_p, c_int, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_table_free": (None, [c_void_p]),
     "ff_table_num_samples": (c_int64, [c_void_p]),
     "ff_table_sample_size": (c_int64, [c_void_p, c_int64]),

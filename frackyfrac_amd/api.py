@@ -141,14 +141,21 @@ class Table:
         return out
 
 
-def parse_abundance(text: str) -> Table:
+def _parse_mt(text: str, sparse: bool, ngoroutines: int) -> Table:
+    data = text.encode("utf-8")
+    h, err = ctypes.c_void_p(), L.errbuf()
+    L.check(L.lib().ff_table_parse_mt(data, len(data), 1 if sparse else 0, ngoroutines, ctypes.byref(h), err, L.ERRLEN), err)
+    return Table(h)
+
+
+def parse_abundance(text: str, ngoroutines: int = 1) -> Table:
     """parser.ParseAbundance (parser/parser.go:21)."""
-    return Table._parse(L.lib().ff_table_parse_dense, text)
+    return _parse_mt(text, False, ngoroutines)
 
 
-def parse_sparse_abundance(text: str) -> Table:
+def parse_sparse_abundance(text: str, ngoroutines: int = 1) -> Table:
     """parser.ParseSparseAbundance (parser/parser.go:85)."""
-    return Table._parse(L.lib().ff_table_parse_sparse, text)
+    return _parse_mt(text, True, ngoroutines)
 
 
 def parse_newick(text: str) -> Tree:

@@ -196,7 +196,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
 
     fputs("Loading abundances\n", stderr);
     ff_table *table = nullptr;
-    if (ff_table_read_file(f.in.empty() ? nullptr : f.in.c_str(), f.sparse, &table, err, sizeof err)) {
+    if (ff_table_read_file_mt(f.in.empty() ? nullptr : f.in.c_str(), f.sparse, (int)f.nt, &table, err, sizeof err)) {
         ff_tree_free(tree);
         return die(err);
     }

@@ -89,155 +89,215 @@ int bad_float(int i, const char *b, const char *e, const char *why, char *err, s
                     ff::go_quote(tok).c_str(), why);
 }
 
+
+
+// ---- row parsers (one line each); keys are species ids of `names` (dense) or of the
+// ---- caller's interner (sparse)
+
+struct LineRef {
+    const char *b, *e;
+};
+
+int parse_dense_row(const char *b, const char *e, const std::vector<int32_t> &names, Row *row, char *err,
+                    size_t errlen)
+{
+    // parseRow, parser.go:59-81: the count is checked before any value is parsed
+    size_t nparts = 0;
+    for (const char *p = b; p < e;) {
+        while (p < e && is_space(*p)) ++p;
+        const char *q = p;
+        while (q < e && !is_space(*q)) ++q;
+        if (q > p) ++nparts;
+        p = q;
+    }
+    if (nparts != names.size())
+        return ff::fail(FF_ERR_PARSE, err, errlen, "has %zu values, expected %zu", nparts, names.size());
+    row->clear();
+    size_t i = 0;
+    for (const char *p = b; p < e;) {
+        while (p < e && is_space(*p)) ++p;
+        const char *q = p;
+        while (q < e && !is_space(*q)) ++q;
+        if (q > p) {
+            double f;
+            const char *why;
+            if (!ff::go_parse_float(p, q, &f, &why)) return bad_float((int)i + 1, p, q, why, err, errlen);
+            if (std::isnan(f) || std::isinf(f) || f < 0) return bad_value((int)i + 1, f, err, errlen);
+            if (f != 0) row->set(names[i], f);
+            ++i;
+        }
+        p = q;
+    }
+    return FF_OK;
+}
+
+template <class Intern>
+int parse_sparse_row(const char *b, const char *e, Intern &&intern, Row *row, char *err, size_t errlen)
+{
+    row->clear();  // a blank line is an empty sample (parser_test.go:29-35)
+    int i = 0;
+    for (const char *p = b; p < e;) {
+        while (p < e && is_space(*p)) ++p;
+        const char *q = p;
+        while (q < e && !is_space(*q)) ++q;
+        if (q > p) {
+            ++i;
+            const char *colon = nullptr;  // splitSparse: the LAST colon (parser.go:129-140)
+            for (const char *c = q; c > p;)
+                if (*--c == ':') {
+                    colon = c;
+                    break;
+                }
+            if (!colon) {
+                std::string tok(p, q);
+                return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: no colon in %s", i, ff::go_quote(tok).c_str());
+            }
+            if (colon == p) return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: empty species name", i);
+            double f;
+            const char *why;
+            if (!ff::go_parse_float(colon + 1, q, &f, &why)) return bad_float(i, colon + 1, q, why, err, errlen);
+            if (std::isnan(f) || std::isinf(f) || f < 0) return bad_value(i, f, err, errlen);
+            if (f == 0)
+                return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: zeros are not allowed in sparse format", i);
+            row->set(intern(p, colon), f);
+        }
+        p = q;
+    }
+    return FF_OK;
+}
+
+// The rows of [first, last) parsed by one thread into a private partial table.
+struct Partial {
+    std::vector<std::string> species;  // sparse only: thread-local dictionary
+    std::unordered_map<std::string, int32_t> species_id;
+    std::vector<int64_t> cnt;          // entries per row
+    std::vector<int32_t> key;
+    std::vector<double> val;
+    int64_t err_line = -1;             // first failing line of this thread
+    int err_code = FF_OK;
+    char err[512] = {0};
+};
+
+int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_table **out, char *err, size_t errlen)
+{
+    if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse: null argument");
+    std::vector<LineRef> lines;
+    {
+        Lines ls{text, text + len};
+        const char *b, *e;
+        while (ls.next(&b, &e)) {
+            if ((size_t)(e - b) > MAX_LINE) return ff::fail(FF_ERR_PARSE, err, errlen, "bufio.Scanner: token too long");
+            lines.push_back({b, e});
+        }
+    }
+    auto *t = new ff_table();
+    t->ptr.push_back(0);
+    std::vector<int32_t> names;
+    size_t first = 0;
+    if (!sparse) {  // header, parser.go:32-40
+        if (lines.empty()) {
+            *out = t;
+            return FF_OK;
+        }
+        for (const char *p = lines[0].b; p < lines[0].e;) {
+            while (p < lines[0].e && is_space(*p)) ++p;
+            const char *q = p;
+            while (q < lines[0].e && !is_space(*q)) ++q;
+            if (q > p) names.push_back(t->intern(p, q));
+            p = q;
+        }
+        if (names.empty()) {
+            delete t;
+            return ff::fail(FF_ERR_PARSE, err, errlen, "row #1 has 0 values");
+        }
+        first = 1;
+    }
+    const int64_t nrows = (int64_t)lines.size() - (int64_t)first;
+    unsigned nt = ff::clamp_threads(nthreads);
+    if ((int64_t)nt > std::max<int64_t>(nrows, 1)) nt = (unsigned)std::max<int64_t>(nrows, 1);
+    std::vector<Partial> parts(nt);
+    ff::parallel_for(nrows, nt, [&](unsigned tid, int64_t b, int64_t e) {
+        Partial &pt = parts[tid];
+        Row row;
+        auto intern = [&pt](const char *p, const char *q) -> int32_t {
+            std::string s(p, q);
+            auto it = pt.species_id.find(s);
+            if (it != pt.species_id.end()) return it->second;
+            const int32_t id = (int32_t)pt.species.size();
+            pt.species.push_back(s);
+            pt.species_id.emplace(std::move(s), id);
+            return id;
+        };
+        for (int64_t r = b; r < e; ++r) {
+            const LineRef &ln = lines[first + (size_t)r];
+            const int rc = sparse ? parse_sparse_row(ln.b, ln.e, intern, &row, pt.err, sizeof pt.err)
+                                  : parse_dense_row(ln.b, ln.e, names, &row, pt.err, sizeof pt.err);
+            if (rc) {
+                pt.err_line = r;
+                pt.err_code = rc;
+                return;
+            }
+            pt.cnt.push_back((int64_t)row.key.size());
+            pt.key.insert(pt.key.end(), row.key.begin(), row.key.end());
+            pt.val.insert(pt.val.end(), row.val.begin(), row.val.end());
+        }
+    });
+    // the first failing row in row order wins, as with the reference's ordered pipeline
+    for (const Partial &pt : parts)
+        if (pt.err_code) {
+            delete t;
+            return ff::fail(pt.err_code, err, errlen, "%s", pt.err);
+        }
+    size_t total = 0;
+    for (const Partial &pt : parts) total += pt.key.size();
+    t->key.reserve(total);
+    t->val.reserve(total);
+    for (Partial &pt : parts) {
+        std::vector<int32_t> remap;
+        if (sparse) {
+            remap.resize(pt.species.size());
+            for (size_t k = 0; k < pt.species.size(); ++k)
+                remap[k] = t->intern(pt.species[k].data(), pt.species[k].data() + pt.species[k].size());
+        }
+        for (size_t k = 0; k < pt.key.size(); ++k) t->key.push_back(sparse ? remap[(size_t)pt.key[k]] : pt.key[k]);
+        t->val.insert(t->val.end(), pt.val.begin(), pt.val.end());
+        for (int64_t c : pt.cnt) t->ptr.push_back(t->ptr.back() + c);
+    }
+    *out = t;
+    return FF_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int ff_table_parse_dense(const char *text, size_t len, ff_table **out, char *err, size_t errlen)
 {
-    if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse_dense: null argument");
-    auto *t = new ff_table();
-    t->ptr.push_back(0);
-    Lines ls{text, text + len};
-    const char *b, *e;
-    std::vector<int32_t> names;
-    bool have_header = false;
-    Row row;
-    while (ls.next(&b, &e)) {
-        if ((size_t)(e - b) > MAX_LINE) {
-            delete t;
-            return ff::fail(FF_ERR_PARSE, err, errlen, "bufio.Scanner: token too long");
-        }
-        if (!have_header) {  // parser.go:32-40
-            for (const char *p = b; p < e;) {
-                while (p < e && is_space(*p)) ++p;
-                const char *q = p;
-                while (q < e && !is_space(*q)) ++q;
-                if (q > p) names.push_back(t->intern(p, q));
-                p = q;
-            }
-            if (names.empty()) {
-                delete t;
-                return ff::fail(FF_ERR_PARSE, err, errlen, "row #1 has 0 values");
-            }
-            have_header = true;
-            continue;
-        }
-        // parseRow, parser.go:59-81: the count is checked before any value is parsed
-        size_t nparts = 0;
-        for (const char *p = b; p < e;) {
-            while (p < e && is_space(*p)) ++p;
-            const char *q = p;
-            while (q < e && !is_space(*q)) ++q;
-            if (q > p) ++nparts;
-            p = q;
-        }
-        if (nparts != names.size()) {
-            delete t;
-            return ff::fail(FF_ERR_PARSE, err, errlen, "has %zu values, expected %zu", nparts,
-                            names.size());
-        }
-        row.clear();
-        size_t i = 0;
-        for (const char *p = b; p < e;) {
-            while (p < e && is_space(*p)) ++p;
-            const char *q = p;
-            while (q < e && !is_space(*q)) ++q;
-            if (q > p) {
-                double f;
-                const char *why;
-                if (!ff::go_parse_float(p, q, &f, &why)) {
-                    int rc = bad_float((int)i + 1, p, q, why, err, errlen);
-                    delete t;
-                    return rc;
-                }
-                if (std::isnan(f) || std::isinf(f) || f < 0) {
-                    int rc = bad_value((int)i + 1, f, err, errlen);
-                    delete t;
-                    return rc;
-                }
-                if (f != 0) row.set(names[i], f);
-                ++i;
-            }
-            p = q;
-        }
-        row.flush(t);
-    }
-    *out = t;
-    return FF_OK;
+    return parse_table(text, len, false, 1, out, err, errlen);
 }
 
 int ff_table_parse_sparse(const char *text, size_t len, ff_table **out, char *err, size_t errlen)
 {
-    if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse_sparse: null argument");
-    auto *t = new ff_table();
-    t->ptr.push_back(0);
-    Lines ls{text, text + len};
-    const char *b, *e;
-    Row row;
-    while (ls.next(&b, &e)) {
-        if ((size_t)(e - b) > MAX_LINE) {
-            delete t;
-            return ff::fail(FF_ERR_PARSE, err, errlen, "bufio.Scanner: token too long");
-        }
-        row.clear();  // a blank line is an empty sample (parser_test.go:29-35)
-        int i = 0;
-        for (const char *p = b; p < e;) {
-            while (p < e && is_space(*p)) ++p;
-            const char *q = p;
-            while (q < e && !is_space(*q)) ++q;
-            if (q > p) {
-                ++i;
-                const char *colon = nullptr;  // splitSparse: the LAST colon (parser.go:129-140)
-                for (const char *c = q; c > p;)
-                    if (*--c == ':') {
-                        colon = c;
-                        break;
-                    }
-                if (!colon) {
-                    std::string tok(p, q);
-                    delete t;
-                    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: no colon in %s", i,
-                                    ff::go_quote(tok).c_str());
-                }
-                if (colon == p) {
-                    delete t;
-                    return ff::fail(FF_ERR_PARSE, err, errlen, "value #%d: empty species name", i);
-                }
-                double f;
-                const char *why;
-                if (!ff::go_parse_float(colon + 1, q, &f, &why)) {
-                    int rc = bad_float(i, colon + 1, q, why, err, errlen);
-                    delete t;
-                    return rc;
-                }
-                if (std::isnan(f) || std::isinf(f) || f < 0) {
-                    int rc = bad_value(i, f, err, errlen);
-                    delete t;
-                    return rc;
-                }
-                if (f == 0) {
-                    delete t;
-                    return ff::fail(FF_ERR_PARSE, err, errlen,
-                                    "value #%d: zeros are not allowed in sparse format", i);
-                }
-                row.set(t->intern(p, colon), f);
-            }
-            p = q;
-        }
-        row.flush(t);
-    }
-    *out = t;
-    return FF_OK;
+    return parse_table(text, len, true, 1, out, err, errlen);
 }
 
-int ff_table_read_file(const char *path, int sparse, ff_table **table, char *err, size_t errlen)
+int ff_table_parse_mt(const char *text, size_t len, int sparse, int threads, ff_table **out, char *err,
+                      size_t errlen)
+{
+    return parse_table(text, len, sparse != 0, threads, out, err, errlen);
+}
+
+int ff_table_read_file_mt(const char *path, int sparse, int threads, ff_table **table, char *err, size_t errlen)
 {
     std::string text;
     int rc = ff::read_all(path, &text, err, errlen);
     if (rc) return rc;
-    return sparse ? ff_table_parse_sparse(text.data(), text.size(), table, err, errlen)
-                  : ff_table_parse_dense(text.data(), text.size(), table, err, errlen);
+    return parse_table(text.data(), text.size(), sparse != 0, threads, table, err, errlen);
+}
+
+int ff_table_read_file(const char *path, int sparse, ff_table **table, char *err, size_t errlen)
+{
+    return ff_table_read_file_mt(path, sparse, 1, table, err, errlen);
 }
 
 void ff_table_free(ff_table *t) { delete t; }

@@ -200,6 +200,13 @@ int ff_table_parse_dense(const char *text, size_t len, ff_table **table, char *e
 int ff_table_parse_sparse(const char *text, size_t len, ff_table **table, char *err, size_t errlen);
 int ff_table_read_file(const char *path /* NULL = stdin */, int sparse, ff_table **table,
                        char *err, size_t errlen);
+/* The same with the rows parsed on `threads` host threads (the ngoroutines argument of
+ * the reference's loaders, parser.go:21,85); the first failing row in row order is the
+ * one reported, as with the reference's ordered pipeline. */
+int ff_table_parse_mt(const char *text, size_t len, int sparse, int threads, ff_table **table,
+                      char *err, size_t errlen);
+int ff_table_read_file_mt(const char *path /* NULL = stdin */, int sparse, int threads,
+                          ff_table **table, char *err, size_t errlen);
 void ff_table_free(ff_table *table);
 int64_t ff_table_num_samples(const ff_table *table);
 int64_t ff_table_sample_size(const ff_table *table, int64_t sample);

@@ -126,6 +126,22 @@ def test_sparse_loader_errors_match_oracle(text):
         assert want is not None and str(got.value) == want
 
 
+def test_parallel_loaders_match_serial():
+    """ngoroutines > 1 (parser.go:21,85): same table; the first failing row wins."""
+    tree, ptr, idx, val = synth.make(97, 300, 0.1, 13)
+    for text, parse in ((synth.sparse_text(tree, ptr, idx, val), ff.parse_sparse_abundance),
+                        (synth.dense_text(tree, ptr, idx, val), ff.parse_abundance)):
+        want = parse(text).to_maps()
+        for nt in (2, 5, 16, 200):
+            assert parse(text, nt).to_maps() == want
+    bad = "a:1\n" * 50 + "b:x\n" + "a:1\n" * 20 + "c\n" + "a:1\n" * 30
+    for nt in (1, 3, 8):
+        with pytest.raises(ff.FFError) as e:
+            ff.parse_sparse_abundance(bad, nt)
+        assert str(e.value) == 'value #1: strconv.ParseFloat: parsing "x": invalid syntax'
+    assert ff.parse_abundance("", 4).to_maps() == [] and ff.parse_sparse_abundance("", 4).to_maps() == []
+
+
 def test_validate_species():
     tree = ff.parse_newick("((a:1,b:1)in:1,c:2);")
     ff.validate_species(ff.parse_sparse_abundance("a:1 in:2\n"), tree)
