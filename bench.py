@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--unweighted", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--end-to-end", action="store_true", help="also time ff_unifrac_dists through host buffers")
     args = ap.parse_args()
 
     import torch
@@ -160,6 +161,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    e2e = None
+    if rank == 0 and world == 1 and args.end_to_end:
+        # Host-buffer entry point (ff_unifrac_dists): upload of the flat nodes over PCIe,
+        # staging, the pair kernels and the download of the distances.  Never `value`.
+        out_host = np.empty(P, dtype=np.float64)
+        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=local_rank, out=out_host)  # warm
+        t0 = time.perf_counter()
+        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=local_rank, out=out_host)
+        e2e = time.perf_counter() - t0
+        log("end-to-end through host buffers (H2D %d MB + stage + kernels + D2H %d MB): %.1f ms = %.3g pairs/s" %
+            ((len(nodes.branch_id) * 12) >> 20, (P * 8) >> 20, e2e * 1e3, P / e2e))
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = P / (elapsed / args.steps)
@@ -200,6 +213,8 @@ def main():
                           "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
                           "parallelism": "pair-tile row shards x%d, gather to rank 0" % world},
                "roofline": roofline}
+        if e2e is not None:
+            out["host_buffers_ms"] = e2e * 1e3  # PCIe-inclusive, informational
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
         # cheap sanity on the result of the last step (not a parity test: tests/ does that)

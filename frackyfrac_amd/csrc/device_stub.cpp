@@ -1,0 +1,21 @@
+// device_stub.cpp -- stands in for ff_device.hip in the sanitizer build of the HOST code
+// (make asan): every device entry point fails with FF_ERR_DEVICE.  Never linked into the
+// product library.
+#include "ff_host.hpp"
+
+namespace ff {
+int unifrac_dists_info(const ff_problem *, const ff_options *, double *, ff_plan_info *, char *err, size_t errlen)
+{
+    return fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
+int unifrac_leaves_info(const ff_tree *, int64_t, const int64_t *, const int64_t *, const double *, int,
+                        const ff_options *, double *, ff_plan_info *, char *err, size_t errlen)
+{
+    return fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
+}  // namespace ff
+
+extern "C" int ff_unifrac_dists(const ff_problem *, const ff_options *, double *, char *err, size_t errlen)
+{
+    return ff::fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
