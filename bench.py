@@ -149,13 +149,13 @@ def main():
     for _ in range(args.warmup):
         run.step()
     barrier()
-    run.plan.timing_collect()
+    run.timing_collect()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = run.step(timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = run.plan.timing_collect()
+    kernel_ms_total, launches = run.timing_collect()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,7 +177,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = P / (elapsed / args.steps)
         # ---- roofline of the dominant kernel (this rank's launch) -------------
-        shard_pairs = info.slot_end - info.slot_begin
+        shard_pairs = run.n_slots
         kernel_ms = kernel_ms_total / max(launches, 1)
         elem_bytes = 4 if info.precision == 1 else 8
         # per pair 2*B lane-ops (subtract + |x|-accumulate per branch) and
