@@ -266,6 +266,141 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
     *pj = k - i * (i - 1) / 2;
 }
 
+// ---- Unweighted on the matrix cores -------------------------------------------------
+//
+// common(i,j) = sum_b k_b u_i(b) u_j(b) (unifrac.go:159) IS a contraction: with the
+// presence bits P[s][b] (int8 0/1) and the integer branch lengths cut into base-128 digits
+// K_d[s][b] = digit_d(k_b) * P[s][b] (int8 0..127), common = sum_d 128^d * (P . K_d^T), an
+// int8 GEMM with exact int32 accumulation (v_mfma_i32_32x32x32_i8).  The distance then
+// follows from U = W_i + W_j - 2*common exactly as on the v_sad_u32 path, so the results
+// are identical bit for bit; only the unit that does the work changes.  Both operands are
+// sample-major (a lane's 16 consecutive branches are one 16-byte load), staged through
+// LDS in 128 x 64-byte slabs with a padded 80-byte row stride (conflict-free ds_read_b128).
+
+constexpr int M_TILE = 128;   // workgroup tile: 128 i-samples x 128 j-samples, 4 waves of 64 x 64
+constexpr int M_KSLAB = 64;   // branches per LDS slab (two K = 32 MFMA steps)
+constexpr int M_STRIDE = 80;  // LDS row stride in bytes
+
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+
+struct MTile {
+    int32_t i0, j0;
+};
+
+// P8 / K8 planes from the flat nodes: one workgroup per sample.
+__global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                                  const uint32_t *__restrict__ klen, int n_digits, int8_t *__restrict__ P8,
+                                  int8_t *__restrict__ K8, int64_t ldb, int64_t plane,
+                                  unsigned long long *__restrict__ W)
+{
+    const int64_t s = blockIdx.x;
+    unsigned long long w = 0;
+    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
+        const int32_t b = branch_id[t];
+        const uint32_t k = klen[b];
+        P8[s * ldb + b] = 1;
+        for (int d = 0; d < n_digits; ++d) K8[d * plane + s * ldb + b] = (int8_t)((k >> (7 * d)) & 127u);
+        w += k;
+    }
+    // W_s = sum of the sample's integer branch lengths (what colsum_kernel gives the SAD path)
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
+}
+
+__global__ __launch_bounds__(256)
+void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
+                             int64_t plane, int n_digits, const MTile *__restrict__ tiles,
+                             const unsigned long long *__restrict__ W, uint32_t *__restrict__ num,
+                             int64_t row_begin, int64_t row_end, int64_t slot_begin)
+{
+    __shared__ __attribute__((aligned(16))) int8_t lds_a[M_TILE * M_STRIDE];
+    __shared__ __attribute__((aligned(16))) int8_t lds_b[M_TILE * M_STRIDE];
+    const MTile tile = tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    // slab copy: 128 rows x 64 bytes = 512 chunks of 16 bytes, two per thread
+    const int r0 = tid >> 2, c0 = (tid & 3) * 16;          // chunk tid
+    const int r1 = (tid + 256) >> 2;                        // chunk tid + 256 (same column)
+    const int8_t *ga0 = P8 + (int64_t)(tile.i0 + r0) * ldb + c0;
+    const int8_t *ga1 = P8 + (int64_t)(tile.i0 + r1) * ldb + c0;
+    uint32_t total[2][2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) total[m][n][r] = 0;
+    const int frag_off = (lane & 31) * M_STRIDE + 16 * (lane >> 5);
+    for (int d = 0; d < n_digits; ++d) {
+        const int8_t *gb0 = K8 + d * plane + (int64_t)(tile.j0 + r0) * ldb + c0;
+        const int8_t *gb1 = K8 + d * plane + (int64_t)(tile.j0 + r1) * ldb + c0;
+        mfma_v16i acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
+        // register-prefetched single LDS buffer: slab k+1 travels global -> registers while
+        // slab k is multiplied out of LDS
+        mfma_v4i pa0 = *(const mfma_v4i *)ga0, pa1 = *(const mfma_v4i *)ga1;
+        mfma_v4i pb0 = *(const mfma_v4i *)gb0, pb1 = *(const mfma_v4i *)gb1;
+        for (int64_t k = 0; k < ldb; k += M_KSLAB) {
+            __syncthreads();  // everyone is done reading the previous slab
+            *(mfma_v4i *)(lds_a + r0 * M_STRIDE + c0) = pa0;
+            *(mfma_v4i *)(lds_a + r1 * M_STRIDE + c0) = pa1;
+            *(mfma_v4i *)(lds_b + r0 * M_STRIDE + c0) = pb0;
+            *(mfma_v4i *)(lds_b + r1 * M_STRIDE + c0) = pb1;
+            __syncthreads();
+            if (k + M_KSLAB < ldb) {
+                pa0 = *(const mfma_v4i *)(ga0 + k + M_KSLAB);
+                pa1 = *(const mfma_v4i *)(ga1 + k + M_KSLAB);
+                pb0 = *(const mfma_v4i *)(gb0 + k + M_KSLAB);
+                pb1 = *(const mfma_v4i *)(gb1 + k + M_KSLAB);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                mfma_v4i a[2], b[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    a[m] = *(const mfma_v4i *)(lds_a + (wi * 64 + m * 32) * M_STRIDE + kt * 32 + frag_off);
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    b[n] = *(const mfma_v4i *)(lds_b + (wj * 64 + n * 32) * M_STRIDE + kt * 32 + frag_off);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) total[m][n][r] += (uint32_t)acc[m][n][r] << (7 * d);
+    }
+    // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t i = tile.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (i < row_begin || i >= row_end) continue;
+            const unsigned long long wi_ = W[i];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int64_t j = tile.j0 + wj * 64 + n * 32 + (lane & 31);
+                if (j >= i) continue;
+                // result = W_i + W_j - 2 * common  (branches on exactly one side)
+                num[i * (i - 1) / 2 - slot_begin + j] = (uint32_t)(wi_ + W[j] - 2ull * total[m][n][r]);
+            }
+        }
+}
+
 // ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
 //
 // S[b][s] (binary64, branch-major) starts as the leaf values.  Internal nodes are then
@@ -521,6 +656,13 @@ struct ff_plan {
     double *d_abnd = nullptr;
     unsigned long long *d_refine_list = nullptr, *d_refine_count = nullptr;
     unsigned long long refine_cap = 0;
+    // FIXED32 unweighted on the matrix cores
+    bool mfma = false;
+    int8_t *d_P8 = nullptr, *d_K8 = nullptr;
+    int64_t m_ldb = 0, m_plane = 0;
+    int m_digits = 0;
+    MTile *d_mtiles = nullptr;
+    int n_mtiles = 0;
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -815,6 +957,9 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_abnd);
     (void)hipFree(pl->d_refine_list);
     (void)hipFree(pl->d_refine_count);
+    (void)hipFree(pl->d_P8);
+    (void)hipFree(pl->d_K8);
+    (void)hipFree(pl->d_mtiles);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_xtiles);
@@ -1050,7 +1195,52 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     }
     inf.precision = prec;
 
-    if (prec == FF_PRECISION_FIXED32) {
+    const bool use_mfma = prec == FF_PRECISION_FIXED32 && !weighted && env_int("FF_UNWEIGHTED_MFMA", 1) != 0 && N > 0 && B > 0;
+    if (use_mfma) {
+        // presence / digit planes, sample-major, zero padded to whole tiles and slabs
+        pl->mfma = true;
+        inf.lengths_exact = q.lengths_exact;
+        inf.scale_log2 = q.e;
+        uint32_t kmax = 0;
+        for (uint32_t k : q.klen) kmax = std::max(kmax, k);
+        int digits = 1;
+        while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
+        pl->m_digits = digits;
+        const int64_t n8 = round_up(N, M_TILE);
+        const int64_t ldb = round_up(B, M_KSLAB);
+        pl->m_ldb = ldb;
+        pl->m_plane = n8 * ldb;
+        inf.ld = n8;
+        inf.rows_padded = ldb;
+        const size_t plane_bytes = (size_t)n8 * (size_t)ldb;
+        inf.staged_bytes = (double)plane_bytes * (1 + digits);
+        FF_HIP(hipMalloc(&pl->d_P8, plane_bytes));
+        FF_HIP(hipMalloc(&pl->d_K8, plane_bytes * (size_t)digits));
+        FF_HIP(hipMemset(pl->d_P8, 0, plane_bytes));
+        FF_HIP(hipMemset(pl->d_K8, 0, plane_bytes * (size_t)digits));
+        FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
+        FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
+        uint32_t *d_klen = nullptr;
+        FF_HIP(hipMalloc(&d_klen, sizeof(uint32_t) * (size_t)B));
+        FF_HIP(hipMemcpy(d_klen, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+        if (nnz > 0)
+            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_klen, digits, pl->d_P8, pl->d_K8,
+                                                                 ldb, pl->m_plane, pl->d_W);
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipDeviceSynchronize());
+        (void)hipFree(d_klen);
+        std::vector<Tile> tiles;
+        build_tiles(N, inf.row_begin, inf.row_end, M_TILE, M_TILE, false, &tiles);
+        std::vector<MTile> mt(tiles.size());
+        for (size_t k = 0; k < tiles.size(); ++k) mt[k] = {tiles[k].i0, tiles[k].j0};
+        pl->n_mtiles = (int)mt.size();
+        inf.n_tiles = inf.n_items = (int64_t)mt.size();
+        inf.n_wave_slots = (int64_t)mt.size() * 4;
+        inf.elements = (double)mt.size() * M_TILE * M_TILE * (double)ldb * digits;
+        FF_HIP(hipMalloc(&pl->d_mtiles, sizeof(MTile) * std::max<size_t>(mt.size(), 1)));
+        if (!mt.empty()) FF_HIP(hipMemcpy(pl->d_mtiles, mt.data(), sizeof(MTile) * mt.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
+    } else if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
         const int64_t rows = round_up(B, 2 * KSTEP);
         inf.ld = ld;
@@ -1200,7 +1390,12 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
     if (inf.precision == FF_PRECISION_FIXED32) {
         FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
-        if (inf.n_items > 0)
+        if (pl->mfma) {
+            if (pl->n_mtiles > 0)
+                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mtiles), dim3(256), 0, st>>>(
+                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->m_digits, pl->d_mtiles, pl->d_W, pl->d_num,
+                    inf.row_begin, inf.row_end, inf.slot_begin);
+        } else if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
