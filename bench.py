@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
 HBM_PEAK_GBPS = 8000.0            # HBM3E spec
 VALU_PEAK_TLANEOPS = 78.65        # 157.3 TFLOP/s FP32 vector / 2 flops per lane-op
+MFMA_I8_PEAK_TOPS = 5000.0        # int8 MFMA issues at 2x the dense bf16 rate (~2.5 PFLOP/s)
 
 
 def log(*a):
@@ -183,24 +184,36 @@ def main():
         # per pair 2*B lane-ops (subtract + |x|-accumulate per branch) and
         # 8 + (elem*N*B + 4*B + 4*N)/P bytes (one f64 result + the pair's share of one
         # compulsory read of the staged matrix, lengths and row sums)
-        laneops = 2.0 * B * shard_pairs
+        from frackyfrac_amd._lib import KERNEL_NAMES
         alg_bytes = 8.0 * shard_pairs + elem_bytes * float(n_samples) * B + 4.0 * B + 4.0 * n_samples
-        achieved_tl = laneops / (kernel_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and info.kernel == 0 and weighted:
             try:
                 traffic = json.load(open(tpath)).get("%s_n%d" % (name, world))
             except Exception:
                 traffic = None
-        roofline = {"bound": "valu", "achieved": achieved_tl, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                    "frac": achieved_tl / VALU_PEAK_TLANEOPS, "traffic": traffic,
-                    "kernel": "pair_sad_kernel" if info.precision == 1 else "pair_exact64_kernel",
-                    "kernel_ms": kernel_ms, "launches": launches,
-                    "algorithmic": "2*B lane-ops per pair (SURVEY 8d), B=%d, %d pairs per launch" % (B, shard_pairs),
-                    "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                            "algorithmic_bytes": alg_bytes}}
+        hbm = {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+               "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "algorithmic_bytes": alg_bytes}
+        if info.kernel == 2:
+            # unweighted on the matrix cores: one multiply-add per branch and pair is the
+            # algorithmic work (the base-128 digit passes are the implementation's)
+            flops = 2.0 * B * shard_pairs
+            achieved = flops / (kernel_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                        "frac": achieved / MFMA_I8_PEAK_TOPS, "traffic": traffic, "kernel": KERNEL_NAMES[2],
+                        "kernel_ms": kernel_ms, "launches": launches, "digits": int(info.n_digits),
+                        "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs),
+                        "hbm": hbm}
+        else:
+            laneops = 2.0 * B * shard_pairs
+            achieved_tl = laneops / (kernel_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu", "achieved": achieved_tl, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                        "frac": achieved_tl / VALU_PEAK_TLANEOPS, "traffic": traffic,
+                        "kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches,
+                        "algorithmic": "2*B lane-ops per pair (SURVEY 8d), B=%d, %d pairs per launch" % (B, shard_pairs),
+                        "hbm": hbm}
         out = {"metric": "sample-pairs/sec (lower triangle), weighted UniFrac 4096 samples x 10k-leaf tree"
                          if name == "C3" and weighted else "sample-pairs/sec (lower triangle)",
                "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -277,16 +277,25 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
 // sample-major (a lane's 16 consecutive branches are one 16-byte load), staged through
 // LDS in 128 x 64-byte slabs with a padded 80-byte row stride (conflict-free ds_read_b128).
 
-constexpr int M_TILE = 128;   // workgroup tile: 128 i-samples x 128 j-samples, 4 waves of 64 x 64
-constexpr int M_KSLAB = 64;   // branches per LDS slab (two K = 32 MFMA steps)
-constexpr int M_STRIDE = 80;  // LDS row stride in bytes
+constexpr int M_TILE = 128;    // workgroup tile: 128 i-samples x 128 j-samples, 4 waves of 64 x 64
+constexpr int M_KSLAB = 128;   // branches per LDS slab (four K = 32 MFMA steps)
+constexpr int M_STRIDE = 144;  // LDS row stride in bytes (128 + 16: conflict-free ds_read_b128)
+constexpr int M_CHUNKS = M_TILE * M_KSLAB / 16 / 256;  // 16-byte chunks per thread and operand slab
 
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 
-struct MTile {
+// One unit of work: a 128 x 128 tile over the branch slabs [k0, k1) for `nd` consecutive
+// digit planes starting at `d0`.  Every item adds its share of U = W_i + W_j - 2*common
+// to num[] atomically (mod 2^32; U < 2^32): the item with `first` also brings W_i + W_j.
+struct MItem {
     int32_t i0, j0;
+    int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
+    int32_t d0, nd;  // digit planes d0 .. d0+nd-1, nd in {1, 2}
+    int32_t first;
+    int32_t pad;
 };
+static_assert(sizeof(MItem) == 32, "MItem must be 32 bytes");
 
 // P8 / K8 planes from the flat nodes: one workgroup per sample.
 __global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
@@ -308,97 +317,119 @@ __global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int3
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
 }
 
-__global__ __launch_bounds__(256)
-void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
-                             int64_t plane, int n_digits, const MTile *__restrict__ tiles,
-                             const unsigned long long *__restrict__ W, uint32_t *__restrict__ num,
-                             int64_t row_begin, int64_t row_end, int64_t slot_begin)
+template <int ND>
+__device__ __forceinline__ void mfma_item(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
+                                          int64_t plane, const MItem item, const unsigned long long *__restrict__ W,
+                                          uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                                          int64_t slot_begin, int8_t *lds)
 {
-    __shared__ __attribute__((aligned(16))) int8_t lds_a[M_TILE * M_STRIDE];
-    __shared__ __attribute__((aligned(16))) int8_t lds_b[M_TILE * M_STRIDE];
-    const MTile tile = tiles[blockIdx.x];
+    int8_t *lds_a = lds;                                  // [128][M_STRIDE]
+    int8_t *lds_b = lds + M_TILE * M_STRIDE;              // [ND][128][M_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
-    // slab copy: 128 rows x 64 bytes = 512 chunks of 16 bytes, two per thread
-    const int r0 = tid >> 2, c0 = (tid & 3) * 16;          // chunk tid
-    const int r1 = (tid + 256) >> 2;                        // chunk tid + 256 (same column)
-    const int8_t *ga0 = P8 + (int64_t)(tile.i0 + r0) * ldb + c0;
-    const int8_t *ga1 = P8 + (int64_t)(tile.i0 + r1) * ldb + c0;
-    uint32_t total[2][2][16];
+    // slab copy: 128 rows x M_KSLAB bytes in 16-byte chunks, M_CHUNKS per thread:
+    // chunk c = tid + 256 q -> row c / (M_KSLAB/16), column (c % (M_KSLAB/16)) * 16
+    constexpr int CPR = M_KSLAB / 16;                     // chunks per row
+    constexpr int RSTEP = 256 / CPR;                      // rows between a thread's chunks
+    const int c16 = (tid % CPR) * 16, rq = tid / CPR;
+    const int8_t *ga = P8 + (int64_t)(item.i0 + rq) * ldb + item.k0 + c16;
+    const int8_t *gb = K8 + (int64_t)item.d0 * plane + (int64_t)(item.j0 + rq) * ldb + item.k0 + c16;
+    const int64_t row32 = (int64_t)RSTEP * ldb;
+    mfma_v16i acc[ND][2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) total[m][n][r] = 0;
-    const int frag_off = (lane & 31) * M_STRIDE + 16 * (lane >> 5);
-    for (int d = 0; d < n_digits; ++d) {
-        const int8_t *gb0 = K8 + d * plane + (int64_t)(tile.j0 + r0) * ldb + c0;
-        const int8_t *gb1 = K8 + d * plane + (int64_t)(tile.j0 + r1) * ldb + c0;
-        mfma_v16i acc[2][2];
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
-        // register-prefetched single LDS buffer: slab k+1 travels global -> registers while
-        // slab k is multiplied out of LDS
-        mfma_v4i pa0 = *(const mfma_v4i *)ga0, pa1 = *(const mfma_v4i *)ga1;
-        mfma_v4i pb0 = *(const mfma_v4i *)gb0, pb1 = *(const mfma_v4i *)gb1;
-        for (int64_t k = 0; k < ldb; k += M_KSLAB) {
-            __syncthreads();  // everyone is done reading the previous slab
-            *(mfma_v4i *)(lds_a + r0 * M_STRIDE + c0) = pa0;
-            *(mfma_v4i *)(lds_a + r1 * M_STRIDE + c0) = pa1;
-            *(mfma_v4i *)(lds_b + r0 * M_STRIDE + c0) = pb0;
-            *(mfma_v4i *)(lds_b + r1 * M_STRIDE + c0) = pb1;
-            __syncthreads();
-            if (k + M_KSLAB < ldb) {
-                pa0 = *(const mfma_v4i *)(ga0 + k + M_KSLAB);
-                pa1 = *(const mfma_v4i *)(ga1 + k + M_KSLAB);
-                pb0 = *(const mfma_v4i *)(gb0 + k + M_KSLAB);
-                pb1 = *(const mfma_v4i *)(gb1 + k + M_KSLAB);
+                for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
+    const int frag_off = (lane & 31) * M_STRIDE + 16 * (lane >> 5);
+    // register-prefetched single LDS buffer: slab k+1 travels global -> registers while slab k
+    // is multiplied out of LDS
+    mfma_v4i pa[M_CHUNKS], pb[ND][M_CHUNKS];
+#pragma unroll
+    for (int q = 0; q < M_CHUNKS; ++q) {
+        pa[q] = *(const mfma_v4i *)(ga + q * row32);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) pb[d][q] = *(const mfma_v4i *)(gb + d * plane + q * row32);
+    }
+    const int nk = item.k1 - item.k0;
+    for (int k = 0; k < nk; k += M_KSLAB) {
+        __syncthreads();  // everyone is done reading the previous slab
+#pragma unroll
+        for (int q = 0; q < M_CHUNKS; ++q) {
+            *(mfma_v4i *)(lds_a + (rq + RSTEP * q) * M_STRIDE + c16) = pa[q];
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                *(mfma_v4i *)(lds_b + d * (M_TILE * M_STRIDE) + (rq + RSTEP * q) * M_STRIDE + c16) = pb[d][q];
+        }
+        __syncthreads();
+        if (k + M_KSLAB < nk) {
+#pragma unroll
+            for (int q = 0; q < M_CHUNKS; ++q) {
+                pa[q] = *(const mfma_v4i *)(ga + k + M_KSLAB + q * row32);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    pb[d][q] = *(const mfma_v4i *)(gb + d * plane + k + M_KSLAB + q * row32);
             }
+        }
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                mfma_v4i a[2], b[2];
+        for (int kt = 0; kt < M_KSLAB / 32; ++kt) {
+            mfma_v4i a[2];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    a[m] = *(const mfma_v4i *)(lds_a + (wi * 64 + m * 32) * M_STRIDE + kt * 32 + frag_off);
+            for (int m = 0; m < 2; ++m)
+                a[m] = *(const mfma_v4i *)(lds_a + (wi * 64 + m * 32) * M_STRIDE + kt * 32 + frag_off);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                mfma_v4i b[2];
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    b[n] = *(const mfma_v4i *)(lds_b + (wj * 64 + n * 32) * M_STRIDE + kt * 32 + frag_off);
+                    b[n] = *(const mfma_v4i *)(lds_b + d * (M_TILE * M_STRIDE) + (wj * 64 + n * 32) * M_STRIDE +
+                                               kt * 32 + frag_off);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+                        acc[d][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[d][m][n], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) total[m][n][r] += (uint32_t)acc[m][n][r] << (7 * d);
     }
     // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t i = tile.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t i = item.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (i < row_begin || i >= row_end) continue;
-            const unsigned long long wi_ = W[i];
+            const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int64_t j = tile.j0 + wj * 64 + n * 32 + (lane & 31);
+                const int64_t j = item.j0 + wj * 64 + n * 32 + (lane & 31);
                 if (j >= i) continue;
-                // result = W_i + W_j - 2 * common  (branches on exactly one side)
-                num[i * (i - 1) / 2 - slot_begin + j] = (uint32_t)(wi_ + W[j] - 2ull * total[m][n][r]);
+                uint32_t common = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) common += (uint32_t)acc[d][m][n][r] << (7 * (item.d0 + d));
+                // this item's share of result = W_i + W_j - 2 * common, modulo 2^32
+                const uint32_t v = wi_ + (item.first ? (uint32_t)W[j] : 0u) - 2u * common;
+                if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
             }
         }
+}
+
+__global__ __launch_bounds__(256, 2)
+void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
+                             int64_t plane, const MItem *__restrict__ items,
+                             const unsigned long long *__restrict__ W, uint32_t *__restrict__ num,
+                             int64_t row_begin, int64_t row_end, int64_t slot_begin)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];
+    const MItem item = items[blockIdx.x];
+    if (item.nd == 2)
+        mfma_item<2>(P8, K8, ldb, plane, item, W, num, row_begin, row_end, slot_begin, mfma_lds);
+    else
+        mfma_item<1>(P8, K8, ldb, plane, item, W, num, row_begin, row_end, slot_begin, mfma_lds);
 }
 
 // ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
@@ -661,8 +692,8 @@ struct ff_plan {
     int8_t *d_P8 = nullptr, *d_K8 = nullptr;
     int64_t m_ldb = 0, m_plane = 0;
     int m_digits = 0;
-    MTile *d_mtiles = nullptr;
-    int n_mtiles = 0;
+    MItem *d_mitems = nullptr;
+    int n_mitems = 0;
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -959,7 +990,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_refine_count);
     (void)hipFree(pl->d_P8);
     (void)hipFree(pl->d_K8);
-    (void)hipFree(pl->d_mtiles);
+    (void)hipFree(pl->d_mitems);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_xtiles);
@@ -1194,11 +1225,13 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         }
     }
     inf.precision = prec;
+    inf.kernel = prec == FF_PRECISION_EXACT64 ? FF_KERNEL_EXACT_F64 : FF_KERNEL_SAD_U32;
 
     const bool use_mfma = prec == FF_PRECISION_FIXED32 && !weighted && env_int("FF_UNWEIGHTED_MFMA", 1) != 0 && N > 0 && B > 0;
     if (use_mfma) {
         // presence / digit planes, sample-major, zero padded to whole tiles and slabs
         pl->mfma = true;
+        inf.kernel = FF_KERNEL_MFMA_I8;
         inf.lengths_exact = q.lengths_exact;
         inf.scale_log2 = q.e;
         uint32_t kmax = 0;
@@ -1206,8 +1239,9 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         int digits = 1;
         while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
         pl->m_digits = digits;
+        inf.n_digits = digits;
         const int64_t n8 = round_up(N, M_TILE);
-        const int64_t ldb = round_up(B, M_KSLAB);
+        const int64_t ldb = round_up(B, M_KSLAB);  // whole slabs
         pl->m_ldb = ldb;
         pl->m_plane = n8 * ldb;
         inf.ld = n8;
@@ -1231,14 +1265,44 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         (void)hipFree(d_klen);
         std::vector<Tile> tiles;
         build_tiles(N, inf.row_begin, inf.row_end, M_TILE, M_TILE, false, &tiles);
-        std::vector<MTile> mt(tiles.size());
-        for (size_t k = 0; k < tiles.size(); ++k) mt[k] = {tiles[k].i0, tiles[k].j0};
-        pl->n_mtiles = (int)mt.size();
-        inf.n_tiles = inf.n_items = (int64_t)mt.size();
-        inf.n_wave_slots = (int64_t)mt.size() * 4;
-        inf.elements = (double)mt.size() * M_TILE * M_TILE * (double)ldb * digits;
-        FF_HIP(hipMalloc(&pl->d_mtiles, sizeof(MTile) * std::max<size_t>(mt.size(), 1)));
-        if (!mt.empty()) FF_HIP(hipMemcpy(pl->d_mtiles, mt.data(), sizeof(MTile) * mt.size(), hipMemcpyHostToDevice));
+        // digit planes in groups of two (one sweep of the presence operand serves both);
+        // each (tile, group) is cut into `split` branch ranges so that the grid has several
+        // workgroups per CU slot and the last round of workgroups is short
+        const int64_t slabs = ldb / M_KSLAB;
+        int split = env_int("FF_MFMA_SPLIT", 0);
+        const int groups = (digits + 1) / 2;
+        if (split <= 0) {
+            const int64_t want = (int64_t)prop.multiProcessorCount * 4;  // two rounds of 2 workgroups per CU
+            split = (int)std::max<int64_t>(1, (want + (int64_t)tiles.size() * groups - 1) /
+                                                  std::max<int64_t>(1, (int64_t)tiles.size() * groups));
+        }
+        split = (int)std::min<int64_t>(split, std::max<int64_t>(1, slabs / 8));  // >= 8 slabs per item
+        std::vector<MItem> mi;
+        for (int g = 0; g < groups; ++g)
+            for (int sp = 0; sp < split; ++sp)
+                for (const Tile &t : tiles) {
+                    const int64_t s0 = slabs * sp / split, s1 = slabs * (sp + 1) / split;
+                    if (s1 <= s0) continue;
+                    MItem it{};
+                    it.i0 = t.i0;
+                    it.j0 = t.j0;
+                    it.k0 = (int32_t)(s0 * M_KSLAB);
+                    it.k1 = (int32_t)(s1 * M_KSLAB);
+                    it.d0 = 2 * g;
+                    it.nd = std::min(2, digits - 2 * g);
+                    it.first = (g == 0 && sp == 0) ? 1 : 0;
+                    mi.push_back(it);
+                }
+        pl->n_mitems = (int)mi.size();
+        inf.n_tiles = (int64_t)tiles.size();
+        inf.n_items = (int64_t)mi.size();
+        inf.n_wave_slots = (int64_t)mi.size() * 4;
+        inf.elements = (double)tiles.size() * M_TILE * M_TILE * (double)ldb * digits;
+        FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
+        if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
+        pl->lds_bytes = (size_t)3 * M_TILE * M_STRIDE;
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
         FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
     } else if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
@@ -1391,10 +1455,10 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->mfma) {
-            if (pl->n_mtiles > 0)
-                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mtiles), dim3(256), 0, st>>>(
-                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->m_digits, pl->d_mtiles, pl->d_W, pl->d_num,
-                    inf.row_begin, inf.row_end, inf.slot_begin);
+            if (pl->n_mitems > 0)
+                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mitems), dim3(256), pl->lds_bytes, st>>>(
+                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_W, pl->d_num, inf.row_begin,
+                    inf.row_end, inf.slot_begin);
         } else if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,

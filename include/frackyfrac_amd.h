@@ -66,7 +66,9 @@ typedef enum ff_precision {
     FF_PRECISION_AUTO = 0,    /* EXACT64 when pairs*branches <= 2^32 (about a millisecond) or
                                  when FIXED32 is not applicable, else FIXED32                 */
     FF_PRECISION_FIXED32 = 1, /* 32-bit fixed point, integer sums: order-independent, exact
-                                 for unweighted whenever all branch lengths are k * 2^-e      */
+                                 for unweighted whenever all branch lengths are k * 2^-e;
+                                 weighted runs on the vector ALU (v_sad_u32), unweighted on
+                                 the int8 matrix cores (same integers, same results)          */
     FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
                                  the reference for any finite input; about 6x slower          */
 } ff_precision;
@@ -129,7 +131,15 @@ typedef struct ff_plan_info {
     int64_t n_wave_slots;     /* persistent waves the main kernel runs                        */
     double staged_bytes;      /* bytes of the staged matrix in HBM                            */
     double elements;          /* sum over items of tile pairs * branches = |a-b| terms issued */
+    int32_t kernel;           /* ff_kernel: which kernel does the pair reduction              */
+    int32_t n_digits;         /* FF_KERNEL_MFMA_I8: base-128 digits of the integer lengths    */
 } ff_plan_info;
+
+typedef enum ff_kernel {
+    FF_KERNEL_SAD_U32 = 0,   /* pair_sad_kernel: v_sad_u32 pair tiles (FIXED32)                    */
+    FF_KERNEL_EXACT_F64 = 1, /* pair_exact64_kernel (EXACT64)                                      */
+    FF_KERNEL_MFMA_I8 = 2    /* pair_common_mfma_kernel: FIXED32 unweighted, int8 matrix cores     */
+} ff_kernel;
 
 /* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM
  * (DESIGN.md "Data layout"), build the tile schedule.  Synchronous. */

@@ -259,6 +259,35 @@ def test_bad_problems_are_rejected():
         ff.unifrac_dists(nodes, True, rank=3, world=2)
 
 
+def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch):
+    """FIXED32 unweighted: the int8 matrix-core contraction and the v_sad_u32 kernel work
+    on the same integers and must give the same bits (three base-128 digits here)."""
+    import torch
+    tree, ptr, idx, val = synth.make(300, 700, 0.1, 91)
+    rng = np.random.default_rng(5)
+    tree.branch_len = rng.integers(1, 1 << 20, size=tree.n).astype(np.float64) / 64.0   # 20-bit integer lengths
+    tree.branch_len[0] = 0.0
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, False)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FF_UNWEIGHTED_MFMA", flag)
+        plan = ff.Plan(nodes, False, precision="fixed32")
+        assert plan.info.kernel == (2 if flag == "1" else 0) and plan.info.lengths_exact == 1
+        if flag == "1":
+            assert plan.info.n_digits == 3
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        outs[flag] = out.cpu().numpy()
+        plan.close()
+    assert np.array_equal(outs["1"], outs["0"])
+    assert np.array_equal(outs["1"], want)
+
+
 # ---------------------------------------------------------------- stage A on the device
 
 @pytest.mark.parametrize("seed,ns,nl,dens", [(1, 64, 200, 0.1), (2, 33, 1000, 0.02), (3, 8, 50, 0.9), (4, 300, 3000, 0.05)])
