@@ -288,6 +288,44 @@ def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch):
     assert np.array_equal(outs["1"], want)
 
 
+def test_unweighted_mfma_five_digits_and_long_lengths():
+    """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps)."""
+    tree, ptr, idx, val = synth.make(130, 20, 0.3, 93)
+    rng = np.random.default_rng(6)
+    tree.branch_len = rng.integers(1, 1 << 24, size=tree.n).astype(np.float64)
+    tree.branch_len[3] = float((1 << 29) - 1)
+    tree.branch_len[0] = 0.0
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.kernel == 2 and plan.info.n_digits == 5 and plan.info.lengths_exact == 1
+    plan.close()
+    assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
+
+
+def test_c5_shaped_sparse_input_through_the_cli(tmp_path):
+    """BASELINE configs[4] shape at reduced sample count: 50k-leaf tree (B = 99,999),
+    5 % density, sparse text table, through the frcfrc executable, both metrics."""
+    tree, ptr, idx, val = synth.make(160, 50000, 0.05, synth.SEED_BASE + 5)
+    (tmp_path / "t.tree").write_text(tree.newick())
+    (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr, idx, val))
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    for flags, weighted in ((["-w"], True), ([], False)):
+        out = tmp_path / "out.txt"
+        r = subprocess.run([L.FRCFRC_PATH, *flags, "-s", "-p", "8", "-precision", "fixed32", "-i", str(tmp_path / "t.sparse"),
+                            "-t", str(tmp_path / "t.tree"), "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.array([float(x) for x in out.read_text().split()])
+        want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=8)
+        if weighted:
+            assert rel_err(got, want) <= WEIGHTED_RTOL
+        else:
+            assert np.array_equal(got, want)
+
+
 # ---------------------------------------------------------------- stage A on the device
 
 @pytest.mark.parametrize("seed,ns,nl,dens", [(1, 64, 200, 0.1), (2, 33, 1000, 0.02), (3, 8, 50, 0.9), (4, 300, 3000, 0.05)])
@@ -361,13 +399,14 @@ def test_plan_from_leaves_equals_plan_from_flat_nodes(precision):
 
 @pytest.mark.parametrize("precision", ["fixed32", "exact64"])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_shards_tile_the_pair_space(precision, world):
+@pytest.mark.parametrize("weighted", [True, False])
+def test_shards_tile_the_pair_space(precision, world, weighted):
     nodes, ip, on, ft = synth_problem(200, 150, 0.1, 41)
-    full = ff.unifrac_dists(nodes, True, precision=precision)
+    full = ff.unifrac_dists(nodes, weighted, precision=precision)
     out = np.full(ff.num_pairs(200), np.nan)
     for r in range(world):
         before = out.copy()
-        ff.unifrac_dists(nodes, True, precision=precision, rank=r, world=world, out=out)
+        ff.unifrac_dists(nodes, weighted, precision=precision, rank=r, world=world, out=out)
         a, b = ff.shard_slots(200, r, world)
         changed = np.flatnonzero(~((out == before) | (np.isnan(out) & np.isnan(before))))
         assert len(changed) == 0 or (changed.min() >= a and changed.max() < b)
