@@ -1,6 +1,6 @@
-// ff_device.hip -- stage B of the UniFrac path on gfx950 (MI355X): staging of the
-// flat-node vectors into a dense branch-major matrix in HBM, the pair-tile
-// reduction kernels, and the plan/run C ABI around them.
+// ff_device.hip -- the UniFrac path on gfx950 (MI355X): stage A on the device, staging
+// of the flat-node vectors into dense matrices in HBM, the pair reduction kernels, and
+// the plan/run C ABI around them.
 //
 // Replaces the per-pair merge walks unifracDistWeighted / unifracDistUnweighted
 // (frcfrc/unifrac.go:144-205) and their driver unifracDists (unifrac.go:209-228).
@@ -8,17 +8,19 @@
 // sample s on branch b (0 where the sample has no flat node):
 //
 //   FIXED32  q_s(b) = round(l_b * abnd_s(b) * 2^e)   (weighted)
-//            q_s(b) = round(l_b * 2^e) * [present]   (unweighted)
-//            U(i,j) = sum_b |q_i(b) - q_j(b)|        one v_sad_u32 per term, exact
-//            weighted   d = U / (W_i + W_j),                  W_s = sum_b q_s(b)
-//            unweighted d = U / (U + C),  C = (W_i + W_j - U) / 2
+//            q_s(b) = k_b * [present], k_b = round(l_b * 2^e)   (unweighted)
+//            U(i,j) = sum_b |q_i(b) - q_j(b)|,  W_s = sum_b q_s(b)   -- exact integers
+//            weighted   d = U / (W_i + W_j)          U by v_sad_u32, one per term
+//            unweighted d = U / (U + C), C = (W_i + W_j - U) / 2
+//                       C = sum_b k_b [i present][j present] is a contraction: int8 MFMA
 //   EXACT64  binary64 running sums over b ascending, with the reference's own
 //            operations (no contraction), so every rounding is the reference's.
 //
-// Layout: QT[b][s], row = branch (pre-order id), column = sample, so that the 64
-// lanes of a wave read 64 consecutive samples of one branch (coalesced) while the
-// other side of the pair tile -- 32 samples of the same branch -- arrives through
-// the scalar cache as SGPR operands.  No LDS, no cross-lane traffic.
+// Layouts.  v_sad_u32 path: QT[b][s], row = branch (pre-order id), column = sample, so
+// that the 64 lanes of a wave read 4 x 64 consecutive samples of one branch (coalesced)
+// while the other side of the pair tile -- 32 samples of the same branch -- arrives
+// through the scalar cache as SGPR operands; no LDS, no cross-lane traffic.  MFMA path:
+// sample-major int8 planes (a lane's 16 consecutive branches are one MFMA fragment).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -45,7 +47,7 @@ constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
 constexpr int X_TILE_J = 64;
 
 struct Item {        // one unit of work for a persistent wave: a pair tile over a
-    int32_t i0, j0;  // branch range [k0, k1) (multiples of KSTEP)
+    int32_t i0, j0;  // branch range [k0, k1)
     int32_t k0, k1;  // multiples of 2*KSTEP
     uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
                      // bit 1: all waves of the workgroup run an item of this length now
