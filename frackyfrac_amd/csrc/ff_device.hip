@@ -279,21 +279,24 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
 // sample-major (a lane's 16 consecutive branches are one 16-byte load), staged through
 // LDS in 128 x 64-byte slabs with a padded 80-byte row stride (conflict-free ds_read_b128).
 
-constexpr int M_TILE = 128;    // workgroup tile: 128 i-samples x 128 j-samples, 4 waves of 64 x 64
-constexpr int M_KSLAB = 128;   // branches per LDS slab (four K = 32 MFMA steps)
-constexpr int M_STRIDE = 144;  // LDS row stride in bytes (128 + 16: conflict-free ds_read_b128)
-constexpr int M_CHUNKS = M_TILE * M_KSLAB / 16 / 256;  // 16-byte chunks per thread and operand slab
+constexpr int M_TILE_I = 256;  // workgroup tile: 256 i-samples x 128 j-samples,
+constexpr int M_TILE_J = 128;  //   8 waves (4 x 2) of 64 x 64, i.e. 2 x 2 MFMA tiles per wave and digit plane
+constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps)
+constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
+constexpr int M_ROWS = M_TILE_I + M_ND * M_TILE_J;  // 512 operand rows per slab
+constexpr int M_STAGE = M_ROWS * M_KSLAB;           // 32 KiB per LDS stage, rows unpadded
+constexpr int M_STAGES = 4;                         // slab S lives in stage S % 4
 
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 
-// One unit of work: a 128 x 128 tile over the branch slabs [k0, k1) for `nd` consecutive
-// digit planes starting at `d0`.  Every item adds its share of U = W_i + W_j - 2*common
-// to num[] atomically (mod 2^32; U < 2^32): the item with `first` also brings W_i + W_j.
+// One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
+// d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]
+// atomically (mod 2^32; U < 2^32); the item with `first` also brings W_i + W_j.
 struct MItem {
     int32_t i0, j0;
     int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
-    int32_t d0, nd;  // digit planes d0 .. d0+nd-1, nd in {1, 2}
+    int32_t d0, nd;  // nd in {1, 2}
     int32_t first;
     int32_t pad;
 };
@@ -319,119 +322,128 @@ __global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int3
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
 }
 
-template <int ND>
-__device__ __forceinline__ void mfma_item(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
-                                          int64_t plane, const MItem item, const unsigned long long *__restrict__ W,
-                                          uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                                          int64_t slot_begin, int8_t *lds)
+// Persistent: workgroup g runs items[item_ptr[g] .. item_ptr[g+1]).
+//
+// Operand slabs go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
+// ds_write), three slabs ahead of the multiply, into a ring of four 32-KiB stages; each
+// wave issues four 1-KiB pieces per slab.  One raw s_barrier per slab: behind it every
+// wave's pieces of slab S have landed (each wave first waits on its own vmcnt) and every
+// wave is done reading slab S-1, whose stage the pieces of slab S+3 may now overwrite.
+// LDS rows are 64 bytes, unpadded (the DMA writes linearly); a 16-byte chunk c of row r sits
+// in slot c ^ ((r >> 2) & 3), applied on the global source address of the DMA and again on
+// the fragment reads, which makes the 16-lane ds_read_b128 groups conflict-free.
+__device__ __forceinline__ void mfma_wait_vmcnt(int pieces_in_flight_allowed)
 {
-    int8_t *lds_a = lds;                                  // [128][M_STRIDE]
-    int8_t *lds_b = lds + M_TILE * M_STRIDE;              // [ND][128][M_STRIDE]
+    if (pieces_in_flight_allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (pieces_in_flight_allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2)
+void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
+                             int64_t plane, const MItem *__restrict__ items,
+                             const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
+                             uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                             int64_t slot_begin)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
-    // slab copy: 128 rows x M_KSLAB bytes in 16-byte chunks, M_CHUNKS per thread:
-    // chunk c = tid + 256 q -> row c / (M_KSLAB/16), column (c % (M_KSLAB/16)) * 16
-    constexpr int CPR = M_KSLAB / 16;                     // chunks per row
-    constexpr int RSTEP = 256 / CPR;                      // rows between a thread's chunks
-    const int c16 = (tid % CPR) * 16, rq = tid / CPR;
-    const int8_t *ga = P8 + (int64_t)(item.i0 + rq) * ldb + item.k0 + c16;
-    const int8_t *gb = K8 + (int64_t)item.d0 * plane + (int64_t)(item.j0 + rq) * ldb + item.k0 + c16;
-    const int64_t row32 = (int64_t)RSTEP * ldb;
-    mfma_v16i acc[ND][2][2];
+    const int it_begin = item_ptr[blockIdx.x], it_end = item_ptr[blockIdx.x + 1];
+    // fragment read offsets inside a stage (bytes), per m / n tile and k step, swizzled
+    const int arow = wi * 64 + (lane & 31), brow = M_TILE_I + wj * 64 + (lane & 31);
+    for (int it = it_begin; it < it_end; ++it) {
+        const MItem item = items[it];
+        const int nd = item.nd;
+        // this wave's four DMA pieces per slab: piece q covers stage rows (4 * wave + q) * 16 .. +16;
+        // lane l moves row + l / 4, slot l % 4, i.e. source chunk (l % 4) ^ ((row >> 2) & 3)
+        const int8_t *src[4];
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+        for (int q = 0; q < 4; ++q) {
+            const int row = (4 * wave + q) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            const int8_t *base;
+            if (row < M_TILE_I) base = P8 + (int64_t)(item.i0 + row) * ldb;
+            else {
+                const int p = (row - M_TILE_I) / M_TILE_J, jr = (row - M_TILE_I) % M_TILE_J;
+                base = K8 + (int64_t)(item.d0 + (p < nd ? p : 0)) * plane + (int64_t)(item.j0 + jr) * ldb;
+            }
+            src[q] = base + item.k0 + chunk * 16;
+        }
+        mfma_v16i acc[M_ND][2][2];
+#pragma unroll
+        for (int d = 0; d < M_ND; ++d)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
+        const int nslab = (item.k1 - item.k0) / M_KSLAB;
+        // previous item: its atomics are out of vmcnt, and every wave is done with the ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto issue = [&](int slab) {
+            int8_t *dst = mfma_lds + (slab % M_STAGES) * M_STAGE + (4 * wave) * 16 * M_KSLAB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src[q] + (int64_t)slab * M_KSLAB),
+                                                 (void __attribute__((address_space(3))) *)(dst + q * 16 * M_KSLAB), 16, 0, 0);
+        };
+        for (int p = 0; p < 3 && p < nslab; ++p) issue(p);
+        for (int sl = 0; sl < nslab; ++sl) {
+            // pieces of later slabs this wave already has in flight: min(nslab - 1 - sl, 2) * 4
+            const int later = nslab - 1 - sl;
+            mfma_wait_vmcnt(later >= 2 ? 8 : later * 4);
+            __builtin_amdgcn_s_barrier();
+            if (sl + 3 < nslab) issue(sl + 3);
+            const int8_t *st = mfma_lds + (sl % M_STAGES) * M_STAGE;
+#pragma unroll
+            for (int kt = 0; kt < M_KSLAB / 32; ++kt) {
+                const int c = 2 * kt + (lane >> 5);
+                mfma_v4i a[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int r = arow + m * 32;
+                    a[m] = *(const mfma_v4i *)(st + r * M_KSLAB + ((c ^ ((r >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int d = 0; d < M_ND; ++d) {
+                    mfma_v4i b[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int r = brow + d * M_TILE_J + n * 32;
+                        b[n] = *(const mfma_v4i *)(st + r * M_KSLAB + ((c ^ ((r >> 2) & 3)) << 4));
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[d][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[d][m][n], 0, 0, 0);
+                }
+            }
+        }
+        // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = item.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < row_begin || i >= row_end) continue;
+                const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
-    const int frag_off = (lane & 31) * M_STRIDE + 16 * (lane >> 5);
-    // register-prefetched single LDS buffer: slab k+1 travels global -> registers while slab k
-    // is multiplied out of LDS
-    mfma_v4i pa[M_CHUNKS], pb[ND][M_CHUNKS];
-#pragma unroll
-    for (int q = 0; q < M_CHUNKS; ++q) {
-        pa[q] = *(const mfma_v4i *)(ga + q * row32);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) pb[d][q] = *(const mfma_v4i *)(gb + d * plane + q * row32);
+                for (int n = 0; n < 2; ++n) {
+                    const int64_t j = item.j0 + wj * 64 + n * 32 + (lane & 31);
+                    if (j >= i) continue;
+                    uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
+                    if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
+                    // this item's share of result = W_i + W_j - 2 * common, modulo 2^32
+                    const uint32_t v = wi_ + (item.first ? (uint32_t)W[j] : 0u) - 2u * common;
+                    if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
+                }
+            }
     }
-    const int nk = item.k1 - item.k0;
-    for (int k = 0; k < nk; k += M_KSLAB) {
-        __syncthreads();  // everyone is done reading the previous slab
-#pragma unroll
-        for (int q = 0; q < M_CHUNKS; ++q) {
-            *(mfma_v4i *)(lds_a + (rq + RSTEP * q) * M_STRIDE + c16) = pa[q];
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-                *(mfma_v4i *)(lds_b + d * (M_TILE * M_STRIDE) + (rq + RSTEP * q) * M_STRIDE + c16) = pb[d][q];
-        }
-        __syncthreads();
-        if (k + M_KSLAB < nk) {
-#pragma unroll
-            for (int q = 0; q < M_CHUNKS; ++q) {
-                pa[q] = *(const mfma_v4i *)(ga + k + M_KSLAB + q * row32);
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    pb[d][q] = *(const mfma_v4i *)(gb + d * plane + k + M_KSLAB + q * row32);
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < M_KSLAB / 32; ++kt) {
-            mfma_v4i a[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                a[m] = *(const mfma_v4i *)(lds_a + (wi * 64 + m * 32) * M_STRIDE + kt * 32 + frag_off);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                mfma_v4i b[2];
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    b[n] = *(const mfma_v4i *)(lds_b + d * (M_TILE * M_STRIDE) + (wj * 64 + n * 32) * M_STRIDE +
-                                               kt * 32 + frag_off);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[d][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[d][m][n], 0, 0, 0);
-            }
-        }
-    }
-    // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t i = item.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (i < row_begin || i >= row_end) continue;
-            const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int64_t j = item.j0 + wj * 64 + n * 32 + (lane & 31);
-                if (j >= i) continue;
-                uint32_t common = 0;
-#pragma unroll
-                for (int d = 0; d < ND; ++d) common += (uint32_t)acc[d][m][n][r] << (7 * (item.d0 + d));
-                // this item's share of result = W_i + W_j - 2 * common, modulo 2^32
-                const uint32_t v = wi_ + (item.first ? (uint32_t)W[j] : 0u) - 2u * common;
-                if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
-            }
-        }
-}
-
-__global__ __launch_bounds__(256, 2)
-void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
-                             int64_t plane, const MItem *__restrict__ items,
-                             const unsigned long long *__restrict__ W, uint32_t *__restrict__ num,
-                             int64_t row_begin, int64_t row_end, int64_t slot_begin)
-{
-    extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];
-    const MItem item = items[blockIdx.x];
-    if (item.nd == 2)
-        mfma_item<2>(P8, K8, ldb, plane, item, W, num, row_begin, row_end, slot_begin, mfma_lds);
-    else
-        mfma_item<1>(P8, K8, ldb, plane, item, W, num, row_begin, row_end, slot_begin, mfma_lds);
 }
 
 // ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
@@ -695,7 +707,8 @@ struct ff_plan {
     int64_t m_ldb = 0, m_plane = 0;
     int m_digits = 0;
     MItem *d_mitems = nullptr;
-    int n_mitems = 0;
+    int32_t *d_mitem_ptr = nullptr;
+    int n_mitems = 0, n_mgroups = 0;
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -993,6 +1006,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_P8);
     (void)hipFree(pl->d_K8);
     (void)hipFree(pl->d_mitems);
+    (void)hipFree(pl->d_mitem_ptr);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_xtiles);
@@ -1242,7 +1256,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
         pl->m_digits = digits;
         inf.n_digits = digits;
-        const int64_t n8 = round_up(N, M_TILE);
+        const int64_t n8 = round_up(N, M_TILE_I);
         const int64_t ldb = round_up(B, M_KSLAB);  // whole slabs
         pl->m_ldb = ldb;
         pl->m_plane = n8 * ldb;
@@ -1265,44 +1279,85 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());
         (void)hipFree(d_klen);
-        std::vector<Tile> tiles;
-        build_tiles(N, inf.row_begin, inf.row_end, M_TILE, M_TILE, false, &tiles);
-        // digit planes in groups of two (one sweep of the presence operand serves both);
-        // each (tile, group) is cut into `split` branch ranges so that the grid has several
-        // workgroups per CU slot and the last round of workgroups is short
-        const int64_t slabs = ldb / M_KSLAB;
-        int split = env_int("FF_MFMA_SPLIT", 0);
-        const int groups = (digits + 1) / 2;
-        if (split <= 0) {
-            const int64_t want = (int64_t)prop.multiProcessorCount * 4;  // two rounds of 2 workgroups per CU
-            split = (int)std::max<int64_t>(1, (want + (int64_t)tiles.size() * groups - 1) /
-                                                  std::max<int64_t>(1, (int64_t)tiles.size() * groups));
+        // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
+        // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
+        // 32 workgroups of one XCD then share their operand rows through that XCD's L2
+        // (without this every slab of every tile came over the fabric: 2.7 GB per pass).
+        struct MT {
+            int32_t i0, j0;
+        };
+        std::vector<MT> tiles;
+        for (int64_t i0 = inf.row_begin / M_TILE_I * M_TILE_I; i0 < inf.row_end; i0 += M_TILE_I) {
+            const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + M_TILE_I, inf.row_end) - 1, N);
+            for (int64_t j0 = 0; j0 < w; j0 += M_TILE_J) tiles.push_back({(int32_t)i0, (int32_t)j0});
         }
-        split = (int)std::min<int64_t>(split, std::max<int64_t>(1, slabs / 8));  // >= 8 slabs per item
-        std::vector<MItem> mi;
-        for (int g = 0; g < groups; ++g)
-            for (int sp = 0; sp < split; ++sp)
-                for (const Tile &t : tiles) {
-                    const int64_t s0 = slabs * sp / split, s1 = slabs * (sp + 1) / split;
-                    if (s1 <= s0) continue;
-                    MItem it{};
-                    it.i0 = t.i0;
-                    it.j0 = t.j0;
-                    it.k0 = (int32_t)(s0 * M_KSLAB);
-                    it.k1 = (int32_t)(s1 * M_KSLAB);
-                    it.d0 = 2 * g;
-                    it.nd = std::min(2, digits - 2 * g);
-                    it.first = (g == 0 && sp == 0) ? 1 : 0;
-                    mi.push_back(it);
+        std::sort(tiles.begin(), tiles.end(), [](const MT &x, const MT &y) {
+            const int64_t bx = ((int64_t)(x.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(x.j0 / (8 * M_TILE_J));
+            const int64_t by = ((int64_t)(y.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(y.j0 / (8 * M_TILE_J));
+            if (bx != by) return bx < by;
+            if (x.i0 != y.i0) return x.i0 < y.i0;
+            return x.j0 < y.j0;
+        });
+        // Units = (digit group, tile).  Main rounds: whole units, one per workgroup, workgroup
+        // g of XCD g % 8 taking unit 32 * (g % 8) + g / 8 of the round, so all workgroups
+        // sweep the branches in step.  Remainder (< G units): cut stream-K style into G equal
+        // slab ranges so that every workgroup ends at the same time.
+        const int64_t slabs = ldb / M_KSLAB;
+        const int groups = (digits + M_ND - 1) / M_ND;
+        const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
+        pl->n_mgroups = G;
+        const int64_t units = (int64_t)groups * (int64_t)tiles.size();
+        auto make_item = [&](int64_t unit, int64_t s0, int64_t s1) {
+            const int64_t grp = unit / (int64_t)tiles.size(), t = unit % (int64_t)tiles.size();
+            MItem itm{};
+            itm.i0 = tiles[(size_t)t].i0;
+            itm.j0 = tiles[(size_t)t].j0;
+            itm.k0 = (int32_t)(s0 * M_KSLAB);
+            itm.k1 = (int32_t)(s1 * M_KSLAB);
+            itm.d0 = (int32_t)(M_ND * grp);
+            itm.nd = std::min(M_ND, digits - M_ND * (int)grp);
+            itm.first = (grp == 0 && s0 == 0) ? 1 : 0;
+            return itm;
+        };
+        std::vector<std::vector<MItem>> per((size_t)G);
+        const int64_t rounds = units / G;
+        const int per_xcd = std::max(1, G / 8);
+        for (int64_t r = 0; r < rounds; ++r)
+            for (int g = 0; g < G; ++g) {
+                const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
+                per[(size_t)g].push_back(make_item(r * G + local, 0, slabs));
+            }
+        const int64_t rem_units = units - rounds * G;
+        if (rem_units > 0) {
+            const int64_t total = rem_units * slabs;
+            const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
+            for (int g = 0; g < G; ++g) {
+                int64_t a2 = (int64_t)g * share;
+                const int64_t b2 = std::min(total, a2 + share);
+                while (a2 < b2) {
+                    const int64_t unit = a2 / slabs, s0 = a2 % slabs;
+                    const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
+                    per[(size_t)g].push_back(make_item(rounds * G + unit, s0, s1));
+                    a2 += s1 - s0;
                 }
+            }
+        }
+        std::vector<MItem> mi;
+        std::vector<int32_t> mptr((size_t)G + 1, 0);
+        for (int g = 0; g < G; ++g) {
+            mi.insert(mi.end(), per[(size_t)g].begin(), per[(size_t)g].end());
+            mptr[(size_t)g + 1] = (int32_t)mi.size();
+        }
         pl->n_mitems = (int)mi.size();
         inf.n_tiles = (int64_t)tiles.size();
         inf.n_items = (int64_t)mi.size();
-        inf.n_wave_slots = (int64_t)mi.size() * 4;
-        inf.elements = (double)tiles.size() * M_TILE * M_TILE * (double)ldb * digits;
+        inf.n_wave_slots = (int64_t)G * 8;
+        inf.elements = (double)tiles.size() * M_TILE_I * M_TILE_J * (double)ldb * digits;
         FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
+        FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
         if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
-        pl->lds_bytes = (size_t)3 * M_TILE * M_STRIDE;
+        FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
+        pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
         FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
         FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
@@ -1458,9 +1513,9 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->mfma) {
             if (pl->n_mitems > 0)
-                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mitems), dim3(256), pl->lds_bytes, st>>>(
-                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_W, pl->d_num, inf.row_begin,
-                    inf.row_end, inf.slot_begin);
+                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
+                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
+                    inf.row_begin, inf.row_end, inf.slot_begin);
         } else if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
