@@ -931,20 +931,34 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     if (rows > 0) {
         int64_t done = 0;  // full-width tiles scheduled in main rounds
         if (T > 0) {
-            int64_t S = T >= U ? 1 : (U + T - 1) / T;
+            // Choose the split S by estimated makespan (unit: one full tile on one wave):
+            // rounds of `pr` tiles take 1/S each; what is left over is cut stream-K style and
+            // runs about 15 % slower per term (its waves are not on common rows).  pr is a
+            // multiple of the workgroup size, so the 8 waves of a workgroup hold the same range
+            // index and hence equally long items (they may then barrier together); a round may
+            // leave slots idle when the shard has fewer than U/S tiles.
             const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
-            S = std::min(S, max_split);
+            int64_t S = 1, per_round = 0;
+            double best = 1e300;
+            for (int64_t cand = 1; cand <= std::min<int64_t>(16, max_split); ++cand) {
+                const int64_t pr = std::min<int64_t>(U / cand, T) / WAVES_PER_WG * WAVES_PER_WG;
+                if (pr <= 0) continue;
+                const int64_t rounds = T / pr, rem = T - rounds * pr;
+                const double est = (double)rounds / (double)cand +
+                                   1.15 * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
+                if (est < best - 1e-9) {
+                    best = est;
+                    S = cand;
+                    per_round = pr;
+                }
+            }
             const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
-            // tiles per main round: a multiple of the workgroup size, so the 8 waves of a
-            // workgroup hold the same range index and hence equally long items (they may
-            // then barrier together)
-            const int64_t per_round = U / S / WAVES_PER_WG * WAVES_PER_WG;
             const int64_t rounds = per_round > 0 ? T / per_round : 0;
             for (int64_t r = 0; r < rounds; ++r)
                 for (int64_t q = 0; q < per_round; ++q) {
                     const Tile &t = wide[(size_t)(r * per_round + q)];
                     for (int64_t sidx = 0; sidx < S; ++sidx) {
-                        // the S ranges of a tile go to waves U/S apart: neighbouring waves keep
+                        // the S ranges of a tile go to waves per_round apart: neighbouring waves keep
                         // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
                         const int u = (int)(sidx * per_round + q);
                         push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
