@@ -32,33 +32,11 @@
 #include <vector>
 
 #include "ff_host.hpp"
+#include "ff_schedule.hpp"
 
-// ----------------------------------------------------------------------------
-// Geometry
-// ----------------------------------------------------------------------------
 namespace {
 
-constexpr int TILE_I = 32;    // rows of a wave's pair tile: samples held in SGPRs
-constexpr int TILE_J = 256;   // columns: 4 per lane (one 16-byte load per lane and row)
-constexpr int KSTEP = 8;      // branch rows per vector buffer; the loop body covers 2*KSTEP rows
-constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefetch
-constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
-constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
-constexpr int X_TILE_J = 64;
-
-struct Item {        // one unit of work for a persistent wave: a pair tile over a
-    int32_t i0, j0;  // branch range [k0, k1)
-    int32_t k0, k1;  // multiples of 2*KSTEP
-    uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
-                     // bit 1: all waves of the workgroup run an item of this length now
-                     // bit 2: half-width tile (32 x 128)
-    int32_t pad[3];
-};
-static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
-
-struct XTile {
-    int32_t i0, j0;
-};
+using namespace ff::sched;
 
 // ----------------------------------------------------------------------------
 // Device code
@@ -279,28 +257,8 @@ __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj
 // sample-major (a lane's 16 consecutive branches are one 16-byte load), staged through
 // LDS in 128 x 64-byte slabs with a padded 80-byte row stride (conflict-free ds_read_b128).
 
-constexpr int M_TILE_I = 256;  // workgroup tile: 256 i-samples x 128 j-samples,
-constexpr int M_TILE_J = 128;  //   8 waves (4 x 2) of 64 x 64, i.e. 2 x 2 MFMA tiles per wave and digit plane
-constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps)
-constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
-constexpr int M_ROWS = M_TILE_I + M_ND * M_TILE_J;  // 512 operand rows per slab
-constexpr int M_STAGE = M_ROWS * M_KSLAB;           // 32 KiB per LDS stage, rows unpadded
-constexpr int M_STAGES = 4;                         // slab S lives in stage S % 4
-
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
-
-// One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
-// d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]
-// atomically (mod 2^32; U < 2^32); the item with `first` also brings W_i + W_j.
-struct MItem {
-    int32_t i0, j0;
-    int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
-    int32_t d0, nd;  // nd in {1, 2}
-    int32_t first;
-    int32_t pad;
-};
-static_assert(sizeof(MItem) == 32, "MItem must be 32 bytes");
 
 // P8 / K8 planes from the flat nodes: one workgroup per sample.
 __global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
@@ -729,7 +687,6 @@ namespace {
                             hipGetErrorString(e_));                                           \
     } while (0)
 
-int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 int env_int(const char *name, int dflt)
 {
@@ -875,132 +832,6 @@ Quant choose_quant(const DeviceCsr &c, bool weighted)
         q.klen[(size_t)b] = (uint32_t)std::llrint(std::ldexp(c.h_len[(size_t)b], q.e));
     q.fixed_ok = true;
     return q;
-}
-
-struct Tile {
-    int32_t i0, j0;
-    int32_t narrow;  // 1: 32 x 128 (the tile overhangs the diagonal by more than half)
-};
-
-// Pair tiles of the shard, row-block major (consecutive tiles share their rows).  tj is
-// the full tile width; with allow_narrow the last tile of a row block is half as wide
-// when at most tj/2 of its columns lie below the diagonal.
-void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles)
-{
-    tiles->clear();
-    if (re <= rb) return;
-    for (int64_t i0 = rb / ti * ti; i0 < re; i0 += ti) {
-        const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + ti, re) - 1, N);  // valid columns: j < w
-        for (int64_t j0 = 0; j0 < w; j0 += tj) {
-            const bool narrow = allow_narrow && (w - j0) <= tj / 2;
-            tiles->push_back({(int32_t)i0, (int32_t)j0, narrow ? 1 : 0});
-        }
-    }
-}
-
-// Balances tiles over U persistent waves.
-//
-//  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
-//    S = ceil(U / T) (1 when there are at least U tiles), and U/S tiles are handed out per
-//    round, one range per wave.  All waves of a round then sweep the branches in step on
-//    S fronts, so the rows they read are shared through L2 (each XCD's 256 waves read the
-//    same few rows; measured: without this alignment 88 % of the loads miss L2).
-//  * Remainder.  The last < U/S full tiles and all half-width tiles are cut stream-K
-//    style into U ranges of equal cost (a half-width row costs half) so that every wave
-//    ends at the same time.
-//
-// Ranges that share a tile add their partial sums atomically; the sums are integers, so
-// the result does not depend on the order.
-void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
-                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
-{
-    std::vector<Tile> wide, rest;
-    for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
-    const int64_t T = (int64_t)wide.size();
-    std::vector<std::vector<Item>> per((size_t)U);
-    auto push = [&](int u, const Tile &t, int64_t k0, int64_t k1) {
-        if (k1 <= k0) return;
-        Item it{};
-        it.i0 = t.i0;
-        it.j0 = t.j0;
-        it.k0 = (int32_t)k0;
-        it.k1 = (int32_t)k1;
-        it.flags = ((k0 == 0 && k1 == rows) ? 0u : 1u) | (t.narrow ? 4u : 0u);
-        per[(size_t)u].push_back(it);
-    };
-    if (rows > 0) {
-        int64_t done = 0;  // full-width tiles scheduled in main rounds
-        if (T > 0) {
-            // Choose the split S by estimated makespan (unit: one full tile on one wave):
-            // rounds of `pr` tiles take 1/S each; what is left over is cut stream-K style and
-            // runs about 15 % slower per term (its waves are not on common rows).  pr is a
-            // multiple of the workgroup size, so the 8 waves of a workgroup hold the same range
-            // index and hence equally long items (they may then barrier together); a round may
-            // leave slots idle when the shard has fewer than U/S tiles.
-            const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
-            int64_t S = 1, per_round = 0;
-            double best = 1e300;
-            for (int64_t cand = 1; cand <= std::min<int64_t>(16, max_split); ++cand) {
-                const int64_t pr = std::min<int64_t>(U / cand, T) / WAVES_PER_WG * WAVES_PER_WG;
-                if (pr <= 0) continue;
-                const int64_t rounds = T / pr, rem = T - rounds * pr;
-                const double est = (double)rounds / (double)cand +
-                                   1.15 * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
-                if (est < best - 1e-9) {
-                    best = est;
-                    S = cand;
-                    per_round = pr;
-                }
-            }
-            const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
-            const int64_t rounds = per_round > 0 ? T / per_round : 0;
-            for (int64_t r = 0; r < rounds; ++r)
-                for (int64_t q = 0; q < per_round; ++q) {
-                    const Tile &t = wide[(size_t)(r * per_round + q)];
-                    for (int64_t sidx = 0; sidx < S; ++sidx) {
-                        // the S ranges of a tile go to waves per_round apart: neighbouring waves keep
-                        // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
-                        const int u = (int)(sidx * per_round + q);
-                        push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
-                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
-                            per[(size_t)u].back().flags |= 2u;
-                    }
-                }
-            done = rounds * per_round;
-        }
-        rest.insert(rest.begin(), wide.begin() + done, wide.end());  // leftover full tiles first
-        if (!rest.empty()) {
-            // cost units: a full-width row = 2, a half-width row = 1
-            std::vector<int64_t> start(rest.size() + 1, 0);
-            for (size_t t = 0; t < rest.size(); ++t) start[t + 1] = start[t] + rows * (rest[t].narrow ? 1 : 2);
-            const int64_t total = start.back();
-            const int64_t share = round_up((total + U - 1) / U, 4 * KSTEP);  // 32 units: 16 wide or 32 narrow rows
-            size_t t = 0;
-            for (int u = 0; u < U; ++u) {
-                int64_t a = (int64_t)u * share;
-                const int64_t b = std::min(total, a + share);
-                while (a < b) {
-                    while (start[t + 1] <= a) ++t;
-                    const int64_t unit = rest[t].narrow ? 1 : 2;
-                    const int64_t k0 = (a - start[t]) / unit;
-                    const int64_t k1 = std::min<int64_t>(rows, (std::min(b, start[t + 1]) - start[t]) / unit);
-                    push(u, rest[t], k0, k1);
-                    a = start[t] + k1 * unit;
-                }
-            }
-        }
-    }
-    items->clear();
-    item_ptr->assign((size_t)U + 1, 0);
-    double el = 0;
-    for (int u = 0; u < U; ++u) {
-        for (const Item &it : per[(size_t)u]) {
-            items->push_back(it);
-            el += (double)(it.k1 - it.k0) * TILE_I * ((it.flags & 4u) ? TILE_J / 2 : TILE_J);
-        }
-        (*item_ptr)[(size_t)u + 1] = (int32_t)items->size();
-    }
-    *elements = el;
 }
 
 void plan_free_device(ff_plan *pl)
@@ -1293,80 +1124,17 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());
         (void)hipFree(d_klen);
-        // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
-        // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
-        // 32 workgroups of one XCD then share their operand rows through that XCD's L2
-        // (without this every slab of every tile came over the fabric: 2.7 GB per pass).
-        struct MT {
-            int32_t i0, j0;
-        };
-        std::vector<MT> tiles;
-        for (int64_t i0 = inf.row_begin / M_TILE_I * M_TILE_I; i0 < inf.row_end; i0 += M_TILE_I) {
-            const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + M_TILE_I, inf.row_end) - 1, N);
-            for (int64_t j0 = 0; j0 < w; j0 += M_TILE_J) tiles.push_back({(int32_t)i0, (int32_t)j0});
-        }
-        std::sort(tiles.begin(), tiles.end(), [](const MT &x, const MT &y) {
-            const int64_t bx = ((int64_t)(x.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(x.j0 / (8 * M_TILE_J));
-            const int64_t by = ((int64_t)(y.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(y.j0 / (8 * M_TILE_J));
-            if (bx != by) return bx < by;
-            if (x.i0 != y.i0) return x.i0 < y.i0;
-            return x.j0 < y.j0;
-        });
-        // Units = (digit group, tile).  Main rounds: whole units, one per workgroup, workgroup
-        // g of XCD g % 8 taking unit 32 * (g % 8) + g / 8 of the round, so all workgroups
-        // sweep the branches in step.  Remainder (< G units): cut stream-K style into G equal
-        // slab ranges so that every workgroup ends at the same time.
         const int64_t slabs = ldb / M_KSLAB;
-        const int groups = (digits + M_ND - 1) / M_ND;
         const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
         pl->n_mgroups = G;
-        const int64_t units = (int64_t)groups * (int64_t)tiles.size();
-        auto make_item = [&](int64_t unit, int64_t s0, int64_t s1) {
-            const int64_t grp = unit / (int64_t)tiles.size(), t = unit % (int64_t)tiles.size();
-            MItem itm{};
-            itm.i0 = tiles[(size_t)t].i0;
-            itm.j0 = tiles[(size_t)t].j0;
-            itm.k0 = (int32_t)(s0 * M_KSLAB);
-            itm.k1 = (int32_t)(s1 * M_KSLAB);
-            itm.d0 = (int32_t)(M_ND * grp);
-            itm.nd = std::min(M_ND, digits - M_ND * (int)grp);
-            itm.first = (grp == 0 && s0 == 0) ? 1 : 0;
-            return itm;
-        };
-        std::vector<std::vector<MItem>> per((size_t)G);
-        const int64_t rounds = units / G;
-        const int per_xcd = std::max(1, G / 8);
-        for (int64_t r = 0; r < rounds; ++r)
-            for (int g = 0; g < G; ++g) {
-                const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
-                per[(size_t)g].push_back(make_item(r * G + local, 0, slabs));
-            }
-        const int64_t rem_units = units - rounds * G;
-        if (rem_units > 0) {
-            const int64_t total = rem_units * slabs;
-            const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
-            for (int g = 0; g < G; ++g) {
-                int64_t a2 = (int64_t)g * share;
-                const int64_t b2 = std::min(total, a2 + share);
-                while (a2 < b2) {
-                    const int64_t unit = a2 / slabs, s0 = a2 % slabs;
-                    const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
-                    per[(size_t)g].push_back(make_item(rounds * G + unit, s0, s1));
-                    a2 += s1 - s0;
-                }
-            }
-        }
         std::vector<MItem> mi;
-        std::vector<int32_t> mptr((size_t)G + 1, 0);
-        for (int g = 0; g < G; ++g) {
-            mi.insert(mi.end(), per[(size_t)g].begin(), per[(size_t)g].end());
-            mptr[(size_t)g + 1] = (int32_t)mi.size();
-        }
+        std::vector<int32_t> mptr;
+        const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, digits, G, &mi, &mptr);
         pl->n_mitems = (int)mi.size();
-        inf.n_tiles = (int64_t)tiles.size();
+        inf.n_tiles = n_mtiles;
         inf.n_items = (int64_t)mi.size();
         inf.n_wave_slots = (int64_t)G * 8;
-        inf.elements = (double)tiles.size() * M_TILE_I * M_TILE_J * (double)ldb * digits;
+        inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)ldb * digits;
         FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
         FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
         if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));

@@ -1,0 +1,246 @@
+// ff_schedule.cpp -- host-side work schedules of the pair kernels (see ff_schedule.hpp).
+#include "ff_schedule.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "frackyfrac_amd.h"
+
+namespace ff {
+namespace sched {
+
+// Pair tiles of the shard, row-block major (consecutive tiles share their rows).  tj is
+// the full tile width; with allow_narrow the last tile of a row block is half as wide
+// when at most tj/2 of its columns lie below the diagonal.
+void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles)
+{
+    tiles->clear();
+    if (re <= rb) return;
+    for (int64_t i0 = rb / ti * ti; i0 < re; i0 += ti) {
+        const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + ti, re) - 1, N);  // valid columns: j < w
+        for (int64_t j0 = 0; j0 < w; j0 += tj) {
+            const bool narrow = allow_narrow && (w - j0) <= tj / 2;
+            tiles->push_back({(int32_t)i0, (int32_t)j0, narrow ? 1 : 0});
+        }
+    }
+}
+
+// Balances tiles over U persistent waves.
+//
+//  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
+//    S = ceil(U / T) (1 when there are at least U tiles), and U/S tiles are handed out per
+//    round, one range per wave.  All waves of a round then sweep the branches in step on
+//    S fronts, so the rows they read are shared through L2 (each XCD's 256 waves read the
+//    same few rows; measured: without this alignment 88 % of the loads miss L2).
+//  * Remainder.  The last < U/S full tiles and all half-width tiles are cut stream-K
+//    style into U ranges of equal cost (a half-width row costs half) so that every wave
+//    ends at the same time.
+//
+// Ranges that share a tile add their partial sums atomically; the sums are integers, so
+// the result does not depend on the order.
+void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
+                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
+{
+    std::vector<Tile> wide, rest;
+    for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
+    const int64_t T = (int64_t)wide.size();
+    std::vector<std::vector<Item>> per((size_t)U);
+    auto push = [&](int u, const Tile &t, int64_t k0, int64_t k1) {
+        if (k1 <= k0) return;
+        Item it{};
+        it.i0 = t.i0;
+        it.j0 = t.j0;
+        it.k0 = (int32_t)k0;
+        it.k1 = (int32_t)k1;
+        it.flags = ((k0 == 0 && k1 == rows) ? 0u : 1u) | (t.narrow ? 4u : 0u);
+        per[(size_t)u].push_back(it);
+    };
+    if (rows > 0) {
+        int64_t done = 0;  // full-width tiles scheduled in main rounds
+        if (T > 0) {
+            // Choose the split S by estimated makespan (unit: one full tile on one wave):
+            // rounds of `pr` tiles take 1/S each; what is left over is cut stream-K style and
+            // runs about 15 % slower per term (its waves are not on common rows).  pr is a
+            // multiple of the workgroup size, so the 8 waves of a workgroup hold the same range
+            // index and hence equally long items (they may then barrier together); a round may
+            // leave slots idle when the shard has fewer than U/S tiles.
+            const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
+            int64_t S = 1, per_round = 0;
+            double best = 1e300;
+            for (int64_t cand = 1; cand <= std::min<int64_t>(256, max_split); ++cand) {
+                const int64_t pr = std::min<int64_t>(U / cand, T) / WAVES_PER_WG * WAVES_PER_WG;
+                if (pr <= 0) continue;
+                const int64_t rounds = T / pr, rem = T - rounds * pr;
+                const double est = (double)rounds / (double)cand +
+                                   1.15 * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
+                if (est < best - 1e-9) {
+                    best = est;
+                    S = cand;
+                    per_round = pr;
+                }
+            }
+            const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
+            const int64_t rounds = per_round > 0 ? T / per_round : 0;
+            for (int64_t r = 0; r < rounds; ++r)
+                for (int64_t q = 0; q < per_round; ++q) {
+                    const Tile &t = wide[(size_t)(r * per_round + q)];
+                    for (int64_t sidx = 0; sidx < S; ++sidx) {
+                        // the S ranges of a tile go to waves per_round apart: neighbouring waves keep
+                        // neighbouring tiles (same 32 rows -> shared scalar-cache lines)
+                        const int u = (int)(sidx * per_round + q);
+                        push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
+                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
+                            per[(size_t)u].back().flags |= 2u;
+                    }
+                }
+            done = rounds * per_round;
+        }
+        rest.insert(rest.begin(), wide.begin() + done, wide.end());  // leftover full tiles first
+        if (!rest.empty()) {
+            // cost units: a full-width row = 2, a half-width row = 1
+            std::vector<int64_t> start(rest.size() + 1, 0);
+            for (size_t t = 0; t < rest.size(); ++t) start[t + 1] = start[t] + rows * (rest[t].narrow ? 1 : 2);
+            const int64_t total = start.back();
+            const int64_t share = round_up((total + U - 1) / U, 4 * KSTEP);  // 32 units: 16 wide or 32 narrow rows
+            size_t t = 0;
+            for (int u = 0; u < U; ++u) {
+                int64_t a = (int64_t)u * share;
+                const int64_t b = std::min(total, a + share);
+                while (a < b) {
+                    while (start[t + 1] <= a) ++t;
+                    const int64_t unit = rest[t].narrow ? 1 : 2;
+                    const int64_t k0 = (a - start[t]) / unit;
+                    const int64_t k1 = std::min<int64_t>(rows, (std::min(b, start[t + 1]) - start[t]) / unit);
+                    push(u, rest[t], k0, k1);
+                    a = start[t] + k1 * unit;
+                }
+            }
+        }
+    }
+    items->clear();
+    item_ptr->assign((size_t)U + 1, 0);
+    double el = 0;
+    for (int u = 0; u < U; ++u) {
+        for (const Item &it : per[(size_t)u]) {
+            items->push_back(it);
+            el += (double)(it.k1 - it.k0) * TILE_I * ((it.flags & 4u) ? TILE_J / 2 : TILE_J);
+        }
+        (*item_ptr)[(size_t)u + 1] = (int32_t)items->size();
+    }
+    *elements = el;
+}
+
+
+int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
+                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr)
+{
+    // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
+    // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
+    // 32 workgroups of one XCD then share their operand rows through that XCD's L2
+    // (without this every slab of every tile came over the fabric: 2.7 GB per pass).
+    struct MT {
+        int32_t i0, j0;
+    };
+    std::vector<MT> tiles;
+    for (int64_t i0 = row_begin / M_TILE_I * M_TILE_I; i0 < row_end; i0 += M_TILE_I) {
+        const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + M_TILE_I, row_end) - 1, N);
+        for (int64_t j0 = 0; j0 < w; j0 += M_TILE_J) tiles.push_back({(int32_t)i0, (int32_t)j0});
+    }
+    std::sort(tiles.begin(), tiles.end(), [](const MT &x, const MT &y) {
+        const int64_t bx = ((int64_t)(x.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(x.j0 / (8 * M_TILE_J));
+        const int64_t by = ((int64_t)(y.i0 / (4 * M_TILE_I)) << 32) | (uint32_t)(y.j0 / (8 * M_TILE_J));
+        if (bx != by) return bx < by;
+        if (x.i0 != y.i0) return x.i0 < y.i0;
+        return x.j0 < y.j0;
+    });
+    // Units = (digit group, tile).  Main rounds: whole units, one per workgroup, workgroup
+    // g of XCD g % 8 taking unit 32 * (g % 8) + g / 8 of the round, so all workgroups
+    // sweep the branches in step.  Remainder (< G units): cut stream-K style into G equal
+    // slab ranges so that every workgroup ends at the same time.
+    const int groups = (digits + M_ND - 1) / M_ND;
+    const int64_t units = (int64_t)groups * (int64_t)tiles.size();
+    auto make_item = [&](int64_t unit, int64_t s0, int64_t s1) {
+        const int64_t grp = unit / (int64_t)tiles.size(), t = unit % (int64_t)tiles.size();
+        MItem itm{};
+        itm.i0 = tiles[(size_t)t].i0;
+        itm.j0 = tiles[(size_t)t].j0;
+        itm.k0 = (int32_t)(s0 * M_KSLAB);
+        itm.k1 = (int32_t)(s1 * M_KSLAB);
+        itm.d0 = (int32_t)(M_ND * grp);
+        itm.nd = std::min(M_ND, digits - M_ND * (int)grp);
+        itm.first = (grp == 0 && s0 == 0) ? 1 : 0;
+        return itm;
+    };
+    std::vector<std::vector<MItem>> per((size_t)G);
+    const int64_t rounds = units / G;
+    const int per_xcd = std::max(1, G / 8);
+    for (int64_t r = 0; r < rounds; ++r)
+        for (int g = 0; g < G; ++g) {
+            const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
+            per[(size_t)g].push_back(make_item(r * G + local, 0, slabs));
+        }
+    const int64_t rem_units = units - rounds * G;
+    if (rem_units > 0) {
+        const int64_t total = rem_units * slabs;
+        const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
+        for (int g = 0; g < G; ++g) {
+            int64_t a2 = (int64_t)g * share;
+            const int64_t b2 = std::min(total, a2 + share);
+            while (a2 < b2) {
+                const int64_t unit = a2 / slabs, s0 = a2 % slabs;
+                const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
+                per[(size_t)g].push_back(make_item(rounds * G + unit, s0, s1));
+                a2 += s1 - s0;
+            }
+        }
+    }
+    std::vector<MItem> &mi = *items;
+    std::vector<int32_t> &mptr = *item_ptr;
+    mi.clear();
+    mptr.assign((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) {
+        mi.insert(mi.end(), per[(size_t)g].begin(), per[(size_t)g].end());
+        mptr[(size_t)g + 1] = (int32_t)mi.size();
+    }
+
+    return (int64_t)tiles.size();
+}
+
+}  // namespace sched
+}  // namespace ff
+
+// Diagnostics / tests: the schedule the engine would build for a shard of rows [row_begin,
+// row_end) of n_samples samples with `rows` staged branch rows on a device with n_cu compute
+// units.  kernel = FF_KERNEL_SAD_U32 or FF_KERNEL_MFMA_I8 (then `rows` is the slab count and
+// n_digits applies).  Items come back as 8 int32 each: SAD {i0, j0, k0, k1, flags, 0, 0, 0},
+// MFMA {i0, j0, k0, k1, d0, nd, first, 0}; item_ptr has one entry per wave slot (SAD: 8 per
+// CU) or workgroup (MFMA: one per CU) plus one.  Returns the number of items, or -needed if
+// max_items is too small.
+extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows, int64_t row_begin, int64_t row_end,
+                                     int n_cu, int n_digits, int allow_narrow, int32_t *items_out, int64_t max_items,
+                                     int32_t *item_ptr_out, int64_t *n_tiles_out)
+{
+    using namespace ff::sched;
+    std::vector<int32_t> ptr;
+    int64_t n = 0;
+    if (kernel == FF_KERNEL_MFMA_I8) {
+        std::vector<MItem> items;
+        const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, rows, n_digits, n_cu, &items, &ptr);
+        if (n_tiles_out) *n_tiles_out = nt;
+        n = (int64_t)items.size();
+        if (n > max_items) return -n;
+        if (n) memcpy(items_out, items.data(), sizeof(MItem) * (size_t)n);
+    } else {
+        std::vector<Tile> tiles;
+        build_tiles(n_samples, row_begin, row_end, TILE_I, TILE_J, allow_narrow != 0, &tiles);
+        if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
+        std::vector<Item> items;
+        double elements = 0;
+        build_schedule(tiles, rows, n_cu * WAVES_PER_WG, &items, &ptr, &elements);
+        n = (int64_t)items.size();
+        if (n > max_items) return -n;
+        if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);
+    }
+    memcpy(item_ptr_out, ptr.data(), sizeof(int32_t) * ptr.size());
+    return n;
+}

@@ -1,0 +1,73 @@
+// ff_schedule.hpp -- tile geometry and host-side work schedules of the pair kernels
+// (pure host C++: built with g++, unit-tested on CPU through ff_debug_schedule).
+#pragma once
+
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace ff {
+namespace sched {
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- v_sad_u32 kernel (pair_sad_kernel) and EXACT64 kernel ----
+constexpr int TILE_I = 32;    // rows of a wave's pair tile: samples held in SGPRs
+constexpr int TILE_J = 256;   // columns: 4 per lane (one 16-byte load per lane and row)
+constexpr int KSTEP = 8;      // branch rows per vector buffer; the loop body covers 2*KSTEP rows
+constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefetch
+constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
+constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
+constexpr int X_TILE_J = 64;
+
+struct Item {        // one unit of work for a persistent wave: a pair tile over a
+    int32_t i0, j0;  // branch range [k0, k1)
+    int32_t k0, k1;  // multiples of 2*KSTEP
+    uint32_t flags;  // bit 0: other items add to the same outputs -> atomic add
+                     // bit 1: all waves of the workgroup run an item of this length now
+                     // bit 2: half-width tile (32 x 128)
+    int32_t pad[3];
+};
+static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
+
+struct XTile {
+    int32_t i0, j0;
+};
+
+
+// ---- int8 MFMA kernel (pair_common_mfma_kernel) ----
+constexpr int M_TILE_I = 256;  // workgroup tile: 256 i-samples x 128 j-samples,
+constexpr int M_TILE_J = 128;  //   8 waves (4 x 2) of 64 x 64, i.e. 2 x 2 MFMA tiles per wave and digit plane
+constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps)
+constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
+constexpr int M_ROWS = M_TILE_I + M_ND * M_TILE_J;  // 512 operand rows per slab
+constexpr int M_STAGE = M_ROWS * M_KSLAB;           // 32 KiB per LDS stage, rows unpadded
+constexpr int M_STAGES = 4;                         // slab S lives in stage S % 4
+
+// One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
+// d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]
+// atomically (mod 2^32; U < 2^32); the item with `first` also brings W_i + W_j.
+struct MItem {
+    int32_t i0, j0;
+    int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
+    int32_t d0, nd;  // nd in {1, 2}
+    int32_t first;
+    int32_t pad;
+};
+static_assert(sizeof(MItem) == 32, "MItem must be 32 bytes");
+
+
+struct Tile {
+    int32_t i0, j0;
+    int32_t narrow;  // 1: 32 x 128 (the tile overhangs the diagonal by more than half)
+};
+
+void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles);
+void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std::vector<Item> *items,
+                    std::vector<int32_t> *item_ptr, double *elements);
+// Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
+int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
+                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr);
+
+}  // namespace sched
+}  // namespace ff
