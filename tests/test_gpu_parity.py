@@ -55,6 +55,19 @@ def test_golden_want(name, weighted, ext, precision):
         assert "".join(ff.format_float(x) + "\n" for x in got) == want_text
 
 
+@pytest.mark.parametrize("ext,flag", [(".sparse", ["-s"]), (".dense", [])])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_selfgenerated_fixture_through_the_cli(tmp_path, ext, flag, weighted):
+    """tests/golden/selfgen (oracle-generated, see its README): AUTO precision is EXACT64 at
+    this size, so the CLI must reproduce the committed text byte for byte."""
+    d = GOLDEN + "/selfgen/synth24"
+    out = tmp_path / "out.txt"
+    r = subprocess.run([L.FRCFRC_PATH, *(["-w"] if weighted else []), *flag, "-i", d + ext, "-t", d + ".tree", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text() == open(d + (".weighted.want" if weighted else ".unweighted.want")).read()
+
+
 def test_unifrac_test_go_values():
     """frcfrc/unifrac_test.go:12-74: exact float64 equality (reflect.DeepEqual)."""
     cases = [("(s2:3,s1:1,s3:5);", "s1:1 s2:1\ns3:1 s2:1\n", False, [6.0 / 9.0]),

@@ -197,3 +197,22 @@ def test_prefix_and_threads():
     full = O.unifrac_dists(ip, nodes, ft.dist, True, 1)
     assert np.array_equal(full, O.unifrac_dists(ip, nodes, ft.dist, True, 5))
     assert np.array_equal(full[100:333], O.unifrac_dists(ip, nodes, ft.dist, True, 3, 100, 333))
+
+
+def test_selfgenerated_fixture_is_stable():
+    """tests/golden/selfgen: written by make_selfgen.py from the oracle itself; pins the
+    synthetic generator (numpy PCG64 stream) and the oracle against silent drift."""
+    import os
+    from conftest import GOLDEN
+    from frackyfrac_amd import synth
+    sys_path = os.path.join(GOLDEN, "selfgen")
+    tree, ptr, idx, val = synth.make(24, 40, 0.25, 0xF4AC0063)
+    tree.branch_len[5] = 0.3
+    tree.branch_len[0] = 0.125
+    assert tree.newick() == open(os.path.join(sys_path, "synth24.tree")).read()
+    assert synth.sparse_text(tree, ptr, idx, val) == open(os.path.join(sys_path, "synth24.sparse")).read()
+    otree = O.parse_newick(open(os.path.join(sys_path, "synth24.tree")).read())
+    for loader, ext in ((O.parse_sparse_abundance, ".sparse"), (O.parse_abundance, ".dense")):
+        oab = loader(open(os.path.join(sys_path, "synth24" + ext)).read())
+        for weighted, name in ((False, "synth24.unweighted.want"), (True, "synth24.weighted.want")):
+            assert O.format_output(O.unifrac(oab, otree, weighted)) == open(os.path.join(sys_path, name)).read()
