@@ -188,7 +188,7 @@ def main():
         alg_bytes = 8.0 * shard_pairs + elem_bytes * float(n_samples) * B + 4.0 * B + 4.0 * n_samples
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and info.kernel == 0 and weighted:
+        if os.path.exists(tpath) and info.kernel in (0, 3) and weighted:
             try:
                 traffic = json.load(open(tpath)).get("%s_n%d" % (name, world))
             except Exception:

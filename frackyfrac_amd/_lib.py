@@ -47,7 +47,8 @@ class ff_plan_info(ctypes.Structure):
                 ("n_tiles", c_int64), ("n_items", c_int64), ("n_wave_slots", c_int64),
                 ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32)]
 
-KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel"}
+KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
+                3: "pair_sad_sparse_kernel"}
 
 
 # name -> (restype, argtypes); exactly the symbols include/frackyfrac_amd.h declares

@@ -237,6 +237,160 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ---- Sparse-aware variant of the pair-tile reduction ----------------------------------
+//
+// A branch row on which none of a tile's 32 i-samples has a flat node ("inactive" for that
+// i-block) contributes |0 - q_j| = q_j to each of the tile's sums, whatever the row of the
+// tile.  The wave therefore walks only the ACTIVE rows of its i-block (a precomputed list
+// of row numbers), and accounts for the others in closed form:
+//     U(i,j) = sum_{b active} |q_i(b) - q_j(b)|  +  R_j - sum_{b active} q_j(b),
+// R_j = sum of column j over the item's branch range, from prefix sums kept every 16 rows.
+// Same integers, same results.  At 10 % leaf density 2 % of the (i-block, row) cells are
+// inactive, at 5 % 10 %, at 1 % 51 %, at 0.2 % 82 %: the plan picks this kernel
+// when at least FF_SPARSE_MIN (default 35 %) are.  Rows past the end of the list are replaced by a
+// zero slack row (|0 - 0| = 0), so the loop has no tail and no branches.
+template <int NC>
+__device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
+                                                const uint32_t *__restrict__ arows,
+                                                const uint32_t *__restrict__ aptr16, int64_t aptr_stride,
+                                                const uint32_t *__restrict__ cs16, int32_t zero_row,
+                                                uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                                                int64_t slot_begin, int lane)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+    const int64_t ib = item.i0 / TILE_I;
+    const_u32_ptr pp = (const_u32_ptr)(aptr16 + ib * aptr_stride);
+    const uint32_t a0 = pp[item.k0 / (2 * KSTEP)], a1 = pp[item.k1 / (2 * KSTEP)];
+    const_u32_ptr pr = (const_u32_ptr)arows;
+    const uint32_t *colj = QT + item.j0 + NC * lane;          // per-lane column base
+    const_u32_ptr coli = (const_u32_ptr)(QT + item.i0);      // wave-uniform column base
+    uint32_t acc[NC][TILE_I], z[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        z[c] = 0;
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
+    }
+    auto row_at = [&](uint32_t idx) -> int64_t { return idx < a1 ? (int64_t)pr[idx] : (int64_t)zero_row; };
+    // vector ring of 4 active rows, scalars double-buffered one active row ahead
+    RowVec<NC> v[4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = load_row<NC>(colj + row_at(a0 + q) * ld);
+    uint32_t sA[TILE_I], sB[TILE_I];
+    {
+        const_u32_ptr p0 = coli + row_at(a0) * ld;
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) sA[r] = p0[r];
+    }
+#define FF_ASTEP(Q, SCUR, SNXT)                                                  \
+    {                                                                          \
+        acc[0][0] = sad_u32(SCUR[0], v[Q].v[0], acc[0][0]);                    \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        {                                                                      \
+            const_u32_ptr pn = coli + row_at(t + (Q) + 1) * ld;                \
+            _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = pn[r]; \
+            v[((Q) + 3) & 3] = load_row<NC>(colj + row_at(t + (Q) + 3) * ld);  \
+        }                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
+                if (r || c) acc[c][r] = sad_u32(SCUR[r], v[Q].v[c], acc[c][r]); \
+            }                                                                  \
+        }                                                                      \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) z[c] += v[Q].v[c];      \
+    }
+    for (uint32_t t = a0; t < a1; t += 4) {
+        FF_ASTEP(0, sA, sB)
+        FF_ASTEP(1, sB, sA)
+        FF_ASTEP(2, sA, sB)
+        FF_ASTEP(3, sB, sA)
+    }
+#undef FF_ASTEP
+    // R_j over [k0, k1) from the 16-row prefix sums
+    const int64_t j = item.j0 + NC * lane;
+    uint32_t rj[NC];
+    {
+        const RowVec<NC> hi = load_row<NC>(cs16 + (int64_t)(item.k1 / (2 * KSTEP)) * ld + j);
+        const RowVec<NC> lo = load_row<NC>(cs16 + (int64_t)(item.k0 / (2 * KSTEP)) * ld + j);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rj[c] = hi.v[c] - lo.v[c] - z[c];
+    }
+    const bool atomic = item.flags & 1u;
+#pragma unroll
+    for (int r = 0; r < TILE_I; ++r) {
+        const int64_t i = item.i0 + r;
+        if (i < row_begin || i >= row_end) continue;
+        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (j + c >= i) continue;
+            const uint32_t val = acc[c][r] + rj[c];
+            if (atomic) {
+                if (val) atomicAdd(&num[base + c], val);
+            } else {
+                num[base + c] = val;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
+void pair_sad_sparse_kernel(const uint32_t *__restrict__ QT, int64_t ld,
+                            const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
+                            const uint32_t *__restrict__ arows, const uint32_t *__restrict__ aptr16,
+                            int64_t aptr_stride, const uint32_t *__restrict__ cs16, int32_t zero_row,
+                            uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                            int64_t slot_begin)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * WAVES_PER_WG + wave;
+    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
+    for (int it = it_begin; it < it_end; ++it) {
+        const Item item = items[it];
+        if (item.flags & 4u)
+            run_item_sparse<2>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
+                               slot_begin, lane);
+        else
+            run_item_sparse<4>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
+                               slot_begin, lane);
+    }
+}
+
+// cs16[t][s] = sum of column s over the rows [0, 16 t): one column per lane, sequential over rows.
+__global__ void prefix16_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
+                                uint32_t *__restrict__ cs16)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ld) return;
+    uint32_t run = 0;
+    cs16[s] = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        run += QT[r * ld + s];
+        if ((r & 15) == 15) cs16[((r >> 4) + 1) * ld + s] = run;
+    }
+}
+
+// act64[iblock][w] bit r: branch row 64 w + r has a non-zero value among the 32 samples of
+// i-block `iblock`.  One wave per (i-block, 64 rows), lane = row.
+__global__ void build_activity_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows, int64_t words,
+                                      unsigned long long *__restrict__ act64)
+{
+    const int64_t w = blockIdx.x, iblock = blockIdx.y;
+    const int64_t row = w * 64 + threadIdx.x;
+    uint32_t any = 0;
+    if (row < rows) {
+        const uint4 *p = (const uint4 *)(QT + row * ld + iblock * TILE_I);
+#pragma unroll
+        for (int q = 0; q < TILE_I / 4; ++q) {
+            const uint4 t = p[q];
+            any |= t.x | t.y | t.z | t.w;
+        }
+    }
+    const unsigned long long mask = __ballot(any != 0);
+    if (threadIdx.x == 0) act64[iblock * words + w] = mask;
+}
+
 __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj)
 {
     int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
@@ -652,6 +806,11 @@ struct ff_plan {
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
     int sync_trips = 0;                      // workgroup barrier every this many loop trips (0 = never)
+    // sparse-aware variant: activity bits per (i-block, 16-row trip)
+    bool sparse = false;
+    uint32_t *d_arows = nullptr, *d_aptr16 = nullptr, *d_cs16 = nullptr;
+    int64_t aptr_stride = 0;
+    int32_t zero_row = 0;
     // refinement of nearly-equal pairs: the flat nodes stay on the device
     bool refine = false;
     int64_t *d_indptr = nullptr;
@@ -843,6 +1002,9 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_items);
     (void)hipFree(pl->d_item_ptr);
     (void)hipFree(pl->d_stamps);
+    (void)hipFree(pl->d_arows);
+    (void)hipFree(pl->d_aptr16);
+    (void)hipFree(pl->d_cs16);
     (void)hipFree(pl->d_indptr);
     (void)hipFree(pl->d_ids);
     (void)hipFree(pl->d_abnd);
@@ -1206,6 +1368,56 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         if (!items.empty())
             FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
         FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
+        // activity of every (i-block, branch row): decides between the dense and the
+        // sparse-aware kernel
+        if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
+            const int64_t n_iblocks = ld / TILE_I, words = (rows + SLACK_ROWS + 63) / 64;
+            unsigned long long *d_act64 = nullptr;
+            FF_HIP(hipMalloc(&d_act64, sizeof(unsigned long long) * (size_t)(n_iblocks * words)));
+            build_activity_kernel<<<dim3((unsigned)words, (unsigned)n_iblocks), dim3(64)>>>(pl->d_QT, ld, rows, words,
+                                                                                            d_act64);
+            FF_HIP(hipGetLastError());
+            std::vector<unsigned long long> a64((size_t)(n_iblocks * words));
+            FF_HIP(hipMemcpy(a64.data(), d_act64, sizeof(unsigned long long) * a64.size(), hipMemcpyDeviceToHost));
+            (void)hipFree(d_act64);
+            // only the i-blocks this shard's tiles use count for the decision
+            const int64_t ib0 = inf.row_begin / TILE_I, ib1 = (inf.row_end + TILE_I - 1) / TILE_I;
+            int64_t active = 0;
+            for (int64_t ib = ib0; ib < ib1; ++ib)
+                for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
+            const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
+            const double inactive = 1.0 - (double)active / total;
+            const char *thr = getenv("FF_SPARSE_MIN");
+            // the list walk runs at about 0.7 of the dense loop's rate per row (shallower
+            // prefetch, per-row address arithmetic), so it pays from about a third upwards
+            if (inactive >= (thr && *thr ? atof(thr) : 0.35)) {
+                // per i-block: the list of active rows and, every 16 rows, where the list stands
+                const int64_t marks = rows / (2 * KSTEP) + 1;
+                pl->aptr_stride = marks;
+                std::vector<uint32_t> arows, aptr((size_t)(n_iblocks * marks), 0u);
+                arows.reserve((size_t)active + 16);
+                for (int64_t ib = 0; ib < n_iblocks; ++ib)
+                    for (int64_t r = 0; r <= rows; ++r) {
+                        if (r % (2 * KSTEP) == 0) aptr[(size_t)(ib * marks + r / (2 * KSTEP))] = (uint32_t)arows.size();
+                        if (r < rows && ((a64[(size_t)(ib * words + r / 64)] >> (r % 64)) & 1ull)) arows.push_back((uint32_t)r);
+                    }
+                if (arows.size() >= 0xFFFFFFF0ull)
+                    return ff::fail(FF_ERR_INTERNAL, err, errlen, "active-row list too long");
+                arows.resize(arows.size() + 8, (uint32_t)rows);
+                pl->zero_row = (int32_t)rows;  // first slack row: zero in every column
+                FF_HIP(hipMalloc(&pl->d_arows, sizeof(uint32_t) * arows.size()));
+                FF_HIP(hipMemcpy(pl->d_arows, arows.data(), sizeof(uint32_t) * arows.size(), hipMemcpyHostToDevice));
+                FF_HIP(hipMalloc(&pl->d_aptr16, sizeof(uint32_t) * aptr.size()));
+                FF_HIP(hipMemcpy(pl->d_aptr16, aptr.data(), sizeof(uint32_t) * aptr.size(), hipMemcpyHostToDevice));
+                FF_HIP(hipMalloc(&pl->d_cs16, sizeof(uint32_t) * (size_t)(marks * ld)));
+                prefix16_kernel<<<dim3((unsigned)((ld + 63) / 64)), dim3(64)>>>(pl->d_QT, ld, rows, pl->d_cs16);
+                FF_HIP(hipGetLastError());
+                pl->sparse = true;
+                inf.kernel = FF_KERNEL_SAD_U32_SPARSE;
+                FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_sparse_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+            }
+        }
         FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
         if (env_int("FF_STAMPS", 0)) {
             FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
@@ -1298,7 +1510,11 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
                     pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     inf.row_begin, inf.row_end, inf.slot_begin);
-        } else if (inf.n_items > 0)
+        } else if (inf.n_items > 0 && pl->sparse)
+            pair_sad_sparse_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
+                pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
+                pl->zero_row, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin);
+        else if (inf.n_items > 0)
             pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
