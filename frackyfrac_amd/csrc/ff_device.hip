@@ -247,7 +247,7 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
 // R_j = sum of column j over the item's branch range, from prefix sums kept every 16 rows.
 // Same integers, same results.  At 10 % leaf density 2 % of the (i-block, row) cells are
 // inactive, at 5 % 10 %, at 1 % 51 %, at 0.2 % 82 %: the plan picks this kernel
-// when at least FF_SPARSE_MIN (default 35 %) are.  Rows past the end of the list are replaced by a
+// when at least FF_SPARSE_MIN (default 28 %) are.  Rows past the end of the list are replaced by a
 // zero slack row (|0 - 0| = 0), so the loop has no tail and no branches.
 template <int NC>
 __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
@@ -271,14 +271,32 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
 #pragma unroll
         for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
     }
-    auto row_at = [&](uint32_t idx) -> int64_t { return idx < a1 ? (int64_t)pr[idx] : (int64_t)zero_row; };
+    // Row numbers travel in batches of four, two batches ahead of their use, so that the
+    // operand loads never wait on a load of their own address (the list is padded with 8
+    // spare entries; positions past the item's segment read the zero slack row instead).
+    auto batch = [&](uint32_t pos) -> uint4 {
+        const_u32_ptr p4 = pr + pos;  // four adjacent scalar loads (one s_load_dwordx4)
+        uint4 b;
+        b.x = p4[0];
+        b.y = p4[1];
+        b.z = p4[2];
+        b.w = p4[3];
+        return b;
+    };
+    auto pick = [&](const uint4 &c, const uint4 &n, int o, uint32_t pos) -> int64_t {
+        // entry o (0..7) of the two batches {c, n}; position `pos` decides whether it is real
+        const uint32_t r = o == 0 ? c.x : o == 1 ? c.y : o == 2 ? c.z : o == 3 ? c.w
+                         : o == 4 ? n.x : o == 5 ? n.y : o == 6 ? n.z : n.w;
+        return pos < a1 ? (int64_t)r : (int64_t)zero_row;
+    };
+    uint4 cur = batch(a0), nxt = batch(a0 + 4);
     // vector ring of 4 active rows, scalars double-buffered one active row ahead
     RowVec<NC> v[4];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) v[q] = load_row<NC>(colj + row_at(a0 + q) * ld);
+    for (int q = 0; q < 3; ++q) v[q] = load_row<NC>(colj + pick(cur, nxt, q, a0 + q) * ld);
     uint32_t sA[TILE_I], sB[TILE_I];
     {
-        const_u32_ptr p0 = coli + row_at(a0) * ld;
+        const_u32_ptr p0 = coli + pick(cur, nxt, 0, a0) * ld;
 #pragma unroll
         for (int r = 0; r < TILE_I; ++r) sA[r] = p0[r];
     }
@@ -287,9 +305,9 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
         acc[0][0] = sad_u32(SCUR[0], v[Q].v[0], acc[0][0]);                    \
         __builtin_amdgcn_sched_barrier(0);                                     \
         {                                                                      \
-            const_u32_ptr pn = coli + row_at(t + (Q) + 1) * ld;                \
+            const_u32_ptr pn = coli + pick(cur, nxt, (Q) + 1, t + (Q) + 1) * ld; \
             _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = pn[r]; \
-            v[((Q) + 3) & 3] = load_row<NC>(colj + row_at(t + (Q) + 3) * ld);  \
+            v[((Q) + 3) & 3] = load_row<NC>(colj + pick(cur, nxt, (Q) + 3, t + (Q) + 3) * ld); \
         }                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                     \
         _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
@@ -300,10 +318,13 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
         _Pragma("unroll") for (int c = 0; c < NC; ++c) z[c] += v[Q].v[c];      \
     }
     for (uint32_t t = a0; t < a1; t += 4) {
+        const uint4 nn = batch(t + 8);
         FF_ASTEP(0, sA, sB)
         FF_ASTEP(1, sB, sA)
         FF_ASTEP(2, sA, sB)
         FF_ASTEP(3, sB, sA)
+        cur = nxt;
+        nxt = nn;
     }
 #undef FF_ASTEP
     // R_j over [k0, k1) from the 16-row prefix sums
@@ -1388,9 +1409,9 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
             const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
             const double inactive = 1.0 - (double)active / total;
             const char *thr = getenv("FF_SPARSE_MIN");
-            // the list walk runs at about 0.7 of the dense loop's rate per row (shallower
-            // prefetch, per-row address arithmetic), so it pays from about a third upwards
-            if (inactive >= (thr && *thr ? atof(thr) : 0.35)) {
+            // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
+            // prefetch, per-row address arithmetic), so it pays from about a quarter upwards
+            if (inactive >= (thr && *thr ? atof(thr) : 0.28)) {
                 // per i-block: the list of active rows and, every 16 rows, where the list stands
                 const int64_t marks = rows / (2 * KSTEP) + 1;
                 pl->aptr_stride = marks;
@@ -1403,7 +1424,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
                     }
                 if (arows.size() >= 0xFFFFFFF0ull)
                     return ff::fail(FF_ERR_INTERNAL, err, errlen, "active-row list too long");
-                arows.resize(arows.size() + 8, (uint32_t)rows);
+                arows.resize(arows.size() + 16, (uint32_t)rows);
                 pl->zero_row = (int32_t)rows;  // first slack row: zero in every column
                 FF_HIP(hipMalloc(&pl->d_arows, sizeof(uint32_t) * arows.size()));
                 FF_HIP(hipMemcpy(pl->d_arows, arows.data(), sizeof(uint32_t) * arows.size(), hipMemcpyHostToDevice));
