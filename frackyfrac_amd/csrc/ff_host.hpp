@@ -29,7 +29,7 @@ std::string go_f(double f);
 // "value out of range") on failure.
 bool go_parse_float(const char *b, const char *e, double *out, const char **why);
 
-// Reads a whole file (path) or stdin (path == nullptr).
+// Reads a whole file (path; gunzipped when it ends in ".gz") or stdin (path == nullptr).
 int read_all(const char *path, std::string *out, char *err, size_t errlen);
 
 unsigned clamp_threads(int requested);

@@ -4,6 +4,8 @@
 #include <functional>
 #include <thread>
 
+#include <zlib.h>
+
 #include "ff_host.hpp"
 
 namespace ff {
@@ -123,12 +125,33 @@ bool go_parse_float(const char *b, const char *e, double *out, const char **why)
     return true;
 }
 
+static bool has_suffix(const char *path, const char *suf)
+{
+    const size_t n = strlen(path), m = strlen(suf);
+    return n >= m && strcmp(path + n - m, suf) == 0;
+}
+
+// aio.Open (frcfrc.go:93): a path ending in ".gz" is decompressed on the fly (the
+// reference's gostuff/aio picks the codec by suffix); anything else, and stdin, is read as is.
 int read_all(const char *path, std::string *out, char *err, size_t errlen)
 {
-    FILE *f = path ? fopen(path, "rb") : stdin;
-    if (!f) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
     out->clear();
     char buf[1 << 16];
+    if (path && has_suffix(path, ".gz")) {
+        gzFile g = gzopen(path, "rb");
+        if (!g) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+        int n;
+        while ((n = gzread(g, buf, sizeof buf)) > 0) out->append(buf, (size_t)n);
+        int zerr = 0;
+        const char *msg = gzerror(g, &zerr);
+        const bool bad = n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END);
+        std::string why = bad ? std::string(msg ? msg : "gzip error") : std::string();
+        gzclose(g);
+        if (bad) return fail(FF_ERR_IO, err, errlen, "read %s: %s", path, why.c_str());
+        return FF_OK;
+    }
+    FILE *f = path ? fopen(path, "rb") : stdin;
+    if (!f) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
     size_t n;
     while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
     bool bad = ferror(f);
@@ -277,8 +300,13 @@ int ff_format_float(double f, char *buf)
 int ff_write_distances(const char *path, const double *d, int64_t n, int threads,
                        char *err, size_t errlen)
 {
-    FILE *f = path ? fopen(path, "wb") : stdout;
-    if (!f) return ff::fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+    // aio.Create (frcfrc.go:102): ".gz" output is compressed, by suffix
+    const bool gz = path && ff::has_suffix(path, ".gz");
+    gzFile g = nullptr;
+    FILE *f = nullptr;
+    if (gz) g = gzopen(path, "wb1");
+    else f = path ? fopen(path, "wb") : stdout;
+    if (!g && !f) return ff::fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
     unsigned nt = ff::clamp_threads(threads);
     const int64_t CHUNK = 1 << 20;  // values formatted per round (<= 26 B each)
     std::vector<std::string> bufs(nt);
@@ -296,14 +324,19 @@ int ff_write_distances(const char *path, const double *d, int64_t n, int threads
                 s.append(tmp, (size_t)k + 1);
             }
         });
-        for (unsigned t = 0; t < nt; ++t)
-            if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), f) != bufs[t].size()) {
-                rc = ff::fail(FF_ERR_IO, err, errlen, "write %s: %s", path ? path : "stdout",
-                              strerror(errno));
+        for (unsigned t = 0; t < nt; ++t) {
+            if (bufs[t].empty()) continue;
+            const bool ok = gz ? gzwrite(g, bufs[t].data(), (unsigned)bufs[t].size()) == (int)bufs[t].size()
+                               : fwrite(bufs[t].data(), 1, bufs[t].size(), f) == bufs[t].size();
+            if (!ok) {
+                rc = ff::fail(FF_ERR_IO, err, errlen, "write %s: %s", path ? path : "stdout", strerror(errno));
                 break;
             }
+        }
     }
-    if (path) {
+    if (gz) {
+        if (gzclose(g) != Z_OK && rc == FF_OK) rc = ff::fail(FF_ERR_IO, err, errlen, "close %s: gzip error", path);
+    } else if (path) {
         if (fclose(f) != 0 && rc == FF_OK)
             rc = ff::fail(FF_ERR_IO, err, errlen, "close %s: %s", path, strerror(errno));
     } else {

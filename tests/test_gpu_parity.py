@@ -91,6 +91,14 @@ def test_cli_run_sh(tmp_path):
             assert r.stderr.startswith("Reading tree\nLoading abundances\nValidating\nConverting abundances\n"
                                        "Calculating distances\nTook ")
             assert r.stderr.endswith("Done\n")
+    # gzip by suffix on both ends (gostuff/aio, frcfrc.go:93,102)
+    import gzip
+    with gzip.open(tmp_path / "wtd.sparse.gz", "wt") as f:
+        f.write(read_golden("wtd.sparse"))
+    r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", "-i", str(tmp_path / "wtd.sparse.gz"), "-t", GOLDEN + "/wtd.tree",
+                        "-o", str(tmp_path / "wtd.got.gz")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(tmp_path / "wtd.got.gz", "rt").read() == read_golden("wtd.want")
     # stdin -> stdout, -p threads
     r = subprocess.run([L.FRCFRC_PATH, "-w", "-p", "4", "-t", GOLDEN + "/wtd.tree"], input=read_golden("wtd.dense"),
                        capture_output=True, text=True)

@@ -237,6 +237,32 @@ def test_write_distances(tmp_path):
     assert np.array_equal(back, d, equal_nan=True)
 
 
+def test_gzip_io_by_suffix(tmp_path):
+    """gostuff/aio (frcfrc.go:93,102): a ".gz" suffix means gzip, on input and on output."""
+    import gzip
+    rng = np.random.default_rng(11)
+    d = rng.random(50000)
+    p = tmp_path / "out.txt.gz"
+    ff.write_distances(str(p), d, 3)
+    assert gzip.open(p, "rt").read() == O.format_output(d)
+    tree_gz = tmp_path / "t.tree.gz"
+    with gzip.open(tree_gz, "wt") as f:
+        f.write(read_golden("uwtd2.tree"))
+    t = ff.Tree.read_file(str(tree_gz))
+    assert t.names == ff.parse_newick(read_golden("uwtd2.tree")).names
+    tab_gz = tmp_path / "t.dense.gz"
+    with gzip.open(tab_gz, "wt") as f:
+        f.write(read_golden("uwtd2.dense"))
+    r = subprocess.run([ff.FRCFRC_PATH, "-t", str(tree_gz), "-i", str(tab_gz), "-l"], capture_output=True, text=True)
+    assert r.returncode == 2 and "-l can only be used" in r.stderr      # (argument check comes first)
+    # a corrupt .gz is an I/O error, not a crash
+    bad = tmp_path / "bad.tree.gz"
+    bad.write_bytes(b"\x1f\x8b\x08\x00garbage-not-deflate")
+    with pytest.raises(ff.FFError) as e:
+        ff.Tree.read_file(str(bad))
+    assert e.value.code == 5
+
+
 def test_iter_pairs_and_slots():
     assert list(ff.iter_pairs(4)) == list(O.iter_pairs(4)) == [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (3, 2)]
     n = 37
