@@ -6,9 +6,10 @@
 // (frcfrc.go:78-86), the same stderr phase lines and the same output: one
 // distance per line in IterPairs order, formatted like fmt.Fprintln (frcfrc.go:58-62).
 // Errors print "ERROR: <msg>" and exit 2 (common/common.go:13-18).
-// Extensions (not in the reference): -precision auto|fixed32|exact64, -stats.
+// Extensions (not in the reference): -precision auto|fixed32|exact64, -stats, -gpus N.
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "ff_host.hpp"
 
@@ -24,6 +25,7 @@ void usage()
 {
     fputs(USAGE, stderr);
     // flag.PrintDefaults(): flags in lexical order
+    fputs("  -gpus int\n    \tNumber of GPUs to shard the pair space over (default 1)\n", stderr);
     fputs("  -i string\n    \tPath to input file (default stdin)\n", stderr);
     fputs("  -l\tLeave abundance values unnormalized (default normalize each sample to sum up to 1)\n", stderr);
     fputs("  -o string\n    \tPath to output file (default stdout)\n", stderr);
@@ -44,7 +46,7 @@ int die(const char *msg)
 struct Flags {
     std::string in, out, tree, precision = "auto";
     bool weighted = false, sparse = false, nnorm = false, stats = false;
-    long nt = 1;
+    long nt = 1, gpus = 1;
 };
 
 bool parse_bool(const std::string &v, bool *out)
@@ -108,7 +110,7 @@ int parse_flags(int argc, char **argv, Flags *f)
         }
         std::string *sp = name == "i" ? &f->in : name == "o" ? &f->out : name == "t" ? &f->tree
                           : name == "precision" ? &f->precision : nullptr;
-        if (!sp && name != "p") {
+        if (!sp && name != "p" && name != "gpus") {
             fprintf(stderr, "flag provided but not defined: -%s\n", name.c_str());
             usage();
             return 2;
@@ -128,11 +130,11 @@ int parse_flags(int argc, char **argv, Flags *f)
             errno = 0;
             long v = strtol(value.c_str(), &end, 0);
             if (value.empty() || *end || errno) {
-                fprintf(stderr, "invalid value %s for flag -p: parse error\n", ff::go_quote(value).c_str());
+                fprintf(stderr, "invalid value %s for flag -%s: parse error\n", ff::go_quote(value).c_str(), name.c_str());
                 usage();
                 return 2;
             }
-            f->nt = v;
+            (name == "p" ? f->nt : f->gpus) = v;
         }
     }
     return -1;
@@ -172,6 +174,11 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         return die(m);
     }
     if (f.nnorm && !f.weighted) return die("-l can only be used with weighted unifrac");  // :84-86
+    if (f.gpus < 1 || f.gpus > 64) {
+        char m[64];
+        snprintf(m, sizeof m, "bad number of GPUs: %ld", f.gpus);
+        return die(m);
+    }
     ff_options opt;
     ff_options_default(&opt);
     opt.weighted = f.weighted;
@@ -222,8 +229,40 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     std::vector<double> out((size_t)ff_num_pairs(n));
     ff_plan_info info{};
     // stage A (abundanceToFlatNodes + normalizeFlatNodes) runs on the device, then stage B
-    rc = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0, &opt,
-                                 out.data(), &info, err, sizeof err);
+    if (f.gpus <= 1) {
+        rc = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0,
+                                     &opt, out.data(), &info, err, sizeof err);
+    } else {
+        // -gpus G: the pair space is cut into G equal-pair row shards (ff_shard_rows), one
+        // host thread per shard; shard g runs on device g modulo the devices present and
+        // writes its contiguous slice of `out`.  (Across processes the same shards are
+        // gathered over RCCL: frackyfrac_amd/distributed.py.)
+        const int ndev = ff::device_count();
+        if (ndev <= 0) return die("no HIP device available; this engine has no CPU path");
+        std::vector<int> rcs((size_t)f.gpus, 0);
+        std::vector<std::string> errs((size_t)f.gpus);
+        std::vector<ff_plan_info> infos((size_t)f.gpus);
+        std::vector<std::thread> th;
+        for (long g = 0; g < f.gpus; ++g)
+            th.emplace_back([&, g] {
+                ff_options o = opt;
+                o.device = (int32_t)(g % ndev);
+                o.rank = (int32_t)g;
+                o.world = (int32_t)f.gpus;
+                char e[1024] = {0};
+                rcs[(size_t)g] = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
+                                                         f.nnorm ? 1 : 0, &o, out.data(), &infos[(size_t)g], e, sizeof e);
+                errs[(size_t)g] = e;
+            });
+        for (auto &t : th) t.join();
+        rc = 0;
+        for (long g = 0; g < f.gpus && rc == 0; ++g)
+            if (rcs[(size_t)g]) {
+                rc = rcs[(size_t)g];
+                snprintf(err, sizeof err, "%s", errs[(size_t)g].c_str());
+            }
+        info = infos[0];
+    }
     ff_tree_free(tree);
     if (rc) return die(err);
     lap(4);

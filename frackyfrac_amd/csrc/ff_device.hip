@@ -1805,6 +1805,12 @@ int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recr
     return rc;
 }
 
+int ff::device_count()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 // ff_unifrac_dists that also reports what the staging decided (used by the CLI's -stats).
 int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info_out,
                            char *err, size_t errlen)

@@ -47,6 +47,8 @@ int unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *l
                         const ff_options *o, double *out, ff_plan_info *info, char *err, size_t errlen);
 int run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
                      ff_plan_info *info, char *err, size_t errlen);
+// Number of HIP devices visible (0 when there is none).
+int device_count();
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
                     std::vector<int64_t> *idx, std::vector<double> *val);

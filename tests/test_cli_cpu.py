@@ -28,6 +28,7 @@ def test_no_args_prints_usage_exit_0():
     (["-t", "x.tree", "-p=-3"], "bad number of threads: -3"),
     (["-t", "x.tree", "-l"], "-l can only be used with weighted unifrac"),
     (["--t=x.tree", "--l=true", "-w=false"], "-l can only be used with weighted unifrac"),
+    (["-t", "x.tree", "-gpus", "0"], "bad number of GPUs: 0"),
 ])
 def test_argument_errors(args, msg):
     r = run(*args)

@@ -99,6 +99,10 @@ def test_cli_run_sh(tmp_path):
                         "-o", str(tmp_path / "wtd.got.gz")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert gzip.open(tmp_path / "wtd.got.gz", "rt").read() == read_golden("wtd.want")
+    # -gpus 3: three row shards (all on the one device here) fill the same output
+    r = subprocess.run([L.FRCFRC_PATH, "-gpus", "3", "-i", GOLDEN + "/uwtd2.dense", "-t", GOLDEN + "/uwtd2.tree"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == read_golden("uwtd2.want")
     # stdin -> stdout, -p threads
     r = subprocess.run([L.FRCFRC_PATH, "-w", "-p", "4", "-t", GOLDEN + "/wtd.tree"], input=read_golden("wtd.dense"),
                        capture_output=True, text=True)
@@ -325,6 +329,20 @@ def test_unweighted_mfma_five_digits_and_long_lengths():
     assert plan.info.kernel == 2 and plan.info.n_digits == 5 and plan.info.lengths_exact == 1
     plan.close()
     assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
+
+
+def test_cli_gpus_flag_matches_single_shard(tmp_path):
+    tree, ptr, idx, val = synth.make(700, 3000, 0.1, 97)
+    (tmp_path / "t.tree").write_text(tree.newick())
+    (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr, idx, val))
+    outs = []
+    for g in ("1", "4"):
+        out = tmp_path / ("out%s.txt" % g)
+        r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", "-gpus", g, "-precision", "fixed32", "-i", str(tmp_path / "t.sparse"),
+                            "-t", str(tmp_path / "t.tree"), "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(out.read_text())
+    assert outs[0] == outs[1] and outs[0].count("\n") == 700 * 699 // 2
 
 
 def test_c5_shaped_sparse_input_through_the_cli(tmp_path):
