@@ -5,6 +5,7 @@ Bars: bit-exact for EXACT64 (any input) and for FIXED32 unweighted when the bran
 lengths are multiples of a power of two; FIXED32 weighted within 1e-6 relative
 (BASELINE.json north_star); golden .want files byte for byte."""
 import math
+import os
 import subprocess
 
 import numpy as np
@@ -19,6 +20,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 WEIGHTED_RTOL = 1e-6  # north_star: "within 1e-6 relative for weighted"
+HOST_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))  # oracle threads (the checker only)
 
 
 def rel_err(got, want):
@@ -491,9 +493,46 @@ def test_shards_tile_the_pair_space(precision, world, weighted):
 
 # ---------------------------------------------------------------- full size, properties
 
+def oracle_ranges_worst(d, ip, on, dist, weighted, n, n_ranges=8, per=125_000):
+    """Worst relative error of d against the oracle over n_ranges slot ranges of `per`
+    pairs each, evenly spread from the first to the last slot of the triangle."""
+    P = ff.num_pairs(n)
+    per = min(per, P // n_ranges)
+    worst = 0.0
+    for q in range(n_ranges):
+        a = (P - per) * q // (n_ranges - 1)
+        want = O.unifrac_dists(ip, on, dist, weighted, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + per)
+        worst = max(worst, rel_err(d[a:a + per], want))
+    return worst
+
+
+@pytest.mark.parametrize("name", ["C4", "C5"])
+def test_c4_c5_full_size_sampled_parity(name):
+    """BASELINE configs[3] and [4] at full size on ONE device (the driver shards them over
+    8): every pair in [0, 1], no NaN, 1 M sampled pairs within 1e-6 of the oracle, and the
+    shard that rank 5 of 8 would compute reproduces the same bits."""
+    cfg = synth.CONFIGS[name]
+    n = cfg["n_samples"]
+    tree, ptr, idx, val = synth.make(n, cfg["n_leaves"], cfg["density"], cfg["seed"])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    d = ff.unifrac_dists(nodes, True, precision="fixed32")
+    assert d.shape == (ff.num_pairs(n),)
+    assert not np.isnan(d).any() and d.min() >= 0.0 and d.max() <= 1.0
+    a, b = ff.shard_slots(n, 5, 8)
+    part = np.full(ff.num_pairs(n), np.nan)
+    ff.unifrac_dists(nodes, True, precision="fixed32", rank=5, world=8, out=part)
+    assert np.array_equal(part[a:b], d[a:b]) and np.isnan(part[:a]).all() and np.isnan(part[b:]).all()
+    del part
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
+
+
 def test_c3_full_size_properties_and_sampled_parity():
     """BASELINE configs[2] (headline): 4096 samples x 10k-leaf tree, weighted, FIXED32.
-    Size-independent checks over all 8.4 M pairs + oracle comparison on 4 slot ranges."""
+    Size-independent checks over all 8.4 M pairs + oracle comparison on 1 M sampled pairs
+    (>= 1e6 sampled pairs at C3-C5)."""
     import torch
 
     cfg = synth.CONFIGS["C3"]
@@ -537,15 +576,10 @@ def test_c3_full_size_properties_and_sampled_parity():
     d3 = np.array([d[slot(max(3, j), min(3, j))] for j in others])
     d7 = np.array([d[slot(max(7, j), min(7, j))] for j in others])
     assert np.array_equal(d3, d7)
-    # sampled parity against the oracle: four contiguous slot ranges across the triangle
+    # sampled parity against the oracle: 1 M pairs in 8 slot ranges spread over the triangle
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
-    P = ff.num_pairs(n)
-    worst = 0.0
-    for a in (0, P // 3, 2 * P // 3, P - 3000):
-        want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=8, pair_begin=a, pair_end=a + 3000)
-        worst = max(worst, rel_err(d[a:a + 3000], want))
-    assert worst <= WEIGHTED_RTOL, worst
+    assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
     # two shards of the same problem reproduce the single-device bits (checksum of checksums)
     parts = []
     for r in range(2):
@@ -566,6 +600,6 @@ def test_c3_unweighted_full_size_bit_exact_on_ranges():
     nodes, ip, on, ft = synth_problem(2048, cfg["n_leaves"], cfg["density"], cfg["seed"])
     got = ff.unifrac_dists(nodes, False, precision="fixed32")
     P = ff.num_pairs(2048)
-    for a in (0, P // 2, P - 2000):
-        want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=8, pair_begin=a, pair_end=a + 2000)
-        assert np.array_equal(got[a:a + 2000], want)
+    for a in (0, P // 4, P // 2, P - 250_000):
+        want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 250_000)
+        assert np.array_equal(got[a:a + 250_000], want)
