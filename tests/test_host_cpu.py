@@ -237,6 +237,29 @@ def test_write_distances(tmp_path):
     assert np.array_equal(back, d, equal_nan=True)
 
 
+def test_write_distances_many_rounds(tmp_path):
+    """More values than one round of the writer holds (2^18 per thread): parts land at
+    the right offsets of a regular file, and a ".gz" output is a sequence of gzip members
+    that reads back as one stream."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(10)
+    d = rng.random(3 * (1 << 18) * 2 + 12345)
+    d[::1000] = 10.0 ** rng.uniform(-9, -3, len(d[::1000]))  # some %e-formatted values
+    want = O.format_output(d)
+    ff.write_distances(str(tmp_path / "a.txt"), d, 3)
+    assert (tmp_path / "a.txt").read_text() == want
+    ff.write_distances(str(tmp_path / "a.txt.gz"), d, 3)
+    raw = (tmp_path / "a.txt.gz").read_bytes()
+    assert gzip.decompress(raw).decode() == want
+    z = zlib.decompressobj(31)
+    z.decompress(raw)
+    assert len(z.unused_data) > 0                       # more than one member
+    # overwriting a longer file truncates it
+    ff.write_distances(str(tmp_path / "a.txt"), d[:10], 3)
+    assert (tmp_path / "a.txt").read_text() == O.format_output(d[:10])
+
+
 def test_gzip_io_by_suffix(tmp_path):
     """gostuff/aio (frcfrc.go:93,102): a ".gz" suffix means gzip, on input and on output."""
     import gzip
