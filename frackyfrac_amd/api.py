@@ -53,6 +53,18 @@ def shard_slots(n: int, rank: int, world: int) -> Tuple[int, int]:
     return rb * (rb - 1) // 2 if rb else 0, re * (re - 1) // 2 if re else 0
 
 
+def _release(obj, free_name: str) -> None:
+    """Frees obj._h once.  At interpreter shutdown the module globals may already be gone;
+    the process is ending, so the handle is simply dropped then."""
+    h = getattr(obj, "_h", None)
+    if not h:
+        return
+    obj._h = None
+    lib = getattr(L, "lib", None) if L is not None else None
+    if lib is not None:
+        getattr(lib(), free_name)(h)
+
+
 class Tree:
     """newick.Node tree flattened in enumerateNodes' pre-order numbering."""
 
@@ -73,9 +85,7 @@ class Tree:
         return cls(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            L.lib().ff_tree_free(self._h)
-            self._h = None
+        _release(self, "ff_tree_free")
 
     @property
     def n(self) -> int:
@@ -121,9 +131,7 @@ class Table:
         return cls(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            L.lib().ff_table_free(self._h)
-            self._h = None
+        _release(self, "ff_table_free")
 
     def __len__(self) -> int:
         return int(L.lib().ff_table_num_samples(self._h))
@@ -297,9 +305,7 @@ class Plan:
         return cls(None, weighted, _handle=h)
 
     def close(self):
-        if getattr(self, "_h", None):
-            L.lib().ff_plan_destroy(self._h)
-            self._h = None
+        _release(self, "ff_plan_destroy")
 
     __del__ = close
 

@@ -5,6 +5,7 @@
 
 namespace ff {
 int device_count() { return 0; }
+void device_warmup(int) {}
 int unifrac_dists_info(const ff_problem *, const ff_options *, double *, ff_plan_info *, char *err, size_t errlen)
 {
     return fail(FF_ERR_DEVICE, err, errlen, "device stub");

@@ -196,6 +196,12 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         phase[k] = std::chrono::duration<double>(now - last).count();
         last = now;
     };
+    // the HIP context takes ~0.15 s to come up: do that while the inputs are read
+    std::thread warm([&f] { ff::device_warmup((int)f.gpus); });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{warm};
     fputs("Reading tree\n", stderr);
     ff_tree *tree = nullptr;
     if (ff_tree_read_file(f.tree.c_str(), &tree, err, sizeof err)) return die(err);
@@ -225,6 +231,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     ff_table_free(table);
     lap(3);
 
+    warm.join();
     fputs("Calculating distances\n", stderr);  // unifrac.go:122
     std::vector<double> out((size_t)ff_num_pairs(n));
     ff_plan_info info{};

@@ -1811,6 +1811,16 @@ int ff::device_count()
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+void ff::device_warmup(int want)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return;
+    n = std::min(n, std::max(want, 1));
+    for (int d = 0; d < n; ++d)
+        if (hipSetDevice(d) == hipSuccess) (void)hipFree(nullptr);
+    if (n > 0) (void)hipSetDevice(0);
+}
+
 // ff_unifrac_dists that also reports what the staging decided (used by the CLI's -stats).
 int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info_out,
                            char *err, size_t errlen)

@@ -49,6 +49,8 @@ int run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate
                      ff_plan_info *info, char *err, size_t errlen);
 // Number of HIP devices visible (0 when there is none).
 int device_count();
+// Brings the HIP context of the first `want` devices up (errors are left for the first real call).
+void device_warmup(int want);
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
                     std::vector<int64_t> *idx, std::vector<double> *val);
