@@ -24,6 +24,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# this pool's driver only supports dmabuf IPC (cross-process device memory: RCCL, the "ipc" gather)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
@@ -135,6 +137,8 @@ def main():
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     info = run.plan.info
+    if rank == 0 and world > 1:
+        log("gather transport: %s%s" % (run.transport, (" (ipc unavailable: %s)" % run.transport_note) if run.transport_note else ""))
     if rank == 0:
         log("workload %s: N=%d leaves=%d B=%d nnz=%d pairs=%d | prep %.2fs stage(H2D+quantise) %.3fs | "
             "precision=%s scale=2^%d tiles=%d items=%d wave_slots=%d" %
@@ -143,6 +147,9 @@ def main():
              info.n_wave_slots))
 
     def barrier():
+        # every rank first drains its own streams (with the "ipc" transport a peer's slice
+        # reaches the root from the PEER's copy stream), then all meet
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -224,15 +231,17 @@ def main():
                                       (name, n_samples, cfg["n_leaves"], B, "weighted" if weighted else "unweighted",
                                        cfg["density"], cfg["seed"]),
                           "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
-                          "parallelism": "pair-tile row shards x%d, gather to rank 0" % world},
+                          "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (world, run.transport)},
                "roofline": roofline}
         if e2e is not None:
             out["host_buffers_ms"] = e2e * 1e3  # PCIe-inclusive, informational
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
         # cheap sanity on the result of the last step (not a parity test: tests/ does that)
-        d = res[: min(P, 1 << 20)].cpu().numpy()
-        assert np.all((d >= 0) & (d <= 1.0000001)), "distance outside [0, 1]"
+        # (every slot, so a slice that never arrived from its rank cannot go unnoticed)
+        lo, hi = float(res.min().item()), float(res.max().item())
+        assert not bool(torch.isnan(res).any().item()), "NaN in the gathered result"
+        assert 0.0 <= lo and hi <= 1.0000001, "distance outside [0, 1]"
         print(json.dumps(out), flush=True)
     run.close()
     if world > 1:

@@ -1382,7 +1382,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         inf.n_wave_slots = U;
         std::vector<Item> items;
         std::vector<int32_t> item_ptr;
-        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements);
+        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices());
         inf.n_items = (int64_t)items.size();
         FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
         FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));

@@ -2,6 +2,7 @@
 #include "ff_schedule.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "frackyfrac_amd.h"
@@ -25,6 +26,15 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
     }
 }
 
+// FF_XCD_SLICES: number of XCDs the main rounds pin branch slices to (0 = the classic
+// rounds).  An MI355X has 8.
+int xcd_slices()
+{
+    const char *e = getenv("FF_XCD_SLICES");
+    const int v = e && *e ? atoi(e) : 0;
+    return v < 0 ? 0 : v;
+}
+
 // Balances tiles over U persistent waves.
 //
 //  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
@@ -39,7 +49,7 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
 // Ranges that share a tile add their partial sums atomically; the sums are integers, so
 // the result does not depend on the order.
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
-                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements)
+                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds)
 {
     std::vector<Tile> wide, rest;
     for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
@@ -57,7 +67,29 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     };
     if (rows > 0) {
         int64_t done = 0;  // full-width tiles scheduled in main rounds
-        if (T > 0) {
+        const int64_t n_wg = U / WAVES_PER_WG;
+        if (xcds > 1 && T > 0 && n_wg % xcds == 0 && rows >= (int64_t)xcds * 8 * KSTEP) {
+            // Branch slices pinned to XCDs.  Workgroup g runs on XCD g mod xcds (round-robin
+            // dispatch); every tile is cut into `xcds` equal branch ranges and range x always goes
+            // to a workgroup of XCD x, so each XCD's L2 only ever sees 1/xcds of the staged rows
+            // and all its waves sweep that slice together.  A round = 8 consecutive tiles per
+            // workgroup of ONE XCD's share, i.e. n_wg/xcds * 8 tiles.
+            const int64_t per_round = n_wg / xcds * WAVES_PER_WG;
+            const int64_t part = round_up((rows + xcds - 1) / xcds, 2 * KSTEP);
+            const int64_t rounds = T / per_round;
+            for (int64_t r = 0; r < rounds; ++r)
+                for (int64_t q = 0; q < per_round; ++q) {
+                    const Tile &t = wide[(size_t)(r * per_round + q)];
+                    const int64_t m = q / WAVES_PER_WG, w = q % WAVES_PER_WG;
+                    for (int64_t x = 0; x < xcds; ++x) {
+                        const int u = (int)((m * xcds + x) * WAVES_PER_WG + w);
+                        const size_t before = per[(size_t)u].size();
+                        push(u, t, std::min(rows, x * part), std::min(rows, (x + 1) * part));
+                        if (per[(size_t)u].size() > before) per[(size_t)u].back().flags |= 2u;
+                    }
+                }
+            done = rounds * per_round;
+        } else if (T > 0) {
             // Choose the split S by estimated makespan (unit: one full tile on one wave):
             // rounds of `pr` tiles take 1/S each; what is left over is cut stream-K style and
             // runs about 15 % slower per term (its waves are not on common rows).  pr is a
@@ -236,7 +268,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
         std::vector<Item> items;
         double elements = 0;
-        build_schedule(tiles, rows, n_cu * WAVES_PER_WG, &items, &ptr, &elements);
+        build_schedule(tiles, rows, n_cu * WAVES_PER_WG, &items, &ptr, &elements, xcd_slices());
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);

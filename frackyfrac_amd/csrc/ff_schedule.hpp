@@ -62,9 +62,10 @@ struct Tile {
     int32_t narrow;  // 1: 32 x 128 (the tile overhangs the diagonal by more than half)
 };
 
+int xcd_slices();
 void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles);
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std::vector<Item> *items,
-                    std::vector<int32_t> *item_ptr, double *elements);
+                    std::vector<int32_t> *item_ptr, double *elements, int xcds = 0);
 // Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr);

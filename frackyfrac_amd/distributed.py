@@ -6,6 +6,16 @@ send/recv, the slices differ in length), which already holds its own slice in
 place.  There is no other collective on the data path: pairs are independent
 (frcfrc/unifrac.go:209-228 maps over pairs with no reduction across them).
 
+Two transports for that exchange (ShardedRun, FF_GATHER=auto|ipc|nccl):
+  * "ipc": the root's result array is mapped into every rank (HIP IPC memory handle,
+    exchanged once) and each rank copies its finished slice straight into it over its
+    xGMI link with a device-to-device hipMemcpyAsync on a side stream -- the copy
+    engines move the slice while the rank's CUs already reduce the next batch (two
+    local result buffers).  No RCCL kernel competes with the persistent pair kernel
+    for CUs.  Checked once at set-up with a known pattern; any failure on any rank
+    makes every rank fall back to
+  * "nccl": batched send/recv (gather_slices below).
+
 torch is plumbing here (device buffers, streams, the process group); the
 reduction itself is ff_plan_run in the C ABI.
 """
@@ -60,7 +70,7 @@ class ShardedRun:
 
     def __init__(self, nodes: api.FlatNodes, weighted: bool, rank: int, world: int,
                  precision="auto", device: Optional[int] = None, root: int = 0, group=None,
-                 chunks: Optional[int] = None):
+                 chunks: Optional[int] = None, transport: Optional[str] = None):
         import os
 
         import torch
@@ -84,6 +94,123 @@ class ShardedRun:
         self.local = self.locals[0]
         self.full = (torch.empty(api.num_pairs(self.n_samples), dtype=torch.float64, device=self.device)
                      if (rank == root and world > 1) else None)
+        if transport is None:
+            transport = os.environ.get("FF_GATHER", "auto")
+        if transport not in ("auto", "ipc", "nccl"):
+            raise ValueError("transport must be auto, ipc or nccl")
+        self.transport = "none" if world == 1 else "nccl"
+        self.transport_note = ""
+        self._k = 0
+        if world > 1 and self.chunks == 1 and transport in ("auto", "ipc"):
+            if self._setup_ipc():
+                self.transport = "ipc"
+            elif transport == "ipc":
+                raise RuntimeError("frackyfrac_amd: FF_GATHER=ipc but the IPC mapping failed: " + self.transport_note)
+
+    # ---- "ipc" transport -------------------------------------------------------------
+    def _flag_all(self, ok: bool) -> bool:
+        """True iff ok on every rank (one all_reduce; every rank always takes part)."""
+        import torch.distributed as dist
+
+        torch = self.torch
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()) == 1)
+
+    def _setup_ipc(self) -> bool:
+        """Maps the root's `full` into this process and proves the mapping with a pattern
+        written through it.  The sequence of collectives is the same on every rank whatever
+        fails locally, and the verdict is taken jointly."""
+        import os
+
+        import torch.distributed as dist
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        torch = self.torch
+        ok, note = True, ""
+        box = [None]
+        if self.rank == self.root:
+            try:
+                self.full.fill_(float("nan"))
+                torch.cuda.synchronize(self.device)
+                box[0] = reduce_tensor(self.full)[1]
+            except Exception as e:  # noqa: BLE001 -- any failure means "use the other transport"
+                ok, note = False, "export: %r" % (e,)
+        dist.broadcast_object_list(box, src=self.root, group=self.group)
+        self.remote = None
+        a, b = api.shard_slots(self.n_samples, self.rank, self.world)
+        if self.rank != self.root:
+            try:
+                if box[0] is None:
+                    raise RuntimeError("root could not export its buffer")
+                if os.environ.get("FF_GATHER_FAULT") == str(self.rank):  # fault injection for the tests
+                    raise RuntimeError("injected fault")
+                from torch.multiprocessing.reductions import rebuild_cuda_tensor
+                self.remote = rebuild_cuda_tensor(*box[0])
+                if b > a:
+                    mark = torch.full((min(16, b - a),), float(self.rank + 1), dtype=torch.float64, device=self.device)
+                    self.remote[a:a + mark.numel()].copy_(mark)
+                    self.remote[b - mark.numel():b].copy_(mark)
+                torch.cuda.synchronize(self.device)
+            except Exception as e:  # noqa: BLE001
+                ok, note = False, "open/write: %r" % (e,)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        if self.rank == self.root and ok:
+            torch.cuda.synchronize(self.device)
+            for r in range(self.world):
+                if r == self.root:
+                    continue
+                ra, rb = api.shard_slots(self.n_samples, r, self.world)
+                if rb > ra:
+                    k = min(16, rb - ra)
+                    got = torch.cat([self.full[ra:ra + k], self.full[rb - k:rb]]).cpu()
+                    if not bool((got == float(r + 1)).all()):
+                        ok, note = False, "pattern of rank %d did not arrive" % r
+        all_ok = self._flag_all(ok)
+        if not all_ok:
+            self.remote = None
+            self.transport_note = note or "another rank failed"
+            return False
+        self.side = torch.cuda.Stream(device=self.device)
+        self.locals = [self.local, torch.empty_like(self.local)] if self.rank != self.root else [self.local]
+        self.copy_done = [None, None]
+        return True
+
+    def _step_ipc(self, timed: bool):
+        torch = self.torch
+        main = torch.cuda.current_stream(self.device)
+        a, b = api.shard_slots(self.n_samples, self.rank, self.world)
+        if self.rank == self.root:
+            if b > a:  # the root's slice is produced in place
+                self.plan.run(self.full.data_ptr() + 8 * a, main.cuda_stream, timed=timed)
+            return self.full
+        if b <= a:
+            return None
+        q = self._k & 1
+        self._k += 1
+        if self.copy_done[q] is not None:
+            main.wait_event(self.copy_done[q])  # the copy that last read this buffer
+        self.plan.run(self.locals[q].data_ptr(), main.cuda_stream, timed=timed)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.remote[a:b].copy_(self.locals[q], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.copy_done[q] = done
+        return None
+
+    def wait(self):
+        """Every step issued so far is complete on the root: each rank drains its own
+        streams (compute, copies, RCCL), then all meet."""
+        import torch.distributed as dist
+
+        self.torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)
 
     @property
     def n_slots(self) -> int:
@@ -91,8 +218,13 @@ class ShardedRun:
 
     def step(self, timed: bool = False):
         """Reduce this rank's pair tiles, then gather to the root.  Returns the full
-        result tensor on the root (the local one when world == 1), None elsewhere."""
+        result tensor on the root (the local one when world == 1), None elsewhere.
+        Asynchronous like any stream work; wait() makes the root's tensor complete (with the
+        "ipc" transport the peers' slices land from THEIR streams, so a synchronize on the
+        root alone is not enough)."""
         torch = self.torch
+        if self.transport == "ipc":
+            return self._step_ipc(timed)
         stream = torch.cuda.current_stream(self.device)
         if self.chunks == 1:
             self.plan.run(self.local.data_ptr(), stream.cuda_stream, timed=timed)
@@ -133,6 +265,9 @@ class ShardedRun:
         return ms, n // max(1, len(self.plans))
 
     def close(self):
+        if getattr(self, "remote", None) is not None:
+            self.torch.cuda.synchronize(self.device)
+            self.remote = None
         for p in self.plans:
             p.close()
 
@@ -152,7 +287,7 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
     if compute is None:
         run = ShardedRun(nodes, weighted, rank, world, precision=precision, root=root, group=group)
         res = run.step()
-        torch.cuda.synchronize()
+        run.wait()
         out = res.cpu().numpy() if res is not None else None
         run.close()
         return out
