@@ -76,6 +76,32 @@ def test_sad_schedule_covers_pairs_and_rows_once(n, rows, n_cu, world, narrow):
             assert per.max() <= cost.sum() / len(per) * 1.6 + 2 * 64
 
 
+def test_xcd_sliced_rounds_pin_branch_slices_to_xcds(monkeypatch):
+    """FF_XCD_SLICES=8: in the main rounds workgroup g (XCD g mod 8) only ever sweeps branch
+    slice g mod 8, and the coverage properties above still hold."""
+    monkeypatch.setenv("FF_XCD_SLICES", "8")
+    n, rows, n_cu = 4096, 20000, 256
+    items, ptr, n_tiles = schedule(0, n, rows, 0, n, n_cu)
+    part = ((rows + 7) // 8 + 15) // 16 * 16
+    flagged = 0
+    for wg in range(n_cu):
+        for w in range(8):
+            for i0, j0, k0, k1, flags, *_ in items[ptr[8 * wg + w]:ptr[8 * wg + w + 1]]:
+                if flags & 2:                              # a main-round item
+                    flagged += 1
+                    x = wg % 8
+                    assert k0 == x * part and k1 == min(rows, (x + 1) * part)
+    assert flagged == 4 * 256 * 8                          # 4 rounds of 256 tiles in 8 slices
+    cover = {}
+    for i0, j0, k0, k1, flags, *_ in items:
+        cover.setdefault((i0, j0), []).append((k0, k1))
+    assert len(cover) == n_tiles
+    for ranges in cover.values():
+        ranges.sort()
+        assert ranges[0][0] == 0 and ranges[-1][1] == rows and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    test_sad_schedule_covers_pairs_and_rows_once(1000, 20000, 256, 3, 1)
+
+
 @pytest.mark.parametrize("n,slabs,n_cu,digits", [(5, 3, 8, 1), (300, 60, 8, 2), (1000, 313, 256, 3), (4096, 313, 256, 2),
                                                   (777, 40, 256, 5)])
 @pytest.mark.parametrize("world", [1, 2])
