@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--end-to-end", action="store_true", help="also time ff_unifrac_dists through host buffers")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 with gloo as control plane (RCCL refuses two ranks on "
+                         "one device): exercises the sharded code path on a one-GPU box; not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -108,11 +111,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     # ---- workload -----------------------------------------------------------
     if args.workload in synth.CONFIGS:
@@ -165,7 +173,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms_total, launches = run.timing_collect()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -225,7 +233,8 @@ def main():
                          if name == "C3" and weighted else "sample-pairs/sec (lower triangle)",
                "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u32" if info.precision == 1 else "f64", "data": "synthetic",
+               "dtype": "u32" if info.precision == 1 else "f64",
+               "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if args.rehearse_on_one_gpu else ""),
                "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
                                       "leaf density %.2f, seed 0x%X" %
                                       (name, n_samples, cfg["n_leaves"], B, "weighted" if weighted else "unweighted",
