@@ -684,26 +684,28 @@ __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
                                       unsigned long long *__restrict__ refine_count,
                                       unsigned long long refine_cap)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_slots) return;
-    int64_t i, j;
-    slot_to_pair(slot_begin + t, &i, &j);
-    const unsigned long long u = num[t];
-    const unsigned long long w = W[i] + W[j];
-    double d;
-    if (weighted) {
-        d = (double)u / (double)w;                 // numer / denom
-    } else {
-        const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
-        d = (double)u / (double)(u + common);      // result / (result + common)
-    }
-    out[t] = d;
-    if (indptr && w != 0) {
-        const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
-        const double err = REFINE_SIGMAS * sqrt(k * (1.0 / 12.0)) + 1.0;
-        if ((double)u * REFINE_REL < err) {
-            const unsigned long long at = atomicAdd(refine_count, 1ull);
-            if (at < refine_cap) refine_list[at] = (unsigned long long)t;
+    // grid-stride: a launch carries at most 2^32 - 1 threads, a shard can have more slots
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i, j;
+        slot_to_pair(slot_begin + t, &i, &j);
+        const unsigned long long u = num[t];
+        const unsigned long long w = W[i] + W[j];
+        double d;
+        if (weighted) {
+            d = (double)u / (double)w;                 // numer / denom
+        } else {
+            const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
+            d = (double)u / (double)(u + common);      // result / (result + common)
+        }
+        out[t] = d;
+        if (indptr && w != 0) {
+            const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
+            const double err = REFINE_SIGMAS * sqrt(k * (1.0 / 12.0)) + 1.0;
+            if ((double)u * REFINE_REL < err) {
+                const unsigned long long at = atomicAdd(refine_count, 1ull);
+                if (at < refine_cap) refine_list[at] = (unsigned long long)t;
+            }
         }
     }
 }
@@ -1464,6 +1466,10 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)B;
         std::vector<XTile> xt(tiles.size());
         for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
+        // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
+        if (xt.size() >= ((size_t)1 << 26))
+            return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
+                            xt.size(), ((size_t)1 << 26) - 1);
         pl->n_xtiles = (int)xt.size();
         FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
         if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
@@ -1540,7 +1546,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
-        const unsigned nb = (unsigned)((n_slots + 255) / 256);
+        const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
         if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long), st));
         finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(
             pl->d_num, pl->d_W, pl->weighted, inf.slot_begin, n_slots, d_out, pl->refine ? pl->d_indptr : nullptr,

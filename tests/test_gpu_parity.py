@@ -529,6 +529,31 @@ def test_c4_c5_full_size_sampled_parity(name):
     assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_more_than_2_to_the_32_pairs(weighted):
+    """Maximum sizes: 93,000 samples = 4.3e9 pairs (35 GB of results) on a 16-leaf tree.
+    Slot arithmetic is 64-bit end to end and no launch may count on more than 2^32 - 1
+    threads (the finish kernel once did: every slot past 2^32 threads' worth stayed
+    unwritten).  Ranges straddle 2^31 and 2^32."""
+    n = 93_000
+    tree, ptr, idx, val = synth.make(n, 16, 0.5, 4242)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    P = ff.num_pairs(n)
+    assert P > 2 ** 32
+    d = np.full(P, -7.0)
+    ff.unifrac_dists(nodes, weighted, precision="fixed32", out=d)
+    assert d.min() >= 0.0 and d.max() <= 1.0                  # every slot written, none NaN
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    for a in (0, 2 ** 31 - 50_000, 2 ** 32 - 50_000, P - 100_000):
+        want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 100_000)
+        if weighted:
+            assert rel_err(d[a:a + 100_000], want) <= WEIGHTED_RTOL
+        else:
+            assert np.array_equal(d[a:a + 100_000], want)
+
+
 def test_c3_full_size_properties_and_sampled_parity():
     """BASELINE configs[2] (headline): 4096 samples x 10k-leaf tree, weighted, FIXED32.
     Size-independent checks over all 8.4 M pairs + oracle comparison on 1 M sampled pairs
