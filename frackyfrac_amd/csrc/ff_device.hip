@@ -864,11 +864,41 @@ namespace {
 #define FF_HIP(call)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* do not leave it for a later call's launch check */    \
             return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: %s failed: %s", #call,           \
                             hipGetErrorString(e_));                                           \
+        }                                                                                     \
     } while (0)
 
+
+// The large buffers of a plan: say what did not fit and what to do about it.
+#define FF_ALLOC(ptr, bytes, what)                                                                 \
+    do {                                                                                           \
+        hipError_t e_ = hipMalloc(&(ptr), (bytes));                                                \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return ff::fail(FF_ERR_DEVICE, err, errlen,                                            \
+                            "HIP: %s: cannot allocate %.2f GB for %s (shard %d of %d; more shards " \
+                            "make it smaller)", hipGetErrorString(e_), (double)(bytes) / 1e9, what, \
+                            (int)o->rank, (int)o->world);                                          \
+        }                                                                                          \
+    } while (0)
+
+// Device scratch that lives for one function: freed on every return path.
+template <typename T> struct Scratch {
+    T *p = nullptr;
+    Scratch() = default;
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)); }
+};
 
 int env_int(const char *name, int dflt)
 {
@@ -1061,6 +1091,7 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
         FF_HIP(hipSetDevice(o->device));
     }
     FF_HIP(hipGetDevice(&pl->device));
+    (void)hipGetLastError();  // a stale error of the caller's (or of a failed plan) is not ours
     FF_HIP(hipGetDeviceProperties(prop, pl->device));
     if (strncmp(prop->gcnArchName, "gfx950", 6) != 0 && !getenv("FF_ALLOW_ANY_ARCH"))
         return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d is %s; this engine is built for gfx950 only",
@@ -1162,6 +1193,7 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError();                                                            \
             cleanup();                                                                          \
             return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: %s failed: %s", #call,             \
                             hipGetErrorString(e_));                                             \
@@ -1294,21 +1326,21 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         inf.rows_padded = ldb;
         const size_t plane_bytes = (size_t)n8 * (size_t)ldb;
         inf.staged_bytes = (double)plane_bytes * (1 + digits);
-        FF_HIP(hipMalloc(&pl->d_P8, plane_bytes));
-        FF_HIP(hipMalloc(&pl->d_K8, plane_bytes * (size_t)digits));
+        FF_ALLOC(pl->d_P8, plane_bytes, "the presence plane");
+        FF_ALLOC(pl->d_K8, plane_bytes * (size_t)digits, "the branch-length digit planes");
         FF_HIP(hipMemset(pl->d_P8, 0, plane_bytes));
         FF_HIP(hipMemset(pl->d_K8, 0, plane_bytes * (size_t)digits));
         FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
         FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
-        uint32_t *d_klen = nullptr;
-        FF_HIP(hipMalloc(&d_klen, sizeof(uint32_t) * (size_t)B));
-        FF_HIP(hipMemcpy(d_klen, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+        Scratch<uint32_t> klen;
+        FF_HIP(klen.alloc((size_t)B));
+        FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
         if (nnz > 0)
-            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_klen, digits, pl->d_P8, pl->d_K8,
+            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, pl->d_P8, pl->d_K8,
                                                                  ldb, pl->m_plane, pl->d_W);
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());
-        (void)hipFree(d_klen);
+        klen.release();
         const int64_t slabs = ldb / M_KSLAB;
         const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
         pl->n_mgroups = G;
@@ -1327,7 +1359,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
         FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-        FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
+        FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
     } else if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
         const int64_t rows = round_up(B, 2 * KSTEP);
@@ -1336,12 +1368,12 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         inf.lengths_exact = weighted ? 0 : q.lengths_exact;
         const size_t qt_bytes = sizeof(uint32_t) * (size_t)(rows + SLACK_ROWS) * (size_t)ld;
         inf.staged_bytes = (double)qt_bytes;
-        FF_HIP(hipMalloc(&pl->d_QT, qt_bytes));
+        FF_ALLOC(pl->d_QT, qt_bytes, "the staged branch x sample matrix");
         FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
-        uint32_t *d_klen = nullptr;
+        Scratch<uint32_t> klen;
         if (!weighted) {
-            FF_HIP(hipMalloc(&d_klen, sizeof(uint32_t) * (size_t)std::max<int64_t>(B, 1)));
-            if (B > 0) FF_HIP(hipMemcpy(d_klen, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+            FF_HIP(klen.alloc((size_t)B));
+            if (B > 0) FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
         }
         std::vector<unsigned long long> hW((size_t)ld);
         int e = q.e;
@@ -1349,7 +1381,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
             FF_HIP(hipMemset(pl->d_QT, 0, qt_bytes));
             FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
             if (N > 0 && nnz > 0)
-                stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, d_klen,
+                stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, klen.p,
                                                                         weighted ? 1 : 0, e, pl->d_QT, ld);
             if (rows > 0) {
                 const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
@@ -1361,13 +1393,11 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
             unsigned long long wmax = 0;
             for (auto w : hW) wmax = std::max(wmax, w);
             if (wmax <= 2147483647ull) break;
-            if (!weighted || attempt >= 3) {
-                (void)hipFree(d_klen);
+            if (!weighted || attempt >= 3)
                 return ff::fail(FF_ERR_INTERNAL, err, errlen, "FIXED32 staging overflow (max column sum %llu)", wmax);
-            }
             --e;  // rounding pushed a column over the bound: drop one bit
         }
-        (void)hipFree(d_klen);
+        klen.release();
         inf.scale_log2 = e;
         // schedule
         std::vector<Tile> tiles;
@@ -1395,14 +1425,14 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         // sparse-aware kernel
         if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
             const int64_t n_iblocks = ld / TILE_I, words = (rows + SLACK_ROWS + 63) / 64;
-            unsigned long long *d_act64 = nullptr;
-            FF_HIP(hipMalloc(&d_act64, sizeof(unsigned long long) * (size_t)(n_iblocks * words)));
+            Scratch<unsigned long long> act64;
+            FF_HIP(act64.alloc((size_t)(n_iblocks * words)));
             build_activity_kernel<<<dim3((unsigned)words, (unsigned)n_iblocks), dim3(64)>>>(pl->d_QT, ld, rows, words,
-                                                                                            d_act64);
+                                                                                            act64.p);
             FF_HIP(hipGetLastError());
             std::vector<unsigned long long> a64((size_t)(n_iblocks * words));
-            FF_HIP(hipMemcpy(a64.data(), d_act64, sizeof(unsigned long long) * a64.size(), hipMemcpyDeviceToHost));
-            (void)hipFree(d_act64);
+            FF_HIP(hipMemcpy(a64.data(), act64.p, sizeof(unsigned long long) * a64.size(), hipMemcpyDeviceToHost));
+            act64.release();
             // only the i-blocks this shard's tiles use count for the decision
             const int64_t ib0 = inf.row_begin / TILE_I, ib1 = (inf.row_end + TILE_I - 1) / TILE_I;
             int64_t active = 0;
@@ -1441,7 +1471,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
             }
         }
-        FF_HIP(hipMalloc(&pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
+        FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
         if (env_int("FF_STAMPS", 0)) {
             FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
             FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
@@ -1454,7 +1484,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         inf.rows_padded = B;
         const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(B, 1) * (size_t)ld;
         inf.staged_bytes = (double)dt_bytes;
-        FF_HIP(hipMalloc(&pl->d_DT, dt_bytes));
+        FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
         FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
         if (N > 0 && nnz > 0)
             stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,

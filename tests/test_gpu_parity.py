@@ -529,6 +529,30 @@ def test_c4_c5_full_size_sampled_parity(name):
     assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
 
 
+def test_out_of_device_memory_is_an_error_not_a_crash():
+    """600,000 samples = 1.8e11 pairs: the accumulators alone would take 720 GB.  The plan
+    must fail with a message, free what it had staged, and leave the device usable."""
+    import torch
+
+    n = 600_000
+    tree, ptr, idx, val = synth.make(n, 16, 0.5, 5)
+    T = ff.parse_newick(tree.newick())
+    nodes, ip, on, ft = synth_problem(50, 40, 0.3, 3)
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    ff.unifrac_dists(nodes, True, precision="exact64")     # (code objects, pools: before the baseline)
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(2):
+        with pytest.raises(L.FFError, match="out of memory"):
+            ff.Plan.from_leaves(T, ptr, idx, val, True, precision="fixed32")
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free0 - free1 < (64 << 20)                   # nothing substantial left behind
+        # and the failure does not stick: the next plan on the same device works
+        for prec in ("exact64", "fixed32"):
+            got = ff.unifrac_dists(nodes, True, precision=prec)
+            assert rel_err(got, want) <= (0 if prec == "exact64" else WEIGHTED_RTOL)
+
+
 @pytest.mark.parametrize("weighted", [True, False])
 def test_more_than_2_to_the_32_pairs(weighted):
     """Maximum sizes: 93,000 samples = 4.3e9 pairs (35 GB of results) on a 16-leaf tree.
