@@ -6,12 +6,13 @@
 namespace ff {
 int device_count() { return 0; }
 void device_warmup(int) {}
+size_t device_free_bytes(int) { return 0; }
 int unifrac_dists_info(const ff_problem *, const ff_options *, double *, ff_plan_info *, char *err, size_t errlen)
 {
     return fail(FF_ERR_DEVICE, err, errlen, "device stub");
 }
 int unifrac_leaves_info(const ff_tree *, int64_t, const int64_t *, const int64_t *, const double *, int,
-                        const ff_options *, double *, ff_plan_info *, char *err, size_t errlen)
+                        const ff_options *, double *, ff_plan_info *, char *err, size_t errlen, bool)
 {
     return fail(FF_ERR_DEVICE, err, errlen, "device stub");
 }

@@ -233,59 +233,130 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
 
     warm.join();
     fputs("Calculating distances\n", stderr);  // unifrac.go:122
-    std::vector<double> out((size_t)ff_num_pairs(n));
+    // The pair space is cut into equal-pair row shards (ff_shard_rows).  -gpus G runs G of them
+    // at a time, one host thread per shard, shard g of a pass on device g modulo the devices
+    // present.  (Across processes the same shards are gathered: frackyfrac_amd/distributed.py.)
+    // Shards hold at most 2^25 pairs (fewer when the device is short of memory): larger
+    // problems run in several passes, and a pass is formatted and appended to the output
+    // by a writer thread while the next one is reduced (two sets of result buffers).  Like the
+    // reference, which streams pair by pair (unifrac.go:209-228), memory does not grow with
+    // the square of the samples.
+    const int ndev = ff::device_count();
+    if (ndev <= 0) {
+        ff_tree_free(tree);
+        return die("no HIP device available; this engine has no CPU path");
+    }
+    const int64_t P = ff_num_pairs(n);
+    int64_t budget = (int64_t)1 << 25;  // pairs per shard: 256 MB of results, written while the next shard runs
+    {
+        const size_t free_b = ff::device_free_bytes(0);
+        // 4 B accumulator + 8 B result per pair, the staged matrix and the rest in the other 40 %
+        if (free_b > 0) budget = std::min<int64_t>(budget, (int64_t)((double)free_b * 0.6 / 12.0));
+        if (const char *e = getenv("FF_CLI_MAX_PAIRS"))  // (tests)
+            if (atoll(e) > 0) budget = atoll(e);
+        budget = std::max<int64_t>(budget, 1);
+    }
+    const int64_t G = f.gpus;
+    int64_t passes = std::max<int64_t>(1, (P + budget * G - 1) / (budget * G));
+    passes = std::min<int64_t>(passes, std::max<int64_t>(1, (n + 31) / 32));  // shards are whole 32-row blocks
+    const int64_t world = G * passes;
+    if (world > INT32_MAX) {
+        ff_tree_free(tree);
+        return die("too many samples");
+    }
+    ff::DistWriter writer;
+    if (writer.open(f.out.empty() ? nullptr : f.out.c_str(), (int)f.nt, err, sizeof err)) {
+        ff_tree_free(tree);
+        return die(err);
+    }
     ff_plan_info info{};
-    // stage A (abundanceToFlatNodes + normalizeFlatNodes) runs on the device, then stage B
-    if (f.gpus <= 1) {
-        rc = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0,
-                                     &opt, out.data(), &info, err, sizeof err);
-    } else {
-        // -gpus G: the pair space is cut into G equal-pair row shards (ff_shard_rows), one
-        // host thread per shard; shard g runs on device g modulo the devices present and
-        // writes its contiguous slice of `out`.  (Across processes the same shards are
-        // gathered over RCCL: frackyfrac_amd/distributed.py.)
-        const int ndev = ff::device_count();
-        if (ndev <= 0) return die("no HIP device available; this engine has no CPU path");
-        std::vector<int> rcs((size_t)f.gpus, 0);
-        std::vector<std::string> errs((size_t)f.gpus);
-        std::vector<ff_plan_info> infos((size_t)f.gpus);
-        std::vector<std::thread> th;
-        for (long g = 0; g < f.gpus; ++g)
-            th.emplace_back([&, g] {
-                ff_options o = opt;
-                o.device = (int32_t)(g % ndev);
-                o.rank = (int32_t)g;
-                o.world = (int32_t)f.gpus;
-                char e[1024] = {0};
-                rcs[(size_t)g] = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
-                                                         f.nnorm ? 1 : 0, &o, out.data(), &infos[(size_t)g], e, sizeof e);
-                errs[(size_t)g] = e;
-            });
-        for (auto &t : th) t.join();
-        rc = 0;
-        for (long g = 0; g < f.gpus && rc == 0; ++g)
+    std::vector<std::vector<double>> sets[2] = {std::vector<std::vector<double>>((size_t)G),
+                                                std::vector<std::vector<double>>((size_t)G)};
+    double t_dist = 0, t_write = 0;  // time the main thread computed / waited for the writer
+    std::thread wr;
+    int wr_rc = 0;
+    char wr_err[1024] = {0};
+    rc = 0;
+    for (int64_t pass = 0; pass < passes && rc == 0; ++pass) {
+        auto p0 = std::chrono::steady_clock::now();
+        std::vector<std::vector<double>> &bufs = sets[pass & 1];
+        std::vector<int> rcs((size_t)G, 0);
+        std::vector<std::string> errs((size_t)G);
+        std::vector<ff_plan_info> infos((size_t)G);
+        auto one = [&](int64_t g) {
+            ff_options o = opt;
+            o.device = (int32_t)(g % ndev);
+            o.rank = (int32_t)(pass * G + g);
+            o.world = (int32_t)world;
+            char e[1024] = {0};
+            int64_t rb = 0, re = 0;
+            int r = ff_shard_rows(n, o.rank, o.world, &rb, &re);
+            if (r == 0) {
+                const int64_t a = rb * (rb - 1) / 2, b = re * (re - 1) / 2;  // IterPairs slots of rows [rb, re)
+                try {
+                    bufs[(size_t)g].resize((size_t)std::max<int64_t>(b - a, 0));
+                } catch (const std::bad_alloc &) {
+                    r = ff::fail(FF_ERR_INTERNAL, e, sizeof e, "out of host memory for %lld distances", (long long)(b - a));
+                }
+                if (r == 0)
+                    r = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0,
+                                                &o, bufs[(size_t)g].data(), &infos[(size_t)g], e, sizeof e, true);
+            } else {
+                snprintf(e, sizeof e, "bad shard %d of %d", o.rank, o.world);
+            }
+            rcs[(size_t)g] = r;
+            errs[(size_t)g] = e;
+        };
+        if (G == 1) {
+            one(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int64_t g = 0; g < G; ++g) th.emplace_back(one, g);
+            for (auto &t : th) t.join();
+        }
+        for (int64_t g = 0; g < G && rc == 0; ++g)
             if (rcs[(size_t)g]) {
                 rc = rcs[(size_t)g];
                 snprintf(err, sizeof err, "%s", errs[(size_t)g].c_str());
             }
-        info = infos[0];
+        if (pass == 0) info = infos[0];
+        auto p1 = std::chrono::steady_clock::now();
+        t_dist += std::chrono::duration<double>(p1 - p0).count();
+        if (wr.joinable()) wr.join();  // the previous pass is on its way out: its buffers are the next ones
+        if (rc == 0 && wr_rc != 0) {
+            rc = wr_rc;
+            snprintf(err, sizeof err, "%s", wr_err);
+        }
+        if (rc == 0)
+            wr = std::thread([&writer, &bufs, &wr_rc, &wr_err, G] {
+                for (int64_t g = 0; g < G && wr_rc == 0; ++g)
+                    wr_rc = writer.write(bufs[(size_t)g].data(), (int64_t)bufs[(size_t)g].size(), wr_err, sizeof wr_err);
+            });
+        t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - p1).count();
+    }
+    {
+        auto p1 = std::chrono::steady_clock::now();
+        if (wr.joinable()) wr.join();
+        t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - p1).count();
+    }
+    if (rc == 0 && wr_rc != 0) {
+        rc = wr_rc;
+        snprintf(err, sizeof err, "%s", wr_err);
     }
     ff_tree_free(tree);
+    if (rc == 0) rc = writer.close(err, sizeof err);
     if (rc) return die(err);
-    lap(4);
-
-    if (ff_write_distances(f.out.empty() ? nullptr : f.out.c_str(), out.data(), (int64_t)out.size(), (int)f.nt, err,
-                           sizeof err))
-        return die(err);
-    lap(5);
+    phase[4] = t_dist;
+    phase[5] = t_write;
+    last = std::chrono::steady_clock::now();
     if (f.stats)
         fprintf(stderr,
                 "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"tiles\": %lld, "
-                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"seconds\": {\"tree\": %.3f, "
+                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"seconds\": {\"tree\": %.3f, "
                 "\"load\": %.3f, \"validate\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f}}\n",
                 info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
                 info.lengths_exact, (long long)info.n_tiles, (long long)info.n_items,
-                (long long)info.n_wave_slots, info.staged_bytes, phase[0], phase[1], phase[2], phase[3], phase[4],
+                (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, phase[0], phase[1], phase[2], phase[3], phase[4],
                 phase[5]);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Took %s\n", go_duration(sec).c_str());

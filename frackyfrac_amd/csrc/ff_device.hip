@@ -1808,7 +1808,7 @@ int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int
 // plan.  If FIXED32's refinement queue overflowed, `recreate` builds an EXACT64 plan and
 // the shard is repeated with it.
 int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
-                         ff_plan_info *info_out, char *err, size_t errlen)
+                         ff_plan_info *info_out, char *err, size_t errlen, bool shard_local)
 {
     int rc = FF_OK;
     const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
@@ -1830,7 +1830,8 @@ int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recr
             if (rc == FF_OK) rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
         }
         if (rc == FF_OK) {
-            he = hipMemcpy(out + pl->info.slot_begin, d_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
+            he = hipMemcpy(out + (shard_local ? 0 : pl->info.slot_begin), d_out, sizeof(double) * (size_t)n_slots,
+                           hipMemcpyDeviceToHost);
             if (he != hipSuccess)
                 rc = ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
         }
@@ -1845,6 +1846,17 @@ int ff::device_count()
 {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+size_t ff::device_free_bytes(int device)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (device >= 0 && device != cur && hipSetDevice(device) != hipSuccess) return 0;
+    const bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (device >= 0 && device != cur) (void)hipSetDevice(cur);
+    return ok ? free_b : 0;
 }
 
 void ff::device_warmup(int want)
@@ -1877,9 +1889,10 @@ int ff::unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out
 // unifrac() with stage A on the device (used by ff_unifrac and the CLI).
 int ff::unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
                             const int64_t *leaf_idx, const double *leaf_val, int leave_unnormalized,
-                            const ff_options *o, double *out, ff_plan_info *info_out, char *err, size_t errlen)
+                            const ff_options *o, double *out, ff_plan_info *info_out, char *err, size_t errlen,
+                            bool shard_local)
 {
-    if (!out && n_samples > 1) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    if (!out && n_samples > 1 && !shard_local) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
     ff_plan *pl = nullptr;
     int rc = ff_plan_create_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, o, &pl,
                                         err, errlen);
@@ -1891,5 +1904,5 @@ int ff::unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_
         return ff_plan_create_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, &o2, np,
                                           err, errlen);
     };
-    return ff::run_plan_to_host(pl, again, out, info_out, err, errlen);
+    return ff::run_plan_to_host(pl, again, out, info_out, err, errlen, shard_local);
 }

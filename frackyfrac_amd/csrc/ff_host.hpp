@@ -42,15 +42,37 @@ void parallel_for(int64_t n, unsigned threads,
 int unifrac_dists_info(const ff_problem *p, const ff_options *o, double *out, ff_plan_info *info,
                        char *err, size_t errlen);
 // The same from leaf values: stage A runs on the device.
+// shard_local: out[0] is the shard's first slot (out has slot_end - slot_begin entries)
+// instead of slot 0 of the whole triangle.
 int unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,
                         const int64_t *leaf_idx, const double *leaf_val, int leave_unnormalized,
-                        const ff_options *o, double *out, ff_plan_info *info, char *err, size_t errlen);
+                        const ff_options *o, double *out, ff_plan_info *info, char *err, size_t errlen,
+                        bool shard_local = false);
 int run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
-                     ff_plan_info *info, char *err, size_t errlen);
+                     ff_plan_info *info, char *err, size_t errlen, bool shard_local = false);
 // Number of HIP devices visible (0 when there is none).
 int device_count();
 // Brings the HIP context of the first `want` devices up (errors are left for the first real call).
 void device_warmup(int want);
+// Free memory of a device in bytes (0 when it cannot be asked).
+size_t device_free_bytes(int device);
+
+// The output file of frcfrc (frcfrc.go:58-62,102): values appended in calls, one per line.
+class DistWriter {
+public:
+    ~DistWriter();
+    int open(const char *path /* null: stdout */, int threads, char *err, size_t errlen);
+    int write(const double *d, int64_t n, char *err, size_t errlen);
+    int close(char *err, size_t errlen);
+
+private:
+    int fd_ = -1;
+    bool own_ = false, gz_ = false, seekable_ = false;
+    unsigned nt_ = 1;
+    int64_t off_ = 0;
+    std::string name_;
+    std::vector<std::string> bufs_, zbufs_;
+};
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
                     std::vector<int64_t> *idx, std::vector<double> *val);

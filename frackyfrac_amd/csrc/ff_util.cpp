@@ -187,6 +187,135 @@ void parallel_for(int64_t n, unsigned threads,
     for (auto &x : th) x.join();
 }
 
+
+// Compresses one buffer into a complete gzip member (RFC 1952 allows a file to be a
+// sequence of members; gostuff/aio's reader, gzip(1) and zlib's gzread all read them as
+// one stream), so the threads of a round can deflate their parts independently.
+static bool gzip_member(const std::string &in, std::string *out)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out->resize(deflateBound(&z, (uLong)in.size()) + 32);
+    z.next_in = (Bytef *)in.data();
+    z.avail_in = (uInt)in.size();
+    z.next_out = (Bytef *)&(*out)[0];
+    z.avail_out = (uInt)out->size();
+    const int r = deflate(&z, Z_FINISH);
+    out->resize(out->size() - z.avail_out);
+    deflateEnd(&z);
+    return r == Z_STREAM_END;
+}
+
+static bool write_fully(int fd, const char *p, size_t n, int64_t off /* -1: append at the file position */)
+{
+    while (n > 0) {
+        const ssize_t w = off >= 0 ? pwrite(fd, p, n, (off_t)off) : write(fd, p, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += w;
+        n -= (size_t)w;
+        if (off >= 0) off += w;
+    }
+    return true;
+}
+
+
+DistWriter::~DistWriter()
+{
+    if (own_ && fd_ >= 0) ::close(fd_);
+}
+
+int DistWriter::open(const char *path, int threads, char *err, size_t errlen)
+{
+    // aio.Create (frcfrc.go:102): ".gz" output is compressed, by suffix
+    gz_ = path && has_suffix(path, ".gz");
+    name_ = path ? path : "stdout";
+    fd_ = 1;
+    own_ = false;
+    if (path) {
+        fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (fd_ < 0) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+        own_ = true;
+    } else {
+        fflush(stdout);
+    }
+    struct stat st;
+    seekable_ = path && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);
+    nt_ = clamp_threads(threads);
+    bufs_.assign(nt_, std::string());
+    zbufs_.assign(gz_ ? nt_ : 0, std::string());
+    off_ = 0;
+    return FF_OK;
+}
+
+int DistWriter::write(const double *d, int64_t n, char *err, size_t errlen)
+{
+    const int64_t PART = 1 << 18;  // values per thread per round (<= 25 B each)
+    const unsigned nt = nt_;
+    std::vector<int> ok(nt, 1);
+    auto io_fail = [&] { return fail(FF_ERR_IO, err, errlen, "write %s: %s", name_.c_str(), strerror(errno)); };
+    for (int64_t base = 0; base < n; base += PART * nt) {
+        const int64_t m = std::min<int64_t>(PART * nt, n - base);
+        for (auto &s : bufs_) s.clear();
+        for (auto &s : zbufs_) s.clear();
+        parallel_for(m, nt, [&](unsigned t, int64_t b, int64_t e) {
+            std::string &s = bufs_[t];
+            s.resize((size_t)(e - b) * 26);
+            char *o = &s[0];
+            for (int64_t i = b; i < e; ++i) {
+                o += ff_format_float(d[base + i], o);
+                *o++ = '\n';
+            }
+            s.resize((size_t)(o - s.data()));
+            if (gz_) ok[t] = gzip_member(s, &zbufs_[t]) ? 1 : 0;
+        });
+        std::vector<std::string> &outb = gz_ ? zbufs_ : bufs_;
+        if (gz_)
+            for (unsigned t = 0; t < nt; ++t)
+                if (!ok[t]) return fail(FF_ERR_IO, err, errlen, "write %s: gzip error", name_.c_str());
+        if (seekable_ && nt > 1) {
+            std::vector<int64_t> off(nt + 1, off_);
+            for (unsigned t = 0; t < nt; ++t) off[t + 1] = off[t] + (int64_t)outb[t].size();
+            int first_errno = 0;
+            parallel_for(nt, nt, [&](unsigned, int64_t b, int64_t e) {
+                for (int64_t t = b; t < e; ++t)
+                    if (!outb[(size_t)t].empty() &&
+                        !write_fully(fd_, outb[(size_t)t].data(), outb[(size_t)t].size(), off[(size_t)t])) {
+                        ok[(size_t)t] = 0;
+                        first_errno = errno;
+                    }
+            });
+            for (unsigned t = 0; t < nt; ++t)
+                if (!ok[t]) {
+                    errno = first_errno;
+                    return io_fail();
+                }
+            off_ = off[nt];
+        } else {
+            for (unsigned t = 0; t < nt; ++t) {
+                if (outb[t].empty()) continue;
+                // (a regular file written by one thread still goes by offset: the parts of later
+                // calls must land behind these)
+                if (!write_fully(fd_, outb[t].data(), outb[t].size(), seekable_ ? off_ : -1)) return io_fail();
+                off_ += (int64_t)outb[t].size();
+            }
+        }
+    }
+    return FF_OK;
+}
+
+int DistWriter::close(char *err, size_t errlen)
+{
+    int rc = FF_OK;
+    if (own_ && fd_ >= 0 && ::close(fd_) != 0) rc = fail(FF_ERR_IO, err, errlen, "close %s: %s", name_.c_str(), strerror(errno));
+    fd_ = -1;
+    own_ = false;
+    return rc;
+}
+
 }  // namespace ff
 
 extern "C" {
@@ -300,40 +429,6 @@ int ff_format_float(double f, char *buf)
     return (int)(o - buf);
 }
 
-// Compresses one buffer into a complete gzip member (RFC 1952 allows a file to be a
-// sequence of members; gostuff/aio's reader, gzip(1) and zlib's gzread all read them as
-// one stream), so the threads of a round can deflate their parts independently.
-static bool gzip_member(const std::string &in, std::string *out)
-{
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    out->resize(deflateBound(&z, (uLong)in.size()) + 32);
-    z.next_in = (Bytef *)in.data();
-    z.avail_in = (uInt)in.size();
-    z.next_out = (Bytef *)&(*out)[0];
-    z.avail_out = (uInt)out->size();
-    const int r = deflate(&z, Z_FINISH);
-    out->resize(out->size() - z.avail_out);
-    deflateEnd(&z);
-    return r == Z_STREAM_END;
-}
-
-static bool write_fully(int fd, const char *p, size_t n, int64_t off /* -1: append at the file position */)
-{
-    while (n > 0) {
-        const ssize_t w = off >= 0 ? pwrite(fd, p, n, (off_t)off) : write(fd, p, n);
-        if (w < 0) {
-            if (errno == EINTR) continue;
-            return false;
-        }
-        p += w;
-        n -= (size_t)w;
-        if (off >= 0) off += w;
-    }
-    return true;
-}
-
 // frcfrc.go:58-62: one fmt.Fprintln(fout, f) per value.  Rounds of `threads` parts: every
 // thread formats its part of the round (and, for ".gz", deflates it into a gzip member of its
 // own); a regular file then takes the parts in parallel at their byte offsets (pwrite), a pipe
@@ -341,70 +436,11 @@ static bool write_fully(int fd, const char *p, size_t n, int64_t off /* -1: appe
 int ff_write_distances(const char *path, const double *d, int64_t n, int threads,
                        char *err, size_t errlen)
 {
-    // aio.Create (frcfrc.go:102): ".gz" output is compressed, by suffix
-    const bool gz = path && ff::has_suffix(path, ".gz");
-    int fd = 1;
-    if (path) {
-        fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
-        if (fd < 0) return ff::fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
-    } else {
-        fflush(stdout);
-    }
-    struct stat st;
-    const bool seekable = path && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
-    const unsigned nt = ff::clamp_threads(threads);
-    const int64_t PART = 1 << 18;  // values per thread per round (<= 25 B each)
-    std::vector<std::string> bufs(nt), zbufs(gz ? nt : 0);
-    std::vector<int> ok(nt, 1);
-    int rc = FF_OK;
-    int64_t file_off = 0;
-    auto io_fail = [&] {
-        return ff::fail(FF_ERR_IO, err, errlen, "write %s: %s", path ? path : "stdout", strerror(errno));
-    };
-    for (int64_t base = 0; base < n && rc == FF_OK; base += PART * nt) {
-        const int64_t m = std::min<int64_t>(PART * nt, n - base);
-        for (auto &s : bufs) s.clear();
-        for (auto &s : zbufs) s.clear();
-        ff::parallel_for(m, nt, [&](unsigned t, int64_t b, int64_t e) {
-            std::string &s = bufs[t];
-            s.resize((size_t)(e - b) * 26);
-            char *o = &s[0];
-            for (int64_t i = b; i < e; ++i) {
-                o += ff_format_float(d[base + i], o);
-                *o++ = '\n';
-            }
-            s.resize((size_t)(o - s.data()));
-            if (gz) ok[t] = gzip_member(s, &zbufs[t]) ? 1 : 0;
-        });
-        std::vector<std::string> &outb = gz ? zbufs : bufs;
-        if (gz)
-            for (unsigned t = 0; t < nt; ++t)
-                if (!ok[t]) rc = ff::fail(FF_ERR_IO, err, errlen, "write %s: gzip error", path);
-        if (rc != FF_OK) break;
-        if (seekable && nt > 1) {
-            std::vector<int64_t> off(nt + 1, file_off);
-            for (unsigned t = 0; t < nt; ++t) off[t + 1] = off[t] + (int64_t)outb[t].size();
-            int first_errno = 0;
-            ff::parallel_for(nt, nt, [&](unsigned, int64_t b, int64_t e) {
-                for (int64_t t = b; t < e; ++t)
-                    if (!outb[(size_t)t].empty() && !write_fully(fd, outb[(size_t)t].data(), outb[(size_t)t].size(), off[(size_t)t])) {
-                        ok[(size_t)t] = 0;
-                        first_errno = errno;
-                    }
-            });
-            for (unsigned t = 0; t < nt; ++t)
-                if (!ok[t]) {
-                    errno = first_errno;
-                    rc = io_fail();
-                }
-            file_off = off[nt];
-        } else {
-            for (unsigned t = 0; t < nt && rc == FF_OK; ++t)
-                if (!outb[t].empty() && !write_fully(fd, outb[t].data(), outb[t].size(), -1)) rc = io_fail();
-        }
-    }
-    if (path && close(fd) != 0 && rc == FF_OK) rc = ff::fail(FF_ERR_IO, err, errlen, "close %s: %s", path, strerror(errno));
-    return rc;
+    ff::DistWriter w;
+    int rc = w.open(path, threads, err, errlen);
+    if (rc == FF_OK) rc = w.write(d, n, err, errlen);
+    const int rc2 = w.close(rc == FF_OK ? err : nullptr, rc == FF_OK ? errlen : 0);
+    return rc != FF_OK ? rc : rc2;
 }
 
 }  // extern "C"

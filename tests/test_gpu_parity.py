@@ -347,6 +347,33 @@ def test_cli_gpus_flag_matches_single_shard(tmp_path):
     assert outs[0] == outs[1] and outs[0].count("\n") == 700 * 699 // 2
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_cli_streams_the_pair_space_in_passes(tmp_path, weighted):
+    """When all pairs at once would not fit the device, frcfrc runs the row shards in
+    passes and appends each pass to the output (forced here with a budget of 5,000 pairs per
+    shard): same bytes as the single pass, to a file, to a .gz, to stdout, with -gpus."""
+    import gzip
+    tree, ptr, idx, val = synth.make(500, 300, 0.1, 98)
+    (tmp_path / "t.tree").write_text(tree.newick())
+    (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr, idx, val))
+    base = [L.FRCFRC_PATH, "-s", "-precision", "fixed32", "-i", str(tmp_path / "t.sparse"), "-t", str(tmp_path / "t.tree")]
+    if weighted:
+        base.insert(1, "-w")
+    r = subprocess.run(base + ["-o", str(tmp_path / "one.txt"), "-stats"], capture_output=True, text=True)
+    assert r.returncode == 0 and '"passes": 1,' in r.stderr, r.stderr
+    want = (tmp_path / "one.txt").read_text()
+    assert want.count("\n") == 500 * 499 // 2
+    env = dict(os.environ, FF_CLI_MAX_PAIRS="5000")
+    r = subprocess.run(base + ["-o", str(tmp_path / "many.txt"), "-stats", "-p", "3"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and '"passes": 16,' in r.stderr, r.stderr      # 500 samples = 16 blocks of 32 rows
+    assert (tmp_path / "many.txt").read_text() == want
+    r = subprocess.run(base + ["-o", str(tmp_path / "many.txt.gz"), "-p", "2", "-gpus", "3"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(tmp_path / "many.txt.gz", "rt").read() == want
+    r = subprocess.run(base + ["-gpus", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout == want
+
+
 def test_c5_shaped_sparse_input_through_the_cli(tmp_path):
     """BASELINE configs[4] shape at reduced sample count: 50k-leaf tree (B = 99,999),
     5 % density, sparse text table, through the frcfrc executable, both metrics."""
