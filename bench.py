@@ -145,8 +145,10 @@ def main():
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     info = run.plan.info
+    if world > 1 and rank == 1 and run.ipc_gbps is not None:
+        log("rank 1: ipc slice copy into the root's buffer %.1f GB/s (all peers at once)" % run.ipc_gbps)
     if rank == 0 and world > 1:
-        log("gather transport: %s%s" % (run.transport, (" (ipc unavailable: %s)" % run.transport_note) if run.transport_note else ""))
+        log("gather transport: %s%s" % (run.transport, (" (ipc not used: %s)" % run.transport_note) if run.transport_note else ""))
     if rank == 0:
         log("workload %s: N=%d leaves=%d B=%d nnz=%d pairs=%d | prep %.2fs stage(H2D+quantise) %.3fs | "
             "precision=%s scale=2^%d tiles=%d items=%d wave_slots=%d" %

@@ -100,6 +100,7 @@ class ShardedRun:
             raise ValueError("transport must be auto, ipc or nccl")
         self.transport = "none" if world == 1 else "nccl"
         self.transport_note = ""
+        self.ipc_gbps = None
         self._k = 0
         if world > 1 and self.chunks == 1 and transport in ("auto", "ipc"):
             if self._setup_ipc():
@@ -172,6 +173,31 @@ class ShardedRun:
         if not all_ok:
             self.remote = None
             self.transport_note = note or "another rank failed"
+            return False
+        # bandwidth probe: all peers copy their whole slice at once, as in a step.  A mapping
+        # that works but crawls (staged through the host, say) must not beat RCCL to the job.
+        gbps = float("inf")
+        try:
+            if self.rank != self.root and b > a:
+                self.remote[a:b].copy_(self.local)           # first touch
+                torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+            if self.rank != self.root and b > a:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.remote[a:b].copy_(self.local, non_blocking=True)
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                gbps = 8.0 * (b - a) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception as e:  # noqa: BLE001
+            gbps, note = 0.0, "probe: %r" % (e,)
+        self.ipc_gbps = gbps
+        min_gbps = float(os.environ.get("FF_GATHER_MIN_GBPS", "15"))
+        fast = gbps >= min_gbps or (b - a) * 8 < (4 << 20)    # (tiny slices only measure latency)
+        if not self._flag_all(fast):
+            self.remote = None
+            self.transport_note = note or ("ipc copies too slow (%.1f GB/s on this rank; FF_GATHER_MIN_GBPS=%g)"
+                                           % (gbps, min_gbps))
             return False
         self.side = torch.cuda.Stream(device=self.device)
         self.locals = [self.local, torch.empty_like(self.local)] if self.rank != self.root else [self.local]
