@@ -77,6 +77,57 @@ private:
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
                     std::vector<int64_t> *idx, std::vector<double> *val);
 
+
+// Index of a vector of distinct names: open addressing over (hash tag, id + 1).  A lookup
+// costs one hash of the token and usually one compare -- no std::string is built per token.
+struct NameIndex {
+    std::vector<uint64_t> slot;  // 0 = empty
+    size_t mask = 0;
+    static uint64_t hash(const char *b, const char *e)
+    {
+        uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a, then a finalising mix
+        for (const char *p = b; p < e; ++p) h = (h ^ (unsigned char)*p) * 0x100000001b3ull;
+        h ^= h >> 29;
+        h *= 0xbf58476d1ce4e5b9ull;
+        h ^= h >> 32;
+        return h;
+    }
+    void grow(const std::vector<std::string> &names)
+    {
+        const size_t n = slot.empty() ? 1024 : slot.size() * 2;
+        std::vector<uint64_t> old;
+        old.swap(slot);
+        slot.assign(n, 0);
+        mask = n - 1;
+        for (uint64_t s : old)
+            if (s) {
+                const std::string &nm = names[(size_t)(uint32_t)s - 1];
+                size_t at = (size_t)hash(nm.data(), nm.data() + nm.size()) & mask;
+                while (slot[at]) at = (at + 1) & mask;
+                slot[at] = s;
+            }
+    }
+    // id of [b, e) in *names, appended when new
+    int32_t intern(std::vector<std::string> *names, const char *b, const char *e)
+    {
+        if ((names->size() + 1) * 2 > slot.size()) grow(*names);
+        const uint64_t h = hash(b, e), tag = h & 0xffffffff00000000ull;
+        const size_t len = (size_t)(e - b);
+        for (size_t at = (size_t)h & mask;; at = (at + 1) & mask) {
+            const uint64_t s = slot[at];
+            if (!s) {
+                names->emplace_back(b, e);
+                slot[at] = tag | (uint64_t)names->size();
+                return (int32_t)names->size() - 1;
+            }
+            if ((s & 0xffffffff00000000ull) == tag) {
+                const std::string &nm = (*names)[(size_t)(uint32_t)s - 1];
+                if (nm.size() == len && memcmp(nm.data(), b, len) == 0) return (int32_t)(uint32_t)s - 1;
+            }
+        }
+    }
+};
+
 }  // namespace ff
 
 // The tree in enumerateNodes' numbering (frcfrc/unifrac.go:127-133).
@@ -97,7 +148,7 @@ struct ff_tree {
 // insertion order; a re-assigned key keeps its slot and takes the last value.
 struct ff_table {
     std::vector<std::string> species;
-    std::unordered_map<std::string, int32_t> species_id;
+    ff::NameIndex index;
     std::vector<int64_t> ptr;  // [n_samples + 1]
     std::vector<int32_t> key;  // species index
     std::vector<double> val;

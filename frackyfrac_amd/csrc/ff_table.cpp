@@ -7,20 +7,13 @@
 // Instead of one Go map per sample the table keeps one species dictionary and
 // CSR rows of (species index, value); a key assigned twice keeps its first
 // position and its last value, which is what a map assignment leaves behind.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "ff_host.hpp"
 
-int32_t ff_table::intern(const char *b, const char *e)
-{
-    std::string s(b, e);
-    auto it = species_id.find(s);
-    if (it != species_id.end()) return it->second;
-    int32_t id = (int32_t)species.size();
-    species.push_back(s);
-    species_id.emplace(std::move(s), id);
-    return id;
-}
+int32_t ff_table::intern(const char *b, const char *e) { return index.intern(&species, b, e); }
 
 namespace {
 
@@ -51,29 +44,33 @@ struct Lines {
 struct Row {  // one sample being assembled, with last-assignment-wins keys
     std::vector<int32_t> key;
     std::vector<double> val;
-    std::unordered_map<int32_t, size_t> pos;
+    // where[k] is key k's position in this row iff stamp[k] == cur (no per-row clearing)
+    std::vector<uint32_t> stamp, where;
+    uint32_t cur = 0;
     void clear()
     {
         key.clear();
         val.clear();
-        pos.clear();
+        if (++cur == 0) {  // the stamp wrapped: forget everything once
+            std::fill(stamp.begin(), stamp.end(), 0u);
+            cur = 1;
+        }
     }
     void set(int32_t k, double v)
     {
-        auto it = pos.find(k);
-        if (it != pos.end()) {
-            val[it->second] = v;
+        if ((size_t)k >= stamp.size()) {
+            const size_t n = std::max<size_t>((size_t)k + 1, stamp.size() * 2);
+            stamp.resize(n, 0u);
+            where.resize(n, 0u);
+        }
+        if (stamp[(size_t)k] == cur) {
+            val[where[(size_t)k]] = v;
             return;
         }
-        pos.emplace(k, key.size());
+        stamp[(size_t)k] = cur;
+        where[(size_t)k] = (uint32_t)key.size();
         key.push_back(k);
         val.push_back(v);
-    }
-    void flush(ff_table *t)
-    {
-        t->key.insert(t->key.end(), key.begin(), key.end());
-        t->val.insert(t->val.end(), val.begin(), val.end());
-        t->ptr.push_back((int64_t)t->key.size());
     }
 };
 
@@ -168,8 +165,8 @@ int parse_sparse_row(const char *b, const char *e, Intern &&intern, Row *row, ch
 
 // The rows of [first, last) parsed by one thread into a private partial table.
 struct Partial {
-    std::vector<std::string> species;  // sparse only: thread-local dictionary
-    std::unordered_map<std::string, int32_t> species_id;
+    std::vector<std::string> names;    // sparse only: thread-local dictionary
+    ff::NameIndex dict;
     std::vector<int64_t> cnt;          // entries per row
     std::vector<int32_t> key;
     std::vector<double> val;
@@ -181,6 +178,9 @@ struct Partial {
 int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_table **out, char *err, size_t errlen)
 {
     if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse: null argument");
+    const bool trace = getenv("FF_TRACE_PARSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = now();
     std::vector<LineRef> lines;
     {
         Lines ls{text, text + len};
@@ -216,18 +216,11 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
     unsigned nt = ff::clamp_threads(nthreads);
     if ((int64_t)nt > std::max<int64_t>(nrows, 1)) nt = (unsigned)std::max<int64_t>(nrows, 1);
     std::vector<Partial> parts(nt);
+    const double T1 = now();
     ff::parallel_for(nrows, nt, [&](unsigned tid, int64_t b, int64_t e) {
         Partial &pt = parts[tid];
         Row row;
-        auto intern = [&pt](const char *p, const char *q) -> int32_t {
-            std::string s(p, q);
-            auto it = pt.species_id.find(s);
-            if (it != pt.species_id.end()) return it->second;
-            const int32_t id = (int32_t)pt.species.size();
-            pt.species.push_back(s);
-            pt.species_id.emplace(std::move(s), id);
-            return id;
-        };
+        auto intern = [&pt](const char *p, const char *q) -> int32_t { return pt.dict.intern(&pt.names, p, q); };
         for (int64_t r = b; r < e; ++r) {
             const LineRef &ln = lines[first + (size_t)r];
             const int rc = sparse ? parse_sparse_row(ln.b, ln.e, intern, &row, pt.err, sizeof pt.err)
@@ -242,27 +235,50 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
             pt.val.insert(pt.val.end(), row.val.begin(), row.val.end());
         }
     });
+    const double T2 = now();
     // the first failing row in row order wins, as with the reference's ordered pipeline
     for (const Partial &pt : parts)
         if (pt.err_code) {
             delete t;
             return ff::fail(pt.err_code, err, errlen, "%s", pt.err);
         }
-    size_t total = 0;
-    for (const Partial &pt : parts) total += pt.key.size();
-    t->key.reserve(total);
-    t->val.reserve(total);
-    for (Partial &pt : parts) {
-        std::vector<int32_t> remap;
+    // merge: thread dictionaries into the table's (first appearance in row order keeps the
+    // lower id), then every partial copies its rows to its place in parallel
+    std::vector<size_t> key_at(parts.size() + 1, 0), row_at(parts.size() + 1, 0);
+    std::vector<std::vector<int32_t>> remap(parts.size());
+    for (size_t q = 0; q < parts.size(); ++q) {
+        const Partial &pt = parts[q];
+        key_at[q + 1] = key_at[q] + pt.key.size();
+        row_at[q + 1] = row_at[q] + pt.cnt.size();
         if (sparse) {
-            remap.resize(pt.species.size());
-            for (size_t k = 0; k < pt.species.size(); ++k)
-                remap[k] = t->intern(pt.species[k].data(), pt.species[k].data() + pt.species[k].size());
+            remap[q].resize(pt.names.size());
+            for (size_t k = 0; k < pt.names.size(); ++k)
+                remap[q][k] = t->intern(pt.names[k].data(), pt.names[k].data() + pt.names[k].size());
         }
-        for (size_t k = 0; k < pt.key.size(); ++k) t->key.push_back(sparse ? remap[(size_t)pt.key[k]] : pt.key[k]);
-        t->val.insert(t->val.end(), pt.val.begin(), pt.val.end());
-        for (int64_t c : pt.cnt) t->ptr.push_back(t->ptr.back() + c);
     }
+    const double T3 = now();
+    t->key.resize(key_at.back());
+    t->val.resize(key_at.back());
+    t->ptr.resize(row_at.back() + 1);
+    ff::parallel_for((int64_t)parts.size(), (unsigned)parts.size(), [&](unsigned, int64_t qb, int64_t qe) {
+        for (int64_t q = qb; q < qe; ++q) {
+            const Partial &pt = parts[(size_t)q];
+            int32_t *kd = t->key.data() + key_at[(size_t)q];
+            if (sparse)
+                for (size_t k = 0; k < pt.key.size(); ++k) kd[k] = remap[(size_t)q][(size_t)pt.key[k]];
+            else if (!pt.key.empty())
+                memcpy(kd, pt.key.data(), sizeof(int32_t) * pt.key.size());
+            if (!pt.val.empty()) memcpy(t->val.data() + key_at[(size_t)q], pt.val.data(), sizeof(double) * pt.val.size());
+            int64_t at = (int64_t)key_at[(size_t)q];
+            for (size_t r = 0; r < pt.cnt.size(); ++r) {
+                at += pt.cnt[r];
+                t->ptr[row_at[(size_t)q] + r + 1] = at;
+            }
+        }
+    });
+    if (trace)
+        fprintf(stderr, "parse_table: lines %.3f rows %.3f dict-merge %.3f copy %.3f s (threads %u)\n", T1 - T0, T2 - T1,
+                T3 - T2, now() - T3, nt);
     *out = t;
     return FF_OK;
 }

@@ -83,6 +83,33 @@ bool go_parse_float(const char *b, const char *e, double *out, const char **why)
 {
     *why = "invalid syntax";
     if (b == e) return false;
+    {
+        // Fast path for the tokens abundance tables are made of: DIGITS or DIGITS.DIGITS with
+        // at most 15 significant digits.  The integer below and the power of ten are then both
+        // exact in binary64, so one division (or none) is correctly rounded (Clinger) -- the
+        // same value the general conversion gives.
+        static const double P10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                     1e12, 1e13, 1e14, 1e15};
+        uint64_t m = 0;
+        int nd = 0, nfrac = -1;
+        const char *q = b;
+        for (; q < e; ++q) {
+            const unsigned c = (unsigned)(*q - '0');
+            if (c <= 9) {
+                m = m * 10 + c;
+                ++nd;
+                if (nfrac >= 0) ++nfrac;
+            } else if (*q == '.' && nfrac < 0 && nd > 0) {
+                nfrac = 0;
+            } else {
+                break;
+            }
+        }
+        if (q == e && nd > 0 && nd <= 15 && nfrac != 0) {
+            *out = nfrac > 0 ? (double)m / P10[nfrac] : (double)m;
+            return true;
+        }
+    }
     const char *p = b;
     bool neg = false;
     if (*p == '+' || *p == '-') {
