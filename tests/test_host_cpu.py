@@ -210,6 +210,29 @@ def test_stage_a_synthetic_matches_oracle(seed, ns, nl, dens):
         assert np.array_equal(again.indptr, got.indptr) and np.array_equal(again.abnd, got.abnd)
 
 
+def test_value_tokens_parse_like_strconv():
+    """Every spelling of a value, including the loader's fast path for plain decimals of at
+    most 15 digits, must give the correctly rounded binary64 (Python's float() is)."""
+    rng = np.random.default_rng(21)
+    toks = ["1", "007", "0.5", "123456789012345", "1234567890123456", "0.000000000000001", "99999.9999999999",
+            "1e3", "1E-3", "1.", ".5", "0x1p-2", "10", "4.9e-324", "1.7976931348623157e308",
+            "2.2250738585072011e-308", "9007199254740993", "0.1", "0.30000000000000004", "123.456", "5e-1"]
+    for _ in range(3000):
+        nd = int(rng.integers(1, 19))
+        digits = "".join(str(int(d)) for d in rng.integers(0, 10, nd))
+        cut = int(rng.integers(0, nd + 1))
+        tok = digits if cut in (0, nd) else digits[:cut] + "." + digits[cut:]
+        if float(tok) > 0:
+            toks.append(tok)
+    val = lambda tok: float.fromhex(tok) if tok.startswith("0x") else float(tok)
+    line = " ".join("s%d:%s" % (i, t) for i, t in enumerate(toks))
+    for threads in (1, 3):
+        t = ff.parse_sparse_abundance(line + "\n", ngoroutines=threads)
+        got = t.to_maps()[0]
+        for i, tok in enumerate(toks):
+            assert got["s%d" % i] == val(tok), tok
+
+
 def test_format_float_matches_oracle():
     rng = np.random.default_rng(5)
     vals = [0.0, 1.0, 0.5, 1e-4, 0.00001234, 2 / 3, 19 / 28, 16 / 22, 22 / 36, 1e6, 123456.0, 1234567.0, 1e-5,
