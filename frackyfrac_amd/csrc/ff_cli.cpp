@@ -226,7 +226,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     fputs("Converting abundances\n", stderr);  // unifrac.go:101
     std::vector<int64_t> leaf_ptr, leaf_idx;
     std::vector<double> leaf_val;
-    ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val);
+    ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val, (int)f.nt);
     const int64_t n = ff_table_num_samples(table);
     ff_table_free(table);
     lap(3);

@@ -108,7 +108,7 @@ namespace ff {
 // a name carried by several leaves feeds each of them; a key naming an internal node is
 // never looked up.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
-                    std::vector<int64_t> *idx, std::vector<double> *val)
+                    std::vector<int64_t> *idx, std::vector<double> *val, int threads)
 {
     std::vector<const std::vector<int64_t> *> where(tb.species.size(), nullptr);
     for (size_t k = 0; k < tb.species.size(); ++k) {
@@ -116,20 +116,33 @@ void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> 
         if (it != tr.leaf_ids.end()) where[k] = &it->second;
     }
     const int64_t ns = (int64_t)tb.ptr.size() - 1;
+    const unsigned nt = clamp_threads(threads);
+    // count, prefix, fill: samples are independent
     ptr->assign((size_t)ns + 1, 0);
-    idx->clear();
-    val->clear();
-    for (int64_t s = 0; s < ns; ++s) {
-        for (int64_t k = tb.ptr[(size_t)s]; k < tb.ptr[(size_t)s + 1]; ++k) {
-            const auto *ids = where[(size_t)tb.key[(size_t)k]];
-            if (!ids) continue;
-            for (int64_t id : *ids) {
-                idx->push_back(id);
-                val->push_back(tb.val[(size_t)k]);
+    parallel_for(ns, nt, [&](unsigned, int64_t sb, int64_t se) {
+        for (int64_t s = sb; s < se; ++s) {
+            int64_t c = 0;
+            for (int64_t k = tb.ptr[(size_t)s]; k < tb.ptr[(size_t)s + 1]; ++k)
+                if (const auto *ids = where[(size_t)tb.key[(size_t)k]]) c += (int64_t)ids->size();
+            (*ptr)[(size_t)s + 1] = c;
+        }
+    });
+    for (int64_t s = 0; s < ns; ++s) (*ptr)[(size_t)s + 1] += (*ptr)[(size_t)s];
+    idx->resize((size_t)(*ptr)[(size_t)ns]);
+    val->resize((size_t)(*ptr)[(size_t)ns]);
+    parallel_for(ns, nt, [&](unsigned, int64_t sb, int64_t se) {
+        for (int64_t s = sb; s < se; ++s) {
+            size_t at = (size_t)(*ptr)[(size_t)s];
+            for (int64_t k = tb.ptr[(size_t)s]; k < tb.ptr[(size_t)s + 1]; ++k) {
+                const auto *ids = where[(size_t)tb.key[(size_t)k]];
+                if (!ids) continue;
+                for (int64_t id : *ids) {
+                    (*idx)[at] = id;
+                    (*val)[at++] = tb.val[(size_t)k];
+                }
             }
         }
-        (*ptr)[(size_t)s + 1] = (int64_t)idx->size();
-    }
+    });
 }
 
 }  // namespace ff

@@ -75,7 +75,7 @@ private:
 };
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
-                    std::vector<int64_t> *idx, std::vector<double> *val);
+                    std::vector<int64_t> *idx, std::vector<double> *val, int threads = 1);
 
 
 // Index of a vector of distinct names: open addressing over (hash tag, id + 1).  A lookup
