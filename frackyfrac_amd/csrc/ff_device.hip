@@ -50,6 +50,12 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t s, uint32_t v, uint32_t acc
     return r;
 }
 
+// The same in place: the accumulator keeps its register (what a kernel with no VGPR to spare needs).
+__device__ __forceinline__ void sad_u32_acc(uint32_t s, uint32_t v, uint32_t &acc)
+{
+    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "s"(s), "v"(v));
+}
+
 // Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
 __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
                                      const int32_t *__restrict__ branch_id,
@@ -113,7 +119,7 @@ template <int NC> __device__ __forceinline__ RowVec<NC> load_row(const uint32_t 
 }
 
 // One work item: a 32 x (64*NC) pair tile over the branch rows [k0, k1).
-template <int NC>
+template <int NC, int KS = KSTEP>
 __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
                                          uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
                                          int64_t slot_begin, int sync_trips, int lane)
@@ -134,17 +140,17 @@ __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_
     // still in flight at the loop's back edge are always old (the compiler drains vmcnt
     // there).  The 32 scalars of the next row are fetched one step ahead into the idle
     // one of two SGPR sets.
-    RowVec<NC> vA[KSTEP], vB[KSTEP];
+    RowVec<NC> vA[KS], vB[KS];
 #pragma unroll
-    for (int d = 0; d < KSTEP; ++d) vA[d] = load_row<NC>(pj + (int64_t)d * ld);
-    const uint32_t *pv = pj + (int64_t)KSTEP * ld;
+    for (int d = 0; d < KS; ++d) vA[d] = load_row<NC>(pj + (int64_t)d * ld);
+    const uint32_t *pv = pj + (int64_t)KS * ld;
     uint32_t sA[TILE_I], sB[TILE_I];
 #pragma unroll
     for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
     const int nk = item.k1 - item.k0;
 #define FF_STEP(SCUR, SNXT, V, PREFETCH)                                        \
     {                                                                          \
-        acc[0][0] = sad_u32(SCUR[0], (V).v[0], acc[0][0]);                     \
+        sad_u32_acc(SCUR[0], (V).v[0], acc[0][0]);                                \
         __builtin_amdgcn_sched_barrier(0);                                     \
         ps += ld;                                                              \
         _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];    \
@@ -152,18 +158,18 @@ __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_
         __builtin_amdgcn_sched_barrier(0);                                     \
         _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
             _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
-                if (r || c) acc[c][r] = sad_u32(SCUR[r], (V).v[c], acc[c][r]); \
+                if (r || c) sad_u32_acc(SCUR[r], (V).v[c], acc[c][r]);         \
             }                                                                  \
         }                                                                      \
     }
 #define FF_FILL(BUF)                                                            \
-    _Pragma("unroll") for (int q = 0; q < KSTEP; ++q) {                        \
+    _Pragma("unroll") for (int q = 0; q < KS; ++q) {                        \
         BUF[q] = load_row<NC>(pv);                                             \
         pv += ld;                                                              \
     }
     const int sync_every = (item.flags & 2u) ? sync_trips : 0;
     int trips_left = sync_every;
-    for (int k = 0; k < nk; k += 2 * KSTEP) {
+    for (int k = 0; k < nk; k += 2 * KS) {
         // Items of a main round have the same length on all 8 waves of the workgroup
         // (flag bit 1): a barrier every few trips keeps them on the same rows, so the
         // older wave of each SIMD (which wins VALU arbitration) cannot run ahead and the
@@ -174,15 +180,15 @@ __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_
         }
         FF_STEP(sA, sB, vA[0], FF_FILL(vB))
 #pragma unroll
-        for (int d = 1; d < KSTEP; d += 2) {
+        for (int d = 1; d < KS; d += 2) {
             FF_STEP(sB, sA, vA[d], )
-            if (d + 1 < KSTEP) FF_STEP(sA, sB, vA[d + 1], )
+            if (d + 1 < KS) FF_STEP(sA, sB, vA[d + 1], )
         }
         FF_STEP(sA, sB, vB[0], FF_FILL(vA))
 #pragma unroll
-        for (int d = 1; d < KSTEP; d += 2) {
+        for (int d = 1; d < KS; d += 2) {
             FF_STEP(sB, sA, vB[d], )
-            if (d + 1 < KSTEP) FF_STEP(sA, sB, vB[d + 1], )
+            if (d + 1 < KS) FF_STEP(sA, sB, vB[d + 1], )
         }
     }
 #undef FF_STEP
@@ -233,6 +239,180 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
             run_item<2>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
         else
             run_item<4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
+    }
+    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
+// The same with half the vector buffers (2 x 4 rows): 168 VGPRs, three waves per SIMD.
+__global__ __launch_bounds__(L_WAVES_PER_WG * 64)
+void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
+                     const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
+                     uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                     int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * L_WAVES_PER_WG + wave;
+    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
+    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
+    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    for (int it = it_begin; it < it_end; ++it) {
+        const Item item = items[it];
+        if (item.flags & 4u)
+            run_item<2, 4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
+        else
+            run_item<4, 4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
+    }
+    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---- LDS-staged variant: three waves per SIMD ----------------------------------------------
+//
+// The register-buffered kernel above keeps 16 branch rows of its vector operand in 64 VGPRs,
+// which with the 128 accumulators allows two waves per SIMD.  Measured there (SQ counters):
+// a wave spends 45 % of its cycles issuing v_sad_u32, 28 % in s_waitcnt (the row's scalar
+// operands, an L2 round trip away) and the rest waiting for the other wave's turn; both waves
+// of a SIMD wait at once 9 % of the time, and that is the idle vector ALU.  A third wave fills
+// most of it, but only fits if the kernel stays under 168 VGPRs.  Here the vector rows travel
+// global -> LDS by LDS-DMA (no registers) into a ring of L_RING rows per wave, 7 rows ahead,
+// and come back one row ahead of their use with a single ds_read_b128: 8 VGPRs instead of 64.
+// Same tiles, same integers.
+template <int NC>
+__device__ __forceinline__ void run_item_lds(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
+                                             uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                                             int64_t slot_begin, int sync_trips, int lane,
+                                             uint32_t __attribute__((address_space(3))) *ring)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
+    typedef const void __attribute__((address_space(1))) *gptr;
+    typedef void __attribute__((address_space(3))) *lptr;
+    constexpr int ROW_WORDS = 64 * NC;          // one ring row: 256 (or 128) samples
+    constexpr int DMA_PER_ROW = NC == 4 ? 1 : 2;  // dwordx4 per lane, or two dwords
+    // per-lane source of row 0; NC == 2 has no 8-byte DMA: two dword pieces, lanes 0..63 | 64..127
+    const uint32_t *src = QT + (int64_t)item.k0 * ld + item.j0 + (NC == 4 ? 4 * lane : lane);
+    const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
+    uint32_t acc[NC][TILE_I];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
+    auto dma = [&](int slot_, const uint32_t *g) {  // one row from g into ring slot slot_
+        uint32_t __attribute__((address_space(3))) *dst = ring + slot_ * ROW_WORDS;
+        if constexpr (NC == 4) {
+            __builtin_amdgcn_global_load_lds((gptr)g, (lptr)dst, 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr)g, (lptr)dst, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(g + 64), (lptr)(dst + 64), 4, 0, 0);
+        }
+    };
+    auto fetch = [&](int slot_) -> RowVec<NC> {  // the lane's NC samples of a landed row
+        RowVec<NC> v;
+        const uint32_t __attribute__((address_space(3))) *p = ring + slot_ * ROW_WORDS + NC * lane;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (NC == 4) {  // one ds_read_b128
+            const u32x4 t = *(const u32x4 __attribute__((address_space(3))) *)p;
+            v.v[0] = t.x; v.v[1] = t.y; v.v[2] = t.z; v.v[3] = t.w;
+        } else {
+            const u32x2 t = *(const u32x2 __attribute__((address_space(3))) *)p;
+            v.v[0] = t.x; v.v[1] = t.y;
+        }
+        return v;
+    };
+    // the previous item's ring reads are complete (their values were consumed); start the ring
+    const uint32_t *pv = src;  // source of the next row to request; rows k..k+7 live in slots 0..7
+#pragma unroll
+    for (int q = 0; q < L_RING; ++q) {
+        dma(q, pv);
+        pv += ld;
+    }
+    uint32_t sA[TILE_I], sB[TILE_I];
+#pragma unroll
+    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
+    // row 0 has landed when at most the L_RING - 1 younger rows are still in flight
+    if constexpr (DMA_PER_ROW == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    RowVec<NC> vA = fetch(0), vB;
+    const int nk = item.k1 - item.k0;
+    // One step (row k + D, ring slot D): the row's vector (VCUR) and scalars (SCUR) are here.  First make sure the
+    // next row's DMA has landed and read it back (VNXT), request the next scalars (SNXT), and
+    // refill this row's ring slot -- its ds_read completed before the step began -- with
+    // the row L_RING ahead; then the 32 x NC v_sad_u32.
+#define FF_LSTEP(D, SCUR, SNXT, VCUR, VNXT)                                     \
+    {                                                                          \
+        sad_u32_acc(SCUR[0], (VCUR).v[0], acc[0][0]);                             \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        /* at most the DMAs of the 6 rows after row k+D+1 may still be in flight */ \
+        if constexpr (DMA_PER_ROW == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
+        VNXT = fetch(((D) + 1) % L_RING);                                      \
+        ps += ld;                                                              \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];    \
+        dma(D, pv);                                                            \
+        pv += ld;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
+                if (r || c) sad_u32_acc(SCUR[r], (VCUR).v[c], acc[c][r]);         \
+            }                                                                  \
+        }                                                                      \
+    }
+    const int sync_every = (item.flags & 2u) ? sync_trips : 0;
+    int trips_left = sync_every;
+    for (int k = 0; k < nk; k += L_RING) {
+        if (sync_every && --trips_left == 0) {
+            __builtin_amdgcn_s_barrier();
+            trips_left = sync_every;
+        }
+#pragma unroll
+        for (int d = 0; d < L_RING; d += 2) {
+            FF_LSTEP(d, sA, sB, vA, vB)
+            FF_LSTEP(d + 1, sB, sA, vB, vA)
+        }
+    }
+#undef FF_LSTEP
+    // drain: the ring still holds prefetched rows past k1 (slack rows of the matrix); nothing
+    // may overwrite a slot while its DMA is in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int64_t j = item.j0 + NC * lane;
+    const bool atomic = item.flags & 1u;
+#pragma unroll
+    for (int r = 0; r < TILE_I; ++r) {
+        const int64_t i = item.i0 + r;
+        if (i < row_begin || i >= row_end) continue;
+        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (j + c >= i) continue;
+            if (atomic) {
+                if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
+            } else {
+                num[base + c] = acc[c][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(L_WAVES_PER_WG * 64)
+void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
+                         const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
+                         uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                         int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
+{
+    extern __shared__ uint32_t lds_ring[];  // L_WAVES_PER_WG rings of L_RING KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * L_WAVES_PER_WG + wave;
+    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
+    uint32_t __attribute__((address_space(3))) *ring =
+        (uint32_t __attribute__((address_space(3))) *)lds_ring + wave * (L_RING * 256);
+    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    for (int it = it_begin; it < it_end; ++it) {
+        const Item item = items[it];
+        if (item.flags & 4u)
+            run_item_lds<2>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane, ring);
+        else
+            run_item_lds<4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane, ring);
     }
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -826,6 +1006,7 @@ struct ff_plan {
     Item *d_items = nullptr;
     int32_t *d_item_ptr = nullptr;
     int n_workgroups = 0;
+    int waves_per_wg = WAVES_PER_WG;
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
     int sync_trips = 0;                      // workgroup barrier every this many loop trips (0 = never)
@@ -1410,17 +1591,6 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         pl->sync_trips = env_int("FF_SYNC_TRIPS", 16);
         // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
         pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
-        const int U = pl->n_workgroups * WAVES_PER_WG;
-        inf.n_wave_slots = U;
-        std::vector<Item> items;
-        std::vector<int32_t> item_ptr;
-        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices());
-        inf.n_items = (int64_t)items.size();
-        FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
-        FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
-        if (!items.empty())
-            FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
-        FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
         // activity of every (i-block, branch row): decides between the dense and the
         // sparse-aware kernel
         if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
@@ -1471,13 +1641,35 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
             }
         }
+        // work schedule: 8 waves per workgroup for the register-buffered and the sparse-aware
+        // kernel, 12 for the LDS-staged one
+        pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
+        if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
+        const int U = pl->n_workgroups * pl->waves_per_wg;
+        inf.n_wave_slots = U;
+        std::vector<Item> items;
+        std::vector<int32_t> item_ptr;
+        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg);
+        inf.n_items = (int64_t)items.size();
+        FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
+        FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
+        if (!items.empty())
+            FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
         FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
         if (env_int("FF_STAMPS", 0)) {
             FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
             FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
         }
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+        if (pl->waves_per_wg == L_WAVES_PER_WG) {
+            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+        }
+        else
+            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     } else {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
         inf.ld = ld;
@@ -1572,7 +1764,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
                 pl->zero_row, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin);
         else if (inf.n_items > 0)
-            pair_sad_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
+            (pl->waves_per_wg == L_WAVES_PER_WG ? (env_int("FF_REG12", 0) ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
+                <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));

@@ -37,6 +37,15 @@ int xcd_slices()
     return v < 0 ? 0 : v;
 }
 
+// FF_WAVES_PER_WG: 12 = the pair kernel that stages its vector operand through LDS and so
+// fits three waves per SIMD; 8 = the register-buffered kernel with two.
+int waves_per_wg()
+{
+    const char *e = getenv("FF_WAVES_PER_WG");
+    const int v = e && *e ? atoi(e) : WAVES_PER_WG;
+    return v == L_WAVES_PER_WG ? L_WAVES_PER_WG : WAVES_PER_WG;
+}
+
 // Balances tiles over U persistent waves.
 //
 //  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
@@ -51,7 +60,7 @@ int xcd_slices()
 // Ranges that share a tile add their partial sums atomically; the sums are integers, so
 // the result does not depend on the order.
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
-                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds)
+                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw)
 {
     std::vector<Tile> wide, rest;
     for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
@@ -69,8 +78,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     };
     if (rows > 0) {
         int64_t done = 0;  // full-width tiles scheduled in main rounds
-        const int64_t n_wg = U / WAVES_PER_WG;
-        if (xcds > 1 && 8 % xcds == 0 && n_wg % 8 == 0 && T >= n_wg / xcds * WAVES_PER_WG &&
+        const int64_t n_wg = U / wpw;
+        if (xcds > 1 && 8 % xcds == 0 && n_wg % 8 == 0 && T >= n_wg / xcds * wpw &&
             rows >= (int64_t)xcds * 8 * KSTEP) {
             // Branch slices pinned to XCDs.  Workgroup g runs on XCD g mod 8 (round-robin
             // dispatch); every tile is cut into `xcds` (2, 4 or 8) equal branch ranges and range x
@@ -78,16 +87,16 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
             // sees 1/xcds of the staged rows and all its waves sweep that slice together.  A round
             // = 8 consecutive tiles per workgroup of ONE group's share, i.e. n_wg/xcds * 8 tiles.
             const int64_t gsz = 8 / xcds;  // XCDs per group
-            const int64_t per_round = n_wg / xcds * WAVES_PER_WG;
+            const int64_t per_round = n_wg / xcds * wpw;
             const int64_t part = round_up((rows + xcds - 1) / xcds, 2 * KSTEP);
             const int64_t rounds = T / per_round;
             for (int64_t r = 0; r < rounds; ++r)
                 for (int64_t q = 0; q < per_round; ++q) {
                     const Tile &t = wide[(size_t)(r * per_round + q)];
-                    const int64_t m = q / WAVES_PER_WG, w = q % WAVES_PER_WG;
+                    const int64_t m = q / wpw, w = q % wpw;
                     for (int64_t x = 0; x < xcds; ++x) {
                         const int64_t wg = 8 * (m / gsz) + x * gsz + (m % gsz);  // m-th workgroup of group x
-                        const int u = (int)(wg * WAVES_PER_WG + w);
+                        const int u = (int)(wg * wpw + w);
                         const size_t before = per[(size_t)u].size();
                         push(u, t, std::min(rows, x * part), std::min(rows, (x + 1) * part));
                         if (per[(size_t)u].size() > before) per[(size_t)u].back().flags |= 2u;
@@ -105,10 +114,12 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
             int64_t S = 1, per_round = 0;
             double best = 1e300;
             for (int64_t cand = 1; cand <= std::min<int64_t>(256, max_split); ++cand) {
-                const int64_t pr = std::min<int64_t>(U / cand, T) / WAVES_PER_WG * WAVES_PER_WG;
+                const int64_t pr = std::min<int64_t>(U / cand, T) / wpw * wpw;
                 if (pr <= 0) continue;
                 const int64_t rounds = T / pr, rem = T - rounds * pr;
-                const double est = (double)rounds / (double)cand +
+                // (an item also costs about 48 rows' worth of start-up and epilogue whatever its
+                // length, which is what keeps the split from growing without bound)
+                const double est = (double)rounds / (double)cand + (double)rounds * 48.0 / (double)rows +
                                    1.15 * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
                 if (est < best - 1e-9) {
                     best = est;
@@ -273,7 +284,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
         std::vector<Item> items;
         double elements = 0;
-        build_schedule(tiles, rows, n_cu * WAVES_PER_WG, &items, &ptr, &elements, xcd_slices());
+        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg());
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);

@@ -17,6 +17,8 @@ constexpr int TILE_J = 256;   // columns: 4 per lane (one 16-byte load per lane 
 constexpr int KSTEP = 8;      // branch rows per vector buffer; the loop body covers 2*KSTEP rows
 constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefetch
 constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
+constexpr int L_WAVES_PER_WG = 12;  // 768-thread workgroups of the LDS-staged pair kernel: three per SIMD
+constexpr int L_RING = 8;           // rows of its per-wave LDS ring (1 KiB each)
 constexpr int X_TILE_I = 16;  // EXACT64 tile: 16 rows x 64 columns per wave
 constexpr int X_TILE_J = 64;
 
@@ -65,7 +67,8 @@ struct Tile {
 int xcd_slices();
 void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles);
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std::vector<Item> *items,
-                    std::vector<int32_t> *item_ptr, double *elements, int xcds = 0);
+                    std::vector<int32_t> *item_ptr, double *elements, int xcds = 0, int wpw = WAVES_PER_WG);
+int waves_per_wg();
 // Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr);

@@ -556,6 +556,27 @@ def test_c4_c5_full_size_sampled_parity(name):
     assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
 
 
+@pytest.mark.parametrize("reg12", ["0", "1"])
+def test_three_waves_per_simd_kernels_give_the_same_integers(monkeypatch, reg12):
+    """FF_WAVES_PER_WG=12 selects the 768-thread variants of the pair kernel (vector rows
+    staged through an LDS ring, or FF_REG12=1: 4-row register buffers): other schedule,
+    other data path, same sums -- bit-identical distances, weighted and unweighted."""
+    nodes, ip, on, ft = synth_problem(900, 2500, 0.1, 77)
+    monkeypatch.setenv("FF_UNWEIGHTED_MFMA", "0")
+    base = [ff.unifrac_dists(nodes, w, precision="fixed32") for w in (True, False)]
+    monkeypatch.setenv("FF_WAVES_PER_WG", "12")
+    monkeypatch.setenv("FF_REG12", reg12)
+    for w, want in zip((True, False), base):
+        plan = ff.Plan(nodes, w, precision="fixed32")
+        assert plan.info.n_wave_slots % 12 == 0 and plan.info.kernel == 0
+        plan.close()
+        assert np.array_equal(ff.unifrac_dists(nodes, w, precision="fixed32"), want, equal_nan=True)
+        parts = np.full_like(want, np.nan)
+        for r in range(3):
+            ff.unifrac_dists(nodes, w, precision="fixed32", rank=r, world=3, out=parts)
+        assert np.array_equal(parts, want, equal_nan=True)
+
+
 def test_out_of_device_memory_is_an_error_not_a_crash():
     """600,000 samples = 1.8e11 pairs: the accumulators alone would take 720 GB.  The plan
     must fail with a message, free what it had staged, and leave the device usable."""
