@@ -45,7 +45,8 @@ class ff_plan_info(ctypes.Structure):
                 ("ld", c_int64), ("rows_padded", c_int64), ("row_begin", c_int64),
                 ("row_end", c_int64), ("slot_begin", c_int64), ("slot_end", c_int64),
                 ("n_tiles", c_int64), ("n_items", c_int64), ("n_wave_slots", c_int64),
-                ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32)]
+                ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32),
+                ("n_rows", c_int64)]
 
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
                 3: "pair_sad_sparse_kernel"}

@@ -62,6 +62,7 @@ __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
                                      const double *__restrict__ abnd,
                                      const double *__restrict__ branch_len,
                                      const uint32_t *__restrict__ klen, int weighted, int e,
+                                     const int32_t *__restrict__ row_of,  // branch id -> staged row (null: identity)
                                      uint32_t *__restrict__ QT, int64_t ld)
 {
     const int64_t s = blockIdx.x;
@@ -75,20 +76,29 @@ __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
         } else {
             q = klen[b];
         }
-        QT[(int64_t)b * ld + s] = q;
+        QT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = q;
     }
+}
+
+// Branch compaction: which branches carry a flat node of any sample.
+__global__ void mark_branches_kernel(const int32_t *__restrict__ branch_id, int64_t nnz, unsigned char *__restrict__ mark)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x)
+        mark[branch_id[t]] = 1;
 }
 
 // Stage EXACT64: the abundance itself (weighted) or 1.0 for presence (unweighted).
 __global__ void stage_exact64_kernel(const int64_t *__restrict__ indptr,
                                      const int32_t *__restrict__ branch_id,
                                      const double *__restrict__ abnd, int weighted,
-                                     double *__restrict__ DT, int64_t ld)
+                                     const int32_t *__restrict__ row_of, double *__restrict__ DT, int64_t ld)
 {
     const int64_t s = blockIdx.x;
     const int64_t b0 = indptr[s], b1 = indptr[s + 1];
-    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x)
-        DT[(int64_t)branch_id[t] * ld + s] = weighted ? abnd[t] : 1.0;
+    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x) {
+        const int32_t b = branch_id[t];
+        DT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = weighted ? abnd[t] : 1.0;
+    }
 }
 
 // W_s = sum_b q_s(b): grid (ld/64, row chunks), one column per lane.
@@ -617,15 +627,17 @@ typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 
 // P8 / K8 planes from the flat nodes: one workgroup per sample.
 __global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
-                                  const uint32_t *__restrict__ klen, int n_digits, int8_t *__restrict__ P8,
+                                  const uint32_t *__restrict__ klen, int n_digits,
+                                  const int32_t *__restrict__ row_of, int8_t *__restrict__ P8,
                                   int8_t *__restrict__ K8, int64_t ldb, int64_t plane,
                                   unsigned long long *__restrict__ W)
 {
     const int64_t s = blockIdx.x;
     unsigned long long w = 0;
     for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
-        const int32_t b = branch_id[t];
-        const uint32_t k = klen[b];
+        const int32_t b0 = branch_id[t];
+        const uint32_t k = klen[b0];
+        const int64_t b = row_of ? row_of[b0] : b0;
         P8[s * ldb + b] = 1;
         for (int d = 0; d < n_digits; ++d) K8[d * plane + s * ldb + b] = (int8_t)((k >> (7 * d)) & 127u);
         w += k;
@@ -1033,6 +1045,7 @@ struct ff_plan {
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
+    double *d_len_rows = nullptr;  // EXACT64 with compacted rows: treeDists by staged row
     XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
     // timing: one event pair per timed run since the last collect
@@ -1250,6 +1263,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_mitem_ptr);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
+    (void)hipFree(pl->d_len_rows);
     (void)hipFree(pl->d_xtiles);
     for (auto &e : pl->events) {
         (void)hipEventDestroy(e.first);
@@ -1466,12 +1480,45 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     int32_t *d_ids = pl->d_ids;
     double *d_abnd = pl->d_abnd, *d_len = pl->d_len;
 
+    // Branch compaction.  A branch no sample has a flat node on is a zero row of the staged
+    // matrix and adds |0 - 0| (or +0.0) to every pair: with a reference phylogeny much larger
+    // than what the samples cover, most rows are like that.  Rows are renumbered over the
+    // branches in use (ascending, so EXACT64 keeps the reference's order) when that drops
+    // at least a tenth of them.  R = staged rows.
+    int64_t R = B;
+    Scratch<int32_t> row_of;
+    std::vector<int32_t> h_row_of, branch_of_row;
+    if (env_int("FF_COMPACT", 1) != 0 && B > 0 && nnz > 0) {
+        Scratch<unsigned char> mark;
+        FF_HIP(mark.alloc((size_t)B));
+        FF_HIP(hipMemset(mark.p, 0, (size_t)B));
+        mark_branches_kernel<<<dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 20)), dim3(256)>>>(d_ids, nnz, mark.p);
+        FF_HIP(hipGetLastError());
+        std::vector<unsigned char> hm((size_t)B);
+        FF_HIP(hipMemcpy(hm.data(), mark.p, (size_t)B, hipMemcpyDeviceToHost));
+        int64_t used = 0;
+        for (unsigned char m : hm) used += m;
+        if (used * 10 <= B * 9) {
+            h_row_of.assign((size_t)B, 0);
+            branch_of_row.reserve((size_t)used);
+            for (int64_t b = 0; b < B; ++b)
+                if (hm[(size_t)b]) {
+                    h_row_of[(size_t)b] = (int32_t)branch_of_row.size();
+                    branch_of_row.push_back((int32_t)b);
+                }
+            R = used;
+            FF_HIP(row_of.alloc((size_t)B));
+            FF_HIP(hipMemcpy(row_of.p, h_row_of.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice));
+        }
+    }
+    inf.n_rows = R;
+
     Quant q;
     int prec = o->precision;
     // AUTO: problems small enough that the binary64 walk costs about a millisecond
     // get the reference's exact roundings (this covers all of the reference's own
     // test data); everything larger takes the 6x faster fixed-point path.
-    if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)B <= 4294967296.0)
+    if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)R <= 4294967296.0)
         prec = FF_PRECISION_EXACT64;
     if (prec != FF_PRECISION_EXACT64) {
         q = choose_quant(*c, weighted);
@@ -1500,7 +1547,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         pl->m_digits = digits;
         inf.n_digits = digits;
         const int64_t n8 = round_up(N, M_TILE_I);
-        const int64_t ldb = round_up(B, M_KSLAB);  // whole slabs
+        const int64_t ldb = round_up(R, M_KSLAB);  // whole slabs
         pl->m_ldb = ldb;
         pl->m_plane = n8 * ldb;
         inf.ld = n8;
@@ -1517,8 +1564,8 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         FF_HIP(klen.alloc((size_t)B));
         FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
         if (nnz > 0)
-            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, pl->d_P8, pl->d_K8,
-                                                                 ldb, pl->m_plane, pl->d_W);
+            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, row_of.p, pl->d_P8,
+                                                                 pl->d_K8, ldb, pl->m_plane, pl->d_W);
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());
         klen.release();
@@ -1543,7 +1590,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
         FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
     } else if (prec == FF_PRECISION_FIXED32) {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
-        const int64_t rows = round_up(B, 2 * KSTEP);
+        const int64_t rows = round_up(R, 2 * KSTEP);
         inf.ld = ld;
         inf.rows_padded = rows;
         inf.lengths_exact = weighted ? 0 : q.lengths_exact;
@@ -1563,7 +1610,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
             FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
             if (N > 0 && nnz > 0)
                 stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, klen.p,
-                                                                        weighted ? 1 : 0, e, pl->d_QT, ld);
+                                                                        weighted ? 1 : 0, e, row_of.p, pl->d_QT, ld);
             if (rows > 0) {
                 const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
                 dim3 grid((unsigned)(ld / 64), (unsigned)((rows + rpb - 1) / rpb));
@@ -1673,19 +1720,25 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     } else {
         const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
         inf.ld = ld;
-        inf.rows_padded = B;
-        const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(B, 1) * (size_t)ld;
+        inf.rows_padded = R;
+        const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(R, 1) * (size_t)ld;
         inf.staged_bytes = (double)dt_bytes;
         FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
         FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
         if (N > 0 && nnz > 0)
             stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,
-                                                                    pl->d_DT, ld);
+                                                                    row_of.p, pl->d_DT, ld);
         FF_HIP(hipGetLastError());
+        if (row_of.p) {  // the walk reads treeDists by staged row
+            std::vector<double> lr((size_t)R);
+            for (int64_t r = 0; r < R; ++r) lr[(size_t)r] = c->h_len[(size_t)branch_of_row[(size_t)r]];
+            FF_HIP(hipMalloc(&pl->d_len_rows, sizeof(double) * (size_t)R));
+            FF_HIP(hipMemcpy(pl->d_len_rows, lr.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice));
+        }
         std::vector<Tile> tiles;
         build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
         inf.n_tiles = inf.n_items = (int64_t)tiles.size();
-        inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)B;
+        inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)R;
         std::vector<XTile> xt(tiles.size());
         for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
         // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
@@ -1784,11 +1837,11 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
             if (pl->weighted)
                 pair_exact64_kernel<true><<<dim3(nb), dim3(256), 0, st>>>(
-                    pl->d_DT, inf.ld, pl->d_len, inf.n_branches, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
+                    pl->d_DT, inf.ld, pl->d_len_rows ? pl->d_len_rows : pl->d_len, inf.n_rows, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
                     inf.row_end, inf.slot_begin, d_out);
             else
                 pair_exact64_kernel<false><<<dim3(nb), dim3(256), 0, st>>>(
-                    pl->d_DT, inf.ld, pl->d_len, inf.n_branches, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
+                    pl->d_DT, inf.ld, pl->d_len_rows ? pl->d_len_rows : pl->d_len, inf.n_rows, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
                     inf.row_end, inf.slot_begin, d_out);
         }
         if (timed) FF_HIP(hipEventRecord(ev1, st));

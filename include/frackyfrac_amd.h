@@ -133,6 +133,8 @@ typedef struct ff_plan_info {
     double elements;          /* sum over items of tile pairs * branches = |a-b| terms issued */
     int32_t kernel;           /* ff_kernel: which kernel does the pair reduction              */
     int32_t n_digits;         /* FF_KERNEL_MFMA_I8: base-128 digits of the integer lengths    */
+    int64_t n_rows;           /* branches staged: n_branches, or only those some sample has a
+                                 flat node on when that drops a tenth of them (compaction)    */
 } ff_plan_info;
 
 typedef enum ff_kernel {

@@ -37,7 +37,7 @@ def test_struct_layouts():
     import ctypes
     assert ctypes.sizeof(L.ff_problem) == 48
     assert ctypes.sizeof(L.ff_options) == 32
-    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8
+    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8 + 8
 
 
 def test_frcfrc_binary_links_the_library():

@@ -577,6 +577,55 @@ def test_three_waves_per_simd_kernels_give_the_same_integers(monkeypatch, reg12)
         assert np.array_equal(parts, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch, weighted):
+    """A 20,000-leaf tree of which the samples touch 4 % of the leaves: only the branches
+    some sample has a flat node on are staged (ff_plan_info.n_rows), and every precision
+    and kernel gives what it gives without compaction -- and what the oracle gives."""
+    tree, ptr, idx, val = synth.make(260, 20000, 0.25, 808)
+    keep = np.zeros(tree.n if hasattr(tree, "n") else len(tree.names), dtype=bool)
+    leaves = np.flatnonzero(np.asarray(tree.size) == 1)
+    rng = np.random.default_rng(5)
+    keep[rng.choice(leaves, size=len(leaves) // 25, replace=False)] = True
+    rows = []
+    for s in range(len(ptr) - 1):
+        li, lv = idx[ptr[s]:ptr[s + 1]], val[ptr[s]:ptr[s + 1]]
+        m = keep[li]
+        rows.append((li[m], lv[m]))
+    rows[5] = (rows[5][0][:0], rows[5][1][:0])                     # and one empty sample
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx = np.concatenate([r[0] for r in rows])
+    val = np.concatenate([r[1] for r in rows])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=HOST_THREADS)
+    B = nodes.n_branches
+    for prec in ("fixed32", "exact64"):
+        for mfma in ("1", "0"):
+            monkeypatch.setenv("FF_UNWEIGHTED_MFMA", mfma)
+            monkeypatch.setenv("FF_COMPACT", "1")
+            plan = ff.Plan(nodes, weighted, precision=prec)
+            assert 0 < plan.info.n_rows < 0.5 * B and plan.info.rows_padded < 0.5 * B + 64
+            plan.close()
+            got = ff.unifrac_dists(nodes, weighted, precision=prec)
+            monkeypatch.setenv("FF_COMPACT", "0")
+            plan = ff.Plan(nodes, weighted, precision=prec)
+            assert plan.info.n_rows == B
+            plan.close()
+            assert np.array_equal(got, ff.unifrac_dists(nodes, weighted, precision=prec), equal_nan=True)
+            if prec == "exact64" or not weighted:
+                assert np.array_equal(got, want, equal_nan=True)
+            else:
+                assert rel_err(got, want) <= WEIGHTED_RTOL
+    # from leaves (stage A on the device) the same rows are staged
+    monkeypatch.setenv("FF_COMPACT", "1")
+    plan = ff.Plan.from_leaves(T, ptr, idx, val, weighted, precision="fixed32")
+    assert 0 < plan.info.n_rows < 0.5 * B
+    plan.close()
+
+
 def test_out_of_device_memory_is_an_error_not_a_crash():
     """600,000 samples = 1.8e11 pairs: the accumulators alone would take 720 GB.  The plan
     must fail with a message, free what it had staged, and leave the device usable."""
