@@ -835,6 +835,7 @@ __global__ void stage_a_fill_kernel(const double *__restrict__ S, int64_t ld, in
                                     int64_t n_samples, const int64_t *__restrict__ indptr,
                                     const double *__restrict__ divisor, int normalize,
                                     const double *__restrict__ branch_len,
+                                    const int32_t *__restrict__ node_of,  // row of S -> branch id (null: identity)
                                     int32_t *__restrict__ ids, double *__restrict__ abnd,
                                     double *__restrict__ weight)
 {
@@ -844,11 +845,12 @@ __global__ void stage_a_fill_kernel(const double *__restrict__ S, int64_t ld, in
     const double d = divisor[s];
     double w = 0.0;
 #pragma unroll 8
-    for (int64_t b = 0; b < n_branches; ++b) {
-        const double v = S[b * ld + s];
+    for (int64_t r = 0; r < n_branches; ++r) {
+        const double v = S[r * ld + s];
         if (v > 0) {
             const double x = normalize ? v / d : v;
-            ids[pos] = (int32_t)b;
+            const int32_t b = node_of ? node_of[r] : (int32_t)r;
+            ids[pos] = b;
             abnd[pos] = x;
             w += branch_len[b] * x;
             ++pos;
@@ -1344,26 +1346,73 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     c->N = N;
     c->B = B;
     c->h_len = t->dist;
+    const int64_t n_leafvals = leaf_ptr[N];
+    for (int64_t k = 0; k < n_leafvals; ++k)
+        if (leaf_idx[k] < 0 || leaf_idx[k] >= B)
+            return ff::fail(FF_ERR_ARG, err, errlen, "leaf index %lld out of range", (long long)leaf_idx[k]);
+    // The tree the sums run over: the whole tree, or -- when the samples touch less than 90 % of
+    // it -- the tree induced by the leaves that carry abundance and their ancestors (W nodes,
+    // pre-order kept; node_of[w] = original id).  An absent child adds +0.0 to its parent's sum,
+    // which changes no bit, so the flat nodes are the same; the dense S matrix is W x N
+    // instead of B x N.
+    std::vector<int32_t> node_of;   // empty: identity
+    std::vector<int64_t> w_parent, w_size, w_lidx;
+    const int64_t *parentP = t->parent.data(), *sizeP = t->size.data(), *lidxP = leaf_idx;
+    int64_t W = B;
+    if (env_int("FF_COMPACT", 1) != 0 && B > 1 && n_leafvals > 0) {
+        std::vector<unsigned char> used((size_t)B, 0);
+        for (int64_t k = 0; k < n_leafvals; ++k)
+            if (t->size[(size_t)leaf_idx[k]] == 1 && leaf_val[k] > 0) used[(size_t)leaf_idx[k]] = 1;
+        int64_t cnt = 0;
+        for (int64_t id = B - 1; id >= 1; --id)  // parent[id] < id
+            if (used[(size_t)id]) {
+                used[(size_t)t->parent[(size_t)id]] = 1;
+                ++cnt;
+            }
+        cnt += used[0];
+        if (cnt > 1 && cnt * 10 <= B * 9) {
+            W = cnt;
+            std::vector<int32_t> row_of((size_t)B, 0);
+            node_of.reserve((size_t)W);
+            for (int64_t id = 0; id < B; ++id)
+                if (used[(size_t)id]) {
+                    row_of[(size_t)id] = (int32_t)node_of.size();
+                    node_of.push_back((int32_t)id);
+                }
+            w_parent.assign((size_t)W, -1);
+            w_size.assign((size_t)W, 1);
+            for (int64_t w = 1; w < W; ++w) w_parent[(size_t)w] = row_of[(size_t)t->parent[(size_t)node_of[(size_t)w]]];
+            for (int64_t w = W - 1; w >= 1; --w) w_size[(size_t)w_parent[(size_t)w]] += w_size[(size_t)w];
+            // an entry that is not a leaf with abundance goes to the root, which is internal here
+            w_lidx.resize((size_t)n_leafvals);
+            for (int64_t k = 0; k < n_leafvals; ++k)
+                w_lidx[(size_t)k] = used[(size_t)leaf_idx[k]] && t->size[(size_t)leaf_idx[k]] == 1
+                                        ? row_of[(size_t)leaf_idx[k]] : 0;
+            parentP = w_parent.data();
+            sizeP = w_size.data();
+            lidxP = w_lidx.data();
+        }
+    }
     // levels: depth of every node; internal nodes grouped by level, deepest first
-    std::vector<int32_t> depth((size_t)B, 0);
+    std::vector<int32_t> depth((size_t)W, 0);
     int32_t max_depth = 0;
-    for (int64_t id = 1; id < B; ++id) {
-        depth[(size_t)id] = depth[(size_t)t->parent[(size_t)id]] + 1;
+    for (int64_t id = 1; id < W; ++id) {
+        depth[(size_t)id] = depth[(size_t)parentP[(size_t)id]] + 1;
         max_depth = std::max(max_depth, depth[(size_t)id]);
     }
     if (max_depth > 4096) {
         *too_deep = true;
         return FF_ERR_INTERNAL;
     }
-    std::vector<int64_t> child_ptr((size_t)B + 1, 0);
+    std::vector<int64_t> child_ptr((size_t)W + 1, 0);
     std::vector<int32_t> child_idx;
-    child_idx.reserve((size_t)B);
+    child_idx.reserve((size_t)W);
     std::vector<std::vector<int32_t>> by_level((size_t)max_depth + 1);
-    for (int64_t id = 0; id < B; ++id) {
-        const int64_t end = id + t->size[(size_t)id];
-        for (int64_t ch = id + 1; ch < end; ch += t->size[(size_t)ch]) child_idx.push_back((int32_t)ch);  // ascending
+    for (int64_t id = 0; id < W; ++id) {
+        const int64_t end = id + sizeP[(size_t)id];
+        for (int64_t ch = id + 1; ch < end; ch += sizeP[(size_t)ch]) child_idx.push_back((int32_t)ch);  // ascending
         child_ptr[(size_t)id + 1] = (int64_t)child_idx.size();
-        if (t->size[(size_t)id] > 1) by_level[(size_t)depth[(size_t)id]].push_back((int32_t)id);
+        if (sizeP[(size_t)id] > 1) by_level[(size_t)depth[(size_t)id]].push_back((int32_t)id);
     }
     std::vector<int32_t> order;
     std::vector<int> level_ptr{0};
@@ -1371,15 +1420,12 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
         order.insert(order.end(), by_level[(size_t)L].begin(), by_level[(size_t)L].end());
         level_ptr.push_back((int)order.size());
     }
-    const int64_t n_leafvals = leaf_ptr[N];
-    for (int64_t k = 0; k < n_leafvals; ++k)
-        if (leaf_idx[k] < 0 || leaf_idx[k] >= B)
-            return ff::fail(FF_ERR_ARG, err, errlen, "leaf index %lld out of range", (long long)leaf_idx[k]);
     const int64_t ld = round_up(std::max<int64_t>(N, 1), 64);
     double *d_S = nullptr, *d_lval = nullptr, *d_div = nullptr, *d_weight = nullptr;
     int64_t *d_lptr = nullptr, *d_lidx = nullptr, *d_size = nullptr, *d_cptr = nullptr, *d_count = nullptr;
-    int32_t *d_cidx = nullptr, *d_order = nullptr;
+    int32_t *d_cidx = nullptr, *d_order = nullptr, *d_node_of = nullptr;
     auto cleanup = [&] {
+        (void)hipFree(d_node_of);
         (void)hipFree(d_S); (void)hipFree(d_lval); (void)hipFree(d_div); (void)hipFree(d_weight);
         (void)hipFree(d_lptr); (void)hipFree(d_lidx); (void)hipFree(d_size); (void)hipFree(d_cptr);
         (void)hipFree(d_count); (void)hipFree(d_cidx); (void)hipFree(d_order);
@@ -1394,14 +1440,18 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
                             hipGetErrorString(e_));                                             \
         }                                                                                       \
     } while (0)
-    const size_t s_bytes = sizeof(double) * (size_t)std::max<int64_t>(B, 1) * (size_t)ld;
+    const size_t s_bytes = sizeof(double) * (size_t)std::max<int64_t>(W, 1) * (size_t)ld;
     FF_HIP_C(hipMalloc(&d_S, s_bytes));
     FF_HIP_C(hipMemset(d_S, 0, s_bytes));
     FF_HIP_C(hipMalloc(&d_lptr, sizeof(int64_t) * (size_t)(N + 1)));
     FF_HIP_C(hipMalloc(&d_lidx, sizeof(int64_t) * (size_t)std::max<int64_t>(n_leafvals, 1)));
     FF_HIP_C(hipMalloc(&d_lval, sizeof(double) * (size_t)std::max<int64_t>(n_leafvals, 1)));
-    FF_HIP_C(hipMalloc(&d_size, sizeof(int64_t) * (size_t)std::max<int64_t>(B, 1)));
-    FF_HIP_C(hipMalloc(&d_cptr, sizeof(int64_t) * (size_t)(B + 1)));
+    FF_HIP_C(hipMalloc(&d_size, sizeof(int64_t) * (size_t)std::max<int64_t>(W, 1)));
+    FF_HIP_C(hipMalloc(&d_cptr, sizeof(int64_t) * (size_t)(W + 1)));
+    if (!node_of.empty()) {
+        FF_HIP_C(hipMalloc(&d_node_of, sizeof(int32_t) * (size_t)W));
+        FF_HIP_C(hipMemcpy(d_node_of, node_of.data(), sizeof(int32_t) * (size_t)W, hipMemcpyHostToDevice));
+    }
     FF_HIP_C(hipMalloc(&d_cidx, sizeof(int32_t) * std::max<size_t>(child_idx.size(), 1)));
     FF_HIP_C(hipMalloc(&d_order, sizeof(int32_t) * std::max<size_t>(order.size(), 1)));
     FF_HIP_C(hipMalloc(&d_count, sizeof(int64_t) * (size_t)std::max<int64_t>(N, 1)));
@@ -1410,14 +1460,14 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     FF_HIP_C(hipMalloc(&c->d_len, sizeof(double) * (size_t)std::max<int64_t>(B, 1)));
     FF_HIP_C(hipMemcpy(d_lptr, leaf_ptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
     if (n_leafvals > 0) {
-        FF_HIP_C(hipMemcpy(d_lidx, leaf_idx, sizeof(int64_t) * (size_t)n_leafvals, hipMemcpyHostToDevice));
+        FF_HIP_C(hipMemcpy(d_lidx, lidxP, sizeof(int64_t) * (size_t)n_leafvals, hipMemcpyHostToDevice));
         FF_HIP_C(hipMemcpy(d_lval, leaf_val, sizeof(double) * (size_t)n_leafvals, hipMemcpyHostToDevice));
     }
     if (B > 0) {
-        FF_HIP_C(hipMemcpy(d_size, t->size.data(), sizeof(int64_t) * (size_t)B, hipMemcpyHostToDevice));
+        FF_HIP_C(hipMemcpy(d_size, sizeP, sizeof(int64_t) * (size_t)W, hipMemcpyHostToDevice));
         FF_HIP_C(hipMemcpy(c->d_len, t->dist.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice));
     }
-    FF_HIP_C(hipMemcpy(d_cptr, child_ptr.data(), sizeof(int64_t) * (size_t)(B + 1), hipMemcpyHostToDevice));
+    FF_HIP_C(hipMemcpy(d_cptr, child_ptr.data(), sizeof(int64_t) * (size_t)(W + 1), hipMemcpyHostToDevice));
     if (!child_idx.empty())
         FF_HIP_C(hipMemcpy(d_cidx, child_idx.data(), sizeof(int32_t) * child_idx.size(), hipMemcpyHostToDevice));
     if (!order.empty())
@@ -1435,7 +1485,7 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
                 b0 += chunk;
             }
         }
-        stage_a_count_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, B, N, d_count, d_div);
+        stage_a_count_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, W, N, d_count, d_div);
     }
     FF_HIP_C(hipGetLastError());
     std::vector<int64_t> cnt((size_t)N, 0);
@@ -1449,9 +1499,9 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     FF_HIP_C(hipMemcpy(c->d_indptr, c->h_indptr.data(), sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice));
     c->h_weight.assign((size_t)N, 0.0);
     if (N > 0 && B > 0) {
-        stage_a_fill_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, B, N, c->d_indptr, d_div,
-                                                                           normalize ? 1 : 0, c->d_len, c->d_ids,
-                                                                           c->d_abnd, d_weight);
+        stage_a_fill_kernel<<<dim3((unsigned)((N + 63) / 64)), dim3(64)>>>(d_S, ld, W, N, c->d_indptr, d_div,
+                                                                           normalize ? 1 : 0, c->d_len, d_node_of,
+                                                                           c->d_ids, c->d_abnd, d_weight);
         FF_HIP_C(hipGetLastError());
         FF_HIP_C(hipMemcpy(c->h_weight.data(), d_weight, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
     }

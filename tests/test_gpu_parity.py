@@ -619,11 +619,22 @@ def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch,
                 assert np.array_equal(got, want, equal_nan=True)
             else:
                 assert rel_err(got, want) <= WEIGHTED_RTOL
-    # from leaves (stage A on the device) the same rows are staged
+    # from leaves (stage A on the device, over the induced tree) the same rows are staged, and
+    # the flat nodes are bit for bit the host's -- an entry naming an internal node is ignored
     monkeypatch.setenv("FF_COMPACT", "1")
     plan = ff.Plan.from_leaves(T, ptr, idx, val, weighted, precision="fixed32")
     assert 0 < plan.info.n_rows < 0.5 * B
     plan.close()
+    internal = int(np.flatnonzero(np.asarray(tree.size) > 1)[7])
+    idx2 = np.concatenate([[internal], idx]).astype(np.int64)
+    val2 = np.concatenate([[3.0], val])
+    ptr2 = ptr.copy()
+    ptr2[1:] += 1
+    for unnorm in (False, True):
+        a = ff.flatten_device(T, ptr2, idx2, val2, leave_unnormalized=unnorm)
+        b = ff.flatten_leaf_csr(T, ptr, idx, val, leave_unnormalized=unnorm)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.branch_id, b.branch_id)
+        assert np.array_equal(a.abnd, b.abnd)
 
 
 def test_out_of_device_memory_is_an_error_not_a_crash():
