@@ -223,6 +223,17 @@ def main():
                         "kernel_ms": kernel_ms, "launches": launches, "digits": int(info.n_digits),
                         "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs),
                         "hbm": hbm}
+        elif info.kernel == 1:
+            # EXACT64: the reference's roundings need six unfused binary64 operations per branch and
+            # pair (numer: sub, mul by |.|, add; denom: add, mul, add; unifrac.go:191-192); the FP64
+            # vector rate is half the FP32 one (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s)
+            ops = 6.0 * B * shard_pairs
+            achieved_t = ops / (kernel_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu", "achieved": achieved_t, "peak": VALU_PEAK_TLANEOPS / 2, "unit": "T f64 op/s",
+                        "frac": achieved_t / (VALU_PEAK_TLANEOPS / 2), "traffic": traffic,
+                        "kernel": KERNEL_NAMES[1], "kernel_ms": kernel_ms, "launches": launches,
+                        "algorithmic": "6*B unfused binary64 ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs),
+                        "hbm": hbm}
         else:
             laneops = 2.0 * B * shard_pairs
             achieved_tl = laneops / (kernel_ms * 1e-3) / 1e12
