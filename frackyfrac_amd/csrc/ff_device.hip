@@ -39,969 +39,13 @@ namespace {
 using namespace ff::sched;
 
 // ----------------------------------------------------------------------------
-// Device code
+// Device code (kernels live in the ff_kernels_*.hpp fragments)
 // ----------------------------------------------------------------------------
-
-// D = |a - b| + c on 32-bit unsigned integers, `a` wave-uniform (SGPR).
-__device__ __forceinline__ uint32_t sad_u32(uint32_t s, uint32_t v, uint32_t acc)
-{
-    uint32_t r;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(acc));
-    return r;
-}
-
-// The same in place: the accumulator keeps its register (what a kernel with no VGPR to spare needs).
-__device__ __forceinline__ void sad_u32_acc(uint32_t s, uint32_t v, uint32_t &acc)
-{
-    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "s"(s), "v"(v));
-}
-
-// Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
-__global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
-                                     const int32_t *__restrict__ branch_id,
-                                     const double *__restrict__ abnd,
-                                     const double *__restrict__ branch_len,
-                                     const uint32_t *__restrict__ klen, int weighted, int e,
-                                     const int32_t *__restrict__ row_of,  // branch id -> staged row (null: identity)
-                                     uint32_t *__restrict__ QT, int64_t ld)
-{
-    const int64_t s = blockIdx.x;
-    const int64_t b0 = indptr[s], b1 = indptr[s + 1];
-    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x) {
-        const int32_t b = branch_id[t];
-        uint32_t q;
-        if (weighted) {
-            const double x = branch_len[b] * abnd[t];  // treeDists[id] * abnd (unifrac.go:180)
-            q = (uint32_t)(unsigned long long)rint(ldexp(x, e));
-        } else {
-            q = klen[b];
-        }
-        QT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = q;
-    }
-}
-
-// Branch compaction: which branches carry a flat node of any sample.
-__global__ void mark_branches_kernel(const int32_t *__restrict__ branch_id, int64_t nnz, unsigned char *__restrict__ mark)
-{
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x)
-        mark[branch_id[t]] = 1;
-}
-
-// Stage EXACT64: the abundance itself (weighted) or 1.0 for presence (unweighted).
-__global__ void stage_exact64_kernel(const int64_t *__restrict__ indptr,
-                                     const int32_t *__restrict__ branch_id,
-                                     const double *__restrict__ abnd, int weighted,
-                                     const int32_t *__restrict__ row_of, double *__restrict__ DT, int64_t ld)
-{
-    const int64_t s = blockIdx.x;
-    const int64_t b0 = indptr[s], b1 = indptr[s + 1];
-    for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x) {
-        const int32_t b = branch_id[t];
-        DT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = weighted ? abnd[t] : 1.0;
-    }
-}
-
-// W_s = sum_b q_s(b): grid (ld/64, row chunks), one column per lane.
-__global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
-                              int64_t rows_per_block, unsigned long long *__restrict__ W)
-{
-    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t r1 = min(rows, r0 + rows_per_block);
-    unsigned long long acc = 0;
-    for (int64_t r = r0; r < r1; ++r) acc += QT[r * ld + s];
-    if (acc) atomicAdd(&W[s], acc);
-}
-
-// NC 32-bit values per lane of one branch row: one 16-byte (NC = 4) or 8-byte (NC = 2) load.
-template <int NC> struct RowVec { uint32_t v[NC]; };
-template <int NC> __device__ __forceinline__ RowVec<NC> load_row(const uint32_t *p)
-{
-    RowVec<NC> r;
-    if constexpr (NC == 4) {
-        const uint4 t = *(const uint4 *)p;
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-    } else {
-        const uint2 t = *(const uint2 *)p;
-        r.v[0] = t.x; r.v[1] = t.y;
-    }
-    return r;
-}
-
-// One work item: a 32 x (64*NC) pair tile over the branch rows [k0, k1).
-template <int NC, int KS = KSTEP>
-__device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
-                                         uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                                         int64_t slot_begin, int sync_trips, int lane)
-{
-    const uint32_t *pj = QT + (int64_t)item.k0 * ld + item.j0 + NC * lane;
-    // constant address space: the staged matrix is read-only for the whole launch, and
-    // loads from it with a wave-uniform address become s_load (scalar cache) without
-    // depending on the compiler's clobber analysis
-    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-    const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
-    uint32_t acc[NC][TILE_I];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
-    // Two vector buffers of KSTEP rows each: while the rows of one are consumed the other
-    // is refilled in one burst, a full KSTEP steps ahead of its first use, so the loads
-    // still in flight at the loop's back edge are always old (the compiler drains vmcnt
-    // there).  The 32 scalars of the next row are fetched one step ahead into the idle
-    // one of two SGPR sets.
-    RowVec<NC> vA[KS], vB[KS];
-#pragma unroll
-    for (int d = 0; d < KS; ++d) vA[d] = load_row<NC>(pj + (int64_t)d * ld);
-    const uint32_t *pv = pj + (int64_t)KS * ld;
-    uint32_t sA[TILE_I], sB[TILE_I];
-#pragma unroll
-    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
-    const int nk = item.k1 - item.k0;
-#define FF_STEP(SCUR, SNXT, V, PREFETCH)                                        \
-    {                                                                          \
-        sad_u32_acc(SCUR[0], (V).v[0], acc[0][0]);                                \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        ps += ld;                                                              \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];    \
-        PREFETCH;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
-            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
-                if (r || c) sad_u32_acc(SCUR[r], (V).v[c], acc[c][r]);         \
-            }                                                                  \
-        }                                                                      \
-    }
-#define FF_FILL(BUF)                                                            \
-    _Pragma("unroll") for (int q = 0; q < KS; ++q) {                        \
-        BUF[q] = load_row<NC>(pv);                                             \
-        pv += ld;                                                              \
-    }
-    const int sync_every = (item.flags & 2u) ? sync_trips : 0;
-    int trips_left = sync_every;
-    for (int k = 0; k < nk; k += 2 * KS) {
-        // Items of a main round have the same length on all 8 waves of the workgroup
-        // (flag bit 1): a barrier every few trips keeps them on the same rows, so the
-        // older wave of each SIMD (which wins VALU arbitration) cannot run ahead and the
-        // vector rows the waves share stay hot in L1/L2.
-        if (sync_every && --trips_left == 0) {
-            __builtin_amdgcn_s_barrier();
-            trips_left = sync_every;
-        }
-        FF_STEP(sA, sB, vA[0], FF_FILL(vB))
-#pragma unroll
-        for (int d = 1; d < KS; d += 2) {
-            FF_STEP(sB, sA, vA[d], )
-            if (d + 1 < KS) FF_STEP(sA, sB, vA[d + 1], )
-        }
-        FF_STEP(sA, sB, vB[0], FF_FILL(vA))
-#pragma unroll
-        for (int d = 1; d < KS; d += 2) {
-            FF_STEP(sB, sA, vB[d], )
-            if (d + 1 < KS) FF_STEP(sA, sB, vB[d + 1], )
-        }
-    }
-#undef FF_STEP
-#undef FF_FILL
-    // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
-    const int64_t j = item.j0 + NC * lane;
-    const bool atomic = item.flags & 1u;
-#pragma unroll
-    for (int r = 0; r < TILE_I; ++r) {
-        const int64_t i = item.i0 + r;
-        if (i < row_begin || i >= row_end) continue;
-        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (j + c >= i) continue;
-            if (atomic) {
-                if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
-            } else {
-                num[base + c] = acc[c][r];
-            }
-        }
-    }
-}
-
-// The pair-tile reduction.  Persistent: wave slot w runs items[item_ptr[w] .. item_ptr[w+1]).
-// Per branch row a wave issues 1 coalesced 1-KiB vector load (4 samples per lane),
-// 2 scalar 64-B loads (32 samples, wave-uniform) and 128 v_sad_u32.  The tile shape
-// is set by the scalar path: it delivers a row's 32 operands about once per 500
-// cycles per wave, so each operand has to feed 4 lanes' worth of v_sad_u32 (16
-// cycles of SIMD time) for the vector ALU, not the scalar cache, to be the limit
-// (measured: 32x128 tiles 27 T, 32x256 tiles 34.7 T |a-b| terms/s).
-// Tiles that overhang the diagonal by more than half run as 32x128 (flag bit 2).
-__global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
-void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
-                     const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                     uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * WAVES_PER_WG + wave;
-    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
-    for (int it = it_begin; it < it_end; ++it) {
-        const Item item = items[it];
-        if (item.flags & 4u)
-            run_item<2>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
-        else
-            run_item<4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
-    }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
-}
-
-// The same with half the vector buffers (2 x 4 rows): 168 VGPRs, three waves per SIMD.
-__global__ __launch_bounds__(L_WAVES_PER_WG * 64)
-void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
-                     const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                     uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * L_WAVES_PER_WG + wave;
-    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
-    for (int it = it_begin; it < it_end; ++it) {
-        const Item item = items[it];
-        if (item.flags & 4u)
-            run_item<2, 4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
-        else
-            run_item<4, 4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane);
-    }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---- LDS-staged variant: three waves per SIMD ----------------------------------------------
-//
-// The register-buffered kernel above keeps 16 branch rows of its vector operand in 64 VGPRs,
-// which with the 128 accumulators allows two waves per SIMD.  Measured there (SQ counters):
-// a wave spends 45 % of its cycles issuing v_sad_u32, 28 % in s_waitcnt (the row's scalar
-// operands, an L2 round trip away) and the rest waiting for the other wave's turn; both waves
-// of a SIMD wait at once 9 % of the time, and that is the idle vector ALU.  A third wave fills
-// most of it, but only fits if the kernel stays under 168 VGPRs.  Here the vector rows travel
-// global -> LDS by LDS-DMA (no registers) into a ring of L_RING rows per wave, 7 rows ahead,
-// and come back one row ahead of their use with a single ds_read_b128: 8 VGPRs instead of 64.
-// Same tiles, same integers.
-template <int NC>
-__device__ __forceinline__ void run_item_lds(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
-                                             uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                                             int64_t slot_begin, int sync_trips, int lane,
-                                             uint32_t __attribute__((address_space(3))) *ring)
-{
-    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-    typedef const void __attribute__((address_space(1))) *gptr;
-    typedef void __attribute__((address_space(3))) *lptr;
-    constexpr int ROW_WORDS = 64 * NC;          // one ring row: 256 (or 128) samples
-    constexpr int DMA_PER_ROW = NC == 4 ? 1 : 2;  // dwordx4 per lane, or two dwords
-    // per-lane source of row 0; NC == 2 has no 8-byte DMA: two dword pieces, lanes 0..63 | 64..127
-    const uint32_t *src = QT + (int64_t)item.k0 * ld + item.j0 + (NC == 4 ? 4 * lane : lane);
-    const_u32_ptr ps = (const_u32_ptr)(QT + (int64_t)item.k0 * ld + item.i0);
-    uint32_t acc[NC][TILE_I];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
-    auto dma = [&](int slot_, const uint32_t *g) {  // one row from g into ring slot slot_
-        uint32_t __attribute__((address_space(3))) *dst = ring + slot_ * ROW_WORDS;
-        if constexpr (NC == 4) {
-            __builtin_amdgcn_global_load_lds((gptr)g, (lptr)dst, 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds((gptr)g, (lptr)dst, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(g + 64), (lptr)(dst + 64), 4, 0, 0);
-        }
-    };
-    auto fetch = [&](int slot_) -> RowVec<NC> {  // the lane's NC samples of a landed row
-        RowVec<NC> v;
-        const uint32_t __attribute__((address_space(3))) *p = ring + slot_ * ROW_WORDS + NC * lane;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        if constexpr (NC == 4) {  // one ds_read_b128
-            const u32x4 t = *(const u32x4 __attribute__((address_space(3))) *)p;
-            v.v[0] = t.x; v.v[1] = t.y; v.v[2] = t.z; v.v[3] = t.w;
-        } else {
-            const u32x2 t = *(const u32x2 __attribute__((address_space(3))) *)p;
-            v.v[0] = t.x; v.v[1] = t.y;
-        }
-        return v;
-    };
-    // the previous item's ring reads are complete (their values were consumed); start the ring
-    const uint32_t *pv = src;  // source of the next row to request; rows k..k+7 live in slots 0..7
-#pragma unroll
-    for (int q = 0; q < L_RING; ++q) {
-        dma(q, pv);
-        pv += ld;
-    }
-    uint32_t sA[TILE_I], sB[TILE_I];
-#pragma unroll
-    for (int r = 0; r < TILE_I; ++r) sA[r] = ps[r];
-    // row 0 has landed when at most the L_RING - 1 younger rows are still in flight
-    if constexpr (DMA_PER_ROW == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    RowVec<NC> vA = fetch(0), vB;
-    const int nk = item.k1 - item.k0;
-    // One step (row k + D, ring slot D): the row's vector (VCUR) and scalars (SCUR) are here.  First make sure the
-    // next row's DMA has landed and read it back (VNXT), request the next scalars (SNXT), and
-    // refill this row's ring slot -- its ds_read completed before the step began -- with
-    // the row L_RING ahead; then the 32 x NC v_sad_u32.
-#define FF_LSTEP(D, SCUR, SNXT, VCUR, VNXT)                                     \
-    {                                                                          \
-        sad_u32_acc(SCUR[0], (VCUR).v[0], acc[0][0]);                             \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        /* at most the DMAs of the 6 rows after row k+D+1 may still be in flight */ \
-        if constexpr (DMA_PER_ROW == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
-        VNXT = fetch(((D) + 1) % L_RING);                                      \
-        ps += ld;                                                              \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = ps[r];    \
-        dma(D, pv);                                                            \
-        pv += ld;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
-            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
-                if (r || c) sad_u32_acc(SCUR[r], (VCUR).v[c], acc[c][r]);         \
-            }                                                                  \
-        }                                                                      \
-    }
-    const int sync_every = (item.flags & 2u) ? sync_trips : 0;
-    int trips_left = sync_every;
-    for (int k = 0; k < nk; k += L_RING) {
-        if (sync_every && --trips_left == 0) {
-            __builtin_amdgcn_s_barrier();
-            trips_left = sync_every;
-        }
-#pragma unroll
-        for (int d = 0; d < L_RING; d += 2) {
-            FF_LSTEP(d, sA, sB, vA, vB)
-            FF_LSTEP(d + 1, sB, sA, vB, vA)
-        }
-    }
-#undef FF_LSTEP
-    // drain: the ring still holds prefetched rows past k1 (slack rows of the matrix); nothing
-    // may overwrite a slot while its DMA is in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int64_t j = item.j0 + NC * lane;
-    const bool atomic = item.flags & 1u;
-#pragma unroll
-    for (int r = 0; r < TILE_I; ++r) {
-        const int64_t i = item.i0 + r;
-        if (i < row_begin || i >= row_end) continue;
-        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (j + c >= i) continue;
-            if (atomic) {
-                if (acc[c][r]) atomicAdd(&num[base + c], acc[c][r]);
-            } else {
-                num[base + c] = acc[c][r];
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(L_WAVES_PER_WG * 64)
-void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
-                         const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                         uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                         int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
-{
-    extern __shared__ uint32_t lds_ring[];  // L_WAVES_PER_WG rings of L_RING KiB
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * L_WAVES_PER_WG + wave;
-    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    uint32_t __attribute__((address_space(3))) *ring =
-        (uint32_t __attribute__((address_space(3))) *)lds_ring + wave * (L_RING * 256);
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
-    for (int it = it_begin; it < it_end; ++it) {
-        const Item item = items[it];
-        if (item.flags & 4u)
-            run_item_lds<2>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane, ring);
-        else
-            run_item_lds<4>(QT, ld, item, num, row_begin, row_end, slot_begin, sync_trips, lane, ring);
-    }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---- Sparse-aware variant of the pair-tile reduction ----------------------------------
-//
-// A branch row on which none of a tile's 32 i-samples has a flat node ("inactive" for that
-// i-block) contributes |0 - q_j| = q_j to each of the tile's sums, whatever the row of the
-// tile.  The wave therefore walks only the ACTIVE rows of its i-block (a precomputed list
-// of row numbers), and accounts for the others in closed form:
-//     U(i,j) = sum_{b active} |q_i(b) - q_j(b)|  +  R_j - sum_{b active} q_j(b),
-// R_j = sum of column j over the item's branch range, from prefix sums kept every 16 rows.
-// Same integers, same results.  At 10 % leaf density 2 % of the (i-block, row) cells are
-// inactive, at 5 % 10 %, at 1 % 51 %, at 0.2 % 82 %: the plan picks this kernel
-// when at least FF_SPARSE_MIN (default 28 %) are.  Rows past the end of the list are replaced by a
-// zero slack row (|0 - 0| = 0), so the loop has no tail and no branches.
-template <int NC>
-__device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
-                                                const uint32_t *__restrict__ arows,
-                                                const uint32_t *__restrict__ aptr16, int64_t aptr_stride,
-                                                const uint32_t *__restrict__ cs16, int32_t zero_row,
-                                                uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                                                int64_t slot_begin, int lane)
-{
-    typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
-    const int64_t ib = item.i0 / TILE_I;
-    const_u32_ptr pp = (const_u32_ptr)(aptr16 + ib * aptr_stride);
-    const uint32_t a0 = pp[item.k0 / (2 * KSTEP)], a1 = pp[item.k1 / (2 * KSTEP)];
-    const_u32_ptr pr = (const_u32_ptr)arows;
-    const uint32_t *colj = QT + item.j0 + NC * lane;          // per-lane column base
-    const_u32_ptr coli = (const_u32_ptr)(QT + item.i0);      // wave-uniform column base
-    uint32_t acc[NC][TILE_I], z[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        z[c] = 0;
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) acc[c][r] = 0;
-    }
-    // Row numbers travel in batches of four, two batches ahead of their use, so that the
-    // operand loads never wait on a load of their own address (the list is padded with 8
-    // spare entries; positions past the item's segment read the zero slack row instead).
-    auto batch = [&](uint32_t pos) -> uint4 {
-        const_u32_ptr p4 = pr + pos;  // four adjacent scalar loads (one s_load_dwordx4)
-        uint4 b;
-        b.x = p4[0];
-        b.y = p4[1];
-        b.z = p4[2];
-        b.w = p4[3];
-        return b;
-    };
-    auto pick = [&](const uint4 &c, const uint4 &n, int o, uint32_t pos) -> int64_t {
-        // entry o (0..7) of the two batches {c, n}; position `pos` decides whether it is real
-        const uint32_t r = o == 0 ? c.x : o == 1 ? c.y : o == 2 ? c.z : o == 3 ? c.w
-                         : o == 4 ? n.x : o == 5 ? n.y : o == 6 ? n.z : n.w;
-        return pos < a1 ? (int64_t)r : (int64_t)zero_row;
-    };
-    uint4 cur = batch(a0), nxt = batch(a0 + 4);
-    // vector ring of 4 active rows, scalars double-buffered one active row ahead
-    RowVec<NC> v[4];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) v[q] = load_row<NC>(colj + pick(cur, nxt, q, a0 + q) * ld);
-    uint32_t sA[TILE_I], sB[TILE_I];
-    {
-        const_u32_ptr p0 = coli + pick(cur, nxt, 0, a0) * ld;
-#pragma unroll
-        for (int r = 0; r < TILE_I; ++r) sA[r] = p0[r];
-    }
-#define FF_ASTEP(Q, SCUR, SNXT)                                                  \
-    {                                                                          \
-        acc[0][0] = sad_u32(SCUR[0], v[Q].v[0], acc[0][0]);                    \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        {                                                                      \
-            const_u32_ptr pn = coli + pick(cur, nxt, (Q) + 1, t + (Q) + 1) * ld; \
-            _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) SNXT[r] = pn[r]; \
-            v[((Q) + 3) & 3] = load_row<NC>(colj + pick(cur, nxt, (Q) + 3, t + (Q) + 3) * ld); \
-        }                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-        _Pragma("unroll") for (int r = 0; r < TILE_I; ++r) {                   \
-            _Pragma("unroll") for (int c = 0; c < NC; ++c) {                   \
-                if (r || c) acc[c][r] = sad_u32(SCUR[r], v[Q].v[c], acc[c][r]); \
-            }                                                                  \
-        }                                                                      \
-        _Pragma("unroll") for (int c = 0; c < NC; ++c) z[c] += v[Q].v[c];      \
-    }
-    for (uint32_t t = a0; t < a1; t += 4) {
-        const uint4 nn = batch(t + 8);
-        FF_ASTEP(0, sA, sB)
-        FF_ASTEP(1, sB, sA)
-        FF_ASTEP(2, sA, sB)
-        FF_ASTEP(3, sB, sA)
-        cur = nxt;
-        nxt = nn;
-    }
-#undef FF_ASTEP
-    // R_j over [k0, k1) from the 16-row prefix sums
-    const int64_t j = item.j0 + NC * lane;
-    uint32_t rj[NC];
-    {
-        const RowVec<NC> hi = load_row<NC>(cs16 + (int64_t)(item.k1 / (2 * KSTEP)) * ld + j);
-        const RowVec<NC> lo = load_row<NC>(cs16 + (int64_t)(item.k0 / (2 * KSTEP)) * ld + j);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) rj[c] = hi.v[c] - lo.v[c] - z[c];
-    }
-    const bool atomic = item.flags & 1u;
-#pragma unroll
-    for (int r = 0; r < TILE_I; ++r) {
-        const int64_t i = item.i0 + r;
-        if (i < row_begin || i >= row_end) continue;
-        const int64_t base = i * (i - 1) / 2 - slot_begin + j;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (j + c >= i) continue;
-            const uint32_t val = acc[c][r] + rj[c];
-            if (atomic) {
-                if (val) atomicAdd(&num[base + c], val);
-            } else {
-                num[base + c] = val;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
-void pair_sad_sparse_kernel(const uint32_t *__restrict__ QT, int64_t ld,
-                            const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                            const uint32_t *__restrict__ arows, const uint32_t *__restrict__ aptr16,
-                            int64_t aptr_stride, const uint32_t *__restrict__ cs16, int32_t zero_row,
-                            uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                            int64_t slot_begin)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * WAVES_PER_WG + wave;
-    const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    for (int it = it_begin; it < it_end; ++it) {
-        const Item item = items[it];
-        if (item.flags & 4u)
-            run_item_sparse<2>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
-                               slot_begin, lane);
-        else
-            run_item_sparse<4>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
-                               slot_begin, lane);
-    }
-}
-
-// cs16[t][s] = sum of column s over the rows [0, 16 t): one column per lane, sequential over rows.
-__global__ void prefix16_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
-                                uint32_t *__restrict__ cs16)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ld) return;
-    uint32_t run = 0;
-    cs16[s] = 0;
-    for (int64_t r = 0; r < rows; ++r) {
-        run += QT[r * ld + s];
-        if ((r & 15) == 15) cs16[((r >> 4) + 1) * ld + s] = run;
-    }
-}
-
-// act64[iblock][w] bit r: branch row 64 w + r has a non-zero value among the 32 samples of
-// i-block `iblock`.  One wave per (i-block, 64 rows), lane = row.
-__global__ void build_activity_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows, int64_t words,
-                                      unsigned long long *__restrict__ act64)
-{
-    const int64_t w = blockIdx.x, iblock = blockIdx.y;
-    const int64_t row = w * 64 + threadIdx.x;
-    uint32_t any = 0;
-    if (row < rows) {
-        const uint4 *p = (const uint4 *)(QT + row * ld + iblock * TILE_I);
-#pragma unroll
-        for (int q = 0; q < TILE_I / 4; ++q) {
-            const uint4 t = p[q];
-            any |= t.x | t.y | t.z | t.w;
-        }
-    }
-    const unsigned long long mask = __ballot(any != 0);
-    if (threadIdx.x == 0) act64[iblock * words + w] = mask;
-}
-
-__device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj)
-{
-    int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
-    while (i * (i - 1) / 2 > k) --i;
-    while ((i + 1) * i / 2 <= k) ++i;
-    *pi = i;
-    *pj = k - i * (i - 1) / 2;
-}
-
-// ---- Unweighted on the matrix cores -------------------------------------------------
-//
-// common(i,j) = sum_b k_b u_i(b) u_j(b) (unifrac.go:159) IS a contraction: with the
-// presence bits P[s][b] (int8 0/1) and the integer branch lengths cut into base-128 digits
-// K_d[s][b] = digit_d(k_b) * P[s][b] (int8 0..127), common = sum_d 128^d * (P . K_d^T), an
-// int8 GEMM with exact int32 accumulation (v_mfma_i32_32x32x32_i8).  The distance then
-// follows from U = W_i + W_j - 2*common exactly as on the v_sad_u32 path, so the results
-// are identical bit for bit; only the unit that does the work changes.  Both operands are
-// sample-major (a lane's 16 consecutive branches are one 16-byte load), staged through
-// LDS in 128 x 64-byte slabs with a padded 80-byte row stride (conflict-free ds_read_b128).
-
-typedef int mfma_v4i __attribute__((ext_vector_type(4)));
-typedef int mfma_v16i __attribute__((ext_vector_type(16)));
-
-// P8 / K8 planes from the flat nodes: one workgroup per sample.
-__global__ void stage_mfma_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
-                                  const uint32_t *__restrict__ klen, int n_digits,
-                                  const int32_t *__restrict__ row_of, int8_t *__restrict__ P8,
-                                  int8_t *__restrict__ K8, int64_t ldb, int64_t plane,
-                                  unsigned long long *__restrict__ W)
-{
-    const int64_t s = blockIdx.x;
-    unsigned long long w = 0;
-    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
-        const int32_t b0 = branch_id[t];
-        const uint32_t k = klen[b0];
-        const int64_t b = row_of ? row_of[b0] : b0;
-        P8[s * ldb + b] = 1;
-        for (int d = 0; d < n_digits; ++d) K8[d * plane + s * ldb + b] = (int8_t)((k >> (7 * d)) & 127u);
-        w += k;
-    }
-    // W_s = sum of the sample's integer branch lengths (what colsum_kernel gives the SAD path)
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
-}
-
-// Persistent: workgroup g runs items[item_ptr[g] .. item_ptr[g+1]).
-//
-// Operand slabs go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
-// ds_write), three slabs ahead of the multiply, into a ring of four 32-KiB stages; each
-// wave issues four 1-KiB pieces per slab.  One raw s_barrier per slab: behind it every
-// wave's pieces of slab S have landed (each wave first waits on its own vmcnt) and every
-// wave is done reading slab S-1, whose stage the pieces of slab S+3 may now overwrite.
-// LDS rows are 64 bytes, unpadded (the DMA writes linearly); a 16-byte chunk c of row r sits
-// in slot c ^ ((r >> 2) & 3), applied on the global source address of the DMA and again on
-// the fragment reads, which makes the 16-lane ds_read_b128 groups conflict-free.
-__device__ __forceinline__ void mfma_wait_vmcnt(int pieces_in_flight_allowed)
-{
-    if (pieces_in_flight_allowed >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (pieces_in_flight_allowed >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__global__ __launch_bounds__(512, 2)
-void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
-                             int64_t plane, const MItem *__restrict__ items,
-                             const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
-                             uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                             int64_t slot_begin)
-{
-    extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
-    const int it_begin = item_ptr[blockIdx.x], it_end = item_ptr[blockIdx.x + 1];
-    // fragment read offsets inside a stage (bytes), per m / n tile and k step, swizzled
-    const int arow = wi * 64 + (lane & 31), brow = M_TILE_I + wj * 64 + (lane & 31);
-    for (int it = it_begin; it < it_end; ++it) {
-        const MItem item = items[it];
-        const int nd = item.nd;
-        // this wave's four DMA pieces per slab: piece q covers stage rows (4 * wave + q) * 16 .. +16;
-        // lane l moves row + l / 4, slot l % 4, i.e. source chunk (l % 4) ^ ((row >> 2) & 3)
-        const int8_t *src[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = (4 * wave + q) * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-            const int8_t *base;
-            if (row < M_TILE_I) base = P8 + (int64_t)(item.i0 + row) * ldb;
-            else {
-                const int p = (row - M_TILE_I) / M_TILE_J, jr = (row - M_TILE_I) % M_TILE_J;
-                base = K8 + (int64_t)(item.d0 + (p < nd ? p : 0)) * plane + (int64_t)(item.j0 + jr) * ldb;
-            }
-            src[q] = base + item.k0 + chunk * 16;
-        }
-        mfma_v16i acc[M_ND][2][2];
-#pragma unroll
-        for (int d = 0; d < M_ND; ++d)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
-        const int nslab = (item.k1 - item.k0) / M_KSLAB;
-        // previous item: its atomics are out of vmcnt, and every wave is done with the ring
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        auto issue = [&](int slab) {
-            int8_t *dst = mfma_lds + (slab % M_STAGES) * M_STAGE + (4 * wave) * 16 * M_KSLAB;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src[q] + (int64_t)slab * M_KSLAB),
-                                                 (void __attribute__((address_space(3))) *)(dst + q * 16 * M_KSLAB), 16, 0, 0);
-        };
-        for (int p = 0; p < 3 && p < nslab; ++p) issue(p);
-        for (int sl = 0; sl < nslab; ++sl) {
-            // pieces of later slabs this wave already has in flight: min(nslab - 1 - sl, 2) * 4
-            const int later = nslab - 1 - sl;
-            mfma_wait_vmcnt(later >= 2 ? 8 : later * 4);
-            __builtin_amdgcn_s_barrier();
-            if (sl + 3 < nslab) issue(sl + 3);
-            const int8_t *st = mfma_lds + (sl % M_STAGES) * M_STAGE;
-#pragma unroll
-            for (int kt = 0; kt < M_KSLAB / 32; ++kt) {
-                const int c = 2 * kt + (lane >> 5);
-                mfma_v4i a[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int r = arow + m * 32;
-                    a[m] = *(const mfma_v4i *)(st + r * M_KSLAB + ((c ^ ((r >> 2) & 3)) << 4));
-                }
-#pragma unroll
-                for (int d = 0; d < M_ND; ++d) {
-                    mfma_v4i b[2];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int r = brow + d * M_TILE_J + n * 32;
-                        b[n] = *(const mfma_v4i *)(st + r * M_KSLAB + ((c ^ ((r >> 2) & 3)) << 4));
-                    }
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[d][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[d][m][n], 0, 0, 0);
-                }
-            }
-        }
-        // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i = item.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i < row_begin || i >= row_end) continue;
-                const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int64_t j = item.j0 + wj * 64 + n * 32 + (lane & 31);
-                    if (j >= i) continue;
-                    uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
-                    if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
-                    // this item's share of result = W_i + W_j - 2 * common, modulo 2^32
-                    const uint32_t v = wi_ + (item.first ? (uint32_t)W[j] : 0u) - 2u * common;
-                    if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
-                }
-            }
-    }
-}
-
-// ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
-//
-// S[b][s] (binary64, branch-major) starts as the leaf values.  Internal nodes are then
-// filled level by level from the deepest level up; a node adds its children's sums in
-// ascending child order, which is the order of the reference's recursion (:35-37), so
-// every sum carries the reference's roundings.
-
-__global__ void stage_a_scatter_kernel(const int64_t *__restrict__ leaf_ptr,
-                                       const int64_t *__restrict__ leaf_idx,
-                                       const double *__restrict__ leaf_val,
-                                       const int64_t *__restrict__ size, double *__restrict__ S,
-                                       int64_t ld)
-{
-    const int64_t s = blockIdx.x;
-    for (int64_t t = leaf_ptr[s] + threadIdx.x; t < leaf_ptr[s + 1]; t += blockDim.x) {
-        const int64_t id = leaf_idx[t];
-        const double a = leaf_val[t];
-        if (size[id] == 1 && a > 0) S[id * ld + s] = a;  // leaves only, if a > 0 (:39-42)
-    }
-}
-
-// One tree level: nodes[level_begin .. level_end) are the internal nodes of that level.
-__global__ void stage_a_level_kernel(const int32_t *__restrict__ nodes, int level_begin, int level_end,
-                                     const int64_t *__restrict__ child_ptr,
-                                     const int32_t *__restrict__ child_idx, double *__restrict__ S,
-                                     int64_t ld, int64_t n_samples)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = level_begin + blockIdx.y;
-    if (s >= n_samples || n >= level_end) return;
-    const int32_t id = nodes[n];
-    double sum = 0.0;
-    for (int64_t c = child_ptr[id]; c < child_ptr[id + 1]; ++c) sum += S[(int64_t)child_idx[c] * ld + s];
-    S[(int64_t)id * ld + s] = sum;
-}
-
-// Per sample: number of flat nodes (sum > 0, :49) and normalizeFlatNodes' divisor: the sum
-// of ALL flat-node abundances in ascending id (:60-63).
-__global__ void stage_a_count_kernel(const double *__restrict__ S, int64_t ld, int64_t n_branches,
-                                     int64_t n_samples, int64_t *__restrict__ count,
-                                     double *__restrict__ divisor)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_samples) return;
-    double total = 0.0;
-    int64_t k = 0;
-#pragma unroll 8
-    for (int64_t b = 0; b < n_branches; ++b) {
-        const double v = S[b * ld + s];
-        if (v > 0) {
-            total += v;
-            ++k;
-        }
-    }
-    count[s] = k;
-    divisor[s] = total;
-}
-
-// Dense sums -> CSR flat nodes in ascending id, normalised (:64-66) unless -l; also the
-// sample's weight sum_b l_b * x_s(b), which only steers the choice of the fixed-point scale.
-__global__ void stage_a_fill_kernel(const double *__restrict__ S, int64_t ld, int64_t n_branches,
-                                    int64_t n_samples, const int64_t *__restrict__ indptr,
-                                    const double *__restrict__ divisor, int normalize,
-                                    const double *__restrict__ branch_len,
-                                    const int32_t *__restrict__ node_of,  // row of S -> branch id (null: identity)
-                                    int32_t *__restrict__ ids, double *__restrict__ abnd,
-                                    double *__restrict__ weight)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_samples) return;
-    int64_t pos = indptr[s];
-    const double d = divisor[s];
-    double w = 0.0;
-#pragma unroll 8
-    for (int64_t r = 0; r < n_branches; ++r) {
-        const double v = S[r * ld + s];
-        if (v > 0) {
-            const double x = normalize ? v / d : v;
-            const int32_t b = node_of ? node_of[r] : (int32_t)r;
-            ids[pos] = b;
-            abnd[pos] = x;
-            w += branch_len[b] * x;
-            ++pos;
-        }
-    }
-    weight[s] = w;
-}
-
-// Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
-//
-// Rounding every staged value to an integer leaves U with an error of about
-// sqrt((k_i + k_j) / 12) units (k = flat nodes of the sample).  Where U is so small
-// that this could exceed REFINE_REL of U -- nearly identical samples -- the pair is
-// queued for refine_exact_kernel, which recomputes it with the reference's own
-// binary64 merge walk; all other pairs already meet the tolerance.
-constexpr double REFINE_REL = 0.5e-6;   // half of the 1e-6 relative bar of BASELINE.json
-constexpr double REFINE_SIGMAS = 6.0;
-
-__global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
-                                      const unsigned long long *__restrict__ W, int weighted,
-                                      int64_t slot_begin, int64_t n_slots,
-                                      double *__restrict__ out,
-                                      const int64_t *__restrict__ indptr,  // null: no refinement
-                                      unsigned long long *__restrict__ refine_list,
-                                      unsigned long long *__restrict__ refine_count,
-                                      unsigned long long refine_cap)
-{
-    // grid-stride: a launch carries at most 2^32 - 1 threads, a shard can have more slots
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots;
-         t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i, j;
-        slot_to_pair(slot_begin + t, &i, &j);
-        const unsigned long long u = num[t];
-        const unsigned long long w = W[i] + W[j];
-        double d;
-        if (weighted) {
-            d = (double)u / (double)w;                 // numer / denom
-        } else {
-            const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
-            d = (double)u / (double)(u + common);      // result / (result + common)
-        }
-        out[t] = d;
-        if (indptr && w != 0) {
-            const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
-            const double err = REFINE_SIGMAS * sqrt(k * (1.0 / 12.0)) + 1.0;
-            if ((double)u * REFINE_REL < err) {
-                const unsigned long long at = atomicAdd(refine_count, 1ull);
-                if (at < refine_cap) refine_list[at] = (unsigned long long)t;
-            }
-        }
-    }
-}
-
-// The reference's merge walk (unifrac.go:144-205) for the queued pairs, one thread per
-// pair, in binary64 and in the reference's order: bit-for-bit the reference's value.
-__global__ void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,
-                                    const unsigned long long *__restrict__ refine_count,
-                                    unsigned long long refine_cap,
-                                    const int64_t *__restrict__ indptr,
-                                    const int32_t *__restrict__ branch_id,
-                                    const double *__restrict__ abnd,
-                                    const double *__restrict__ tree_dists, int weighted,
-                                    int64_t slot_begin, double *__restrict__ out)
-{
-    unsigned long long n = *refine_count;
-    if (n > refine_cap) n = refine_cap;
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n;
-         q += (unsigned long long)gridDim.x * blockDim.x) {
-        const int64_t t = (int64_t)refine_list[q];
-        int64_t si, sj;
-        slot_to_pair(slot_begin + t, &si, &sj);
-        int64_t i = indptr[si], ie = indptr[si + 1];  // a = sample i (the higher index)
-        int64_t j = indptr[sj], je = indptr[sj + 1];  // b = sample j
-        double x = 0.0, y = 0.0;                      // numer/denom or result/common
-        while (i < ie && j < je) {
-            const int32_t ia = branch_id[i], ib = branch_id[j];
-            if (ia < ib) {
-                const double l = tree_dists[ia];
-                if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
-                ++i;
-            } else if (ia > ib) {
-                const double l = tree_dists[ib];
-                if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
-                ++j;
-            } else {
-                const double l = tree_dists[ia];
-                if (weighted) { x += l * fabs(abnd[i] - abnd[j]); y += l * (abnd[i] + abnd[j]); } else { y += l; }
-                ++i;
-                ++j;
-            }
-        }
-        for (; i < ie; ++i) {
-            const double l = tree_dists[branch_id[i]];
-            if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
-        }
-        for (; j < je; ++j) {
-            const double l = tree_dists[branch_id[j]];
-            if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
-        }
-        out[t] = weighted ? x / y : x / (x + y);
-    }
-}
-
-// EXACT64: each lane owns the pairs (i0..i0+15, j0+lane) and walks every branch in
-// ascending id with the reference's operations.  Compiled with -ffp-contract=off.
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256)
-void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
-                         const double *__restrict__ branch_len, int64_t n_branches,
-                         const XTile *__restrict__ tiles, int n_tiles, int64_t row_begin,
-                         int64_t row_end, int64_t slot_begin, double *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= n_tiles) return;
-    const XTile tile = tiles[t];
-    double a[X_TILE_I], c[X_TILE_I];  // numer/denom, or result/common
-#pragma unroll
-    for (int r = 0; r < X_TILE_I; ++r) {
-        a[r] = 0.0;
-        c[r] = 0.0;
-    }
-    const double *pj = DT + tile.j0 + lane;
-    const double *pi = DT + tile.i0;
-#pragma unroll 2
-    for (int64_t k = 0; k < n_branches; ++k) {
-        const double l = branch_len[k];
-        const double y = pj[k * ld];
-        const double *row = pi + k * ld;
-#pragma unroll
-        for (int r = 0; r < X_TILE_I; ++r) {
-            const double x = row[r];
-            if (WEIGHTED) {
-                a[r] = a[r] + l * fabs(x - y);  // numer += treeDists[id] * |a-b|  (:191)
-                c[r] = c[r] + l * (x + y);      // denom += treeDists[id] * (a+b)  (:192)
-            } else {
-                a[r] = a[r] + l * fabs(x - y);  // result += treeDists[id] iff exactly one present
-                c[r] = c[r] + l * (x * y);      // common += treeDists[id] iff both present
-            }
-        }
-    }
-    const int64_t j = tile.j0 + lane;
-#pragma unroll
-    for (int r = 0; r < X_TILE_I; ++r) {
-        const int64_t i = tile.i0 + r;
-        if (i < row_begin || i >= row_end || j >= i) continue;
-        const double d = WEIGHTED ? a[r] / c[r] : a[r] / (a[r] + c[r]);
-        out[i * (i - 1) / 2 - slot_begin + j] = d;
-    }
-}
+#include "ff_kernels_stage.hpp"
+#include "ff_kernels_pair_sad.hpp"
+#include "ff_kernels_mfma.hpp"
+#include "ff_kernels_stage_a.hpp"
+#include "ff_kernels_finish.hpp"
 
 }  // namespace
 
