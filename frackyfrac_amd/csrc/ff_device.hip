@@ -554,34 +554,48 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     return FF_OK;
 }
 
-// Stages the device-resident flat nodes and builds the schedule.  Takes ownership of *c.
-int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, ff_plan *pl, char *err,
-               size_t errlen)
-{
-    const int64_t N = c->N, B = c->B, nnz = c->nnz;
-    const bool weighted = pl->weighted != 0;
-    ff_plan_info &inf = pl->info;
-    const int64_t n_slots = inf.slot_end - inf.slot_begin;
-    pl->d_len = c->d_len;  // the plan owns the device arrays from here on
-    pl->d_indptr = c->d_indptr;
-    pl->d_ids = c->d_ids;
-    pl->d_abnd = c->d_abnd;
-    c->d_len = nullptr;
-    c->d_indptr = nullptr;
-    c->d_ids = nullptr;
-    c->d_abnd = nullptr;
-    int64_t *d_indptr = pl->d_indptr;
-    int32_t *d_ids = pl->d_ids;
-    double *d_abnd = pl->d_abnd, *d_len = pl->d_len;
+// What the staging steps of a plan share.
+struct StageCtx {
+    const ff_options *o;
+    DeviceCsr *c;
+    const hipDeviceProp_t *prop;
+    ff_plan *pl;
+    int64_t R = 0;                       // staged rows: B, or the branches in use (compaction)
+    Scratch<int32_t> row_of;             // branch id -> staged row (null: identity)
+    std::vector<int32_t> branch_of_row;  // staged row -> branch id (empty: identity)
+    Quant q;
+};
 
+// The names the staging code is written in.
+#define FF_STAGE_NAMES                                                                      \
+    const ff_options *o = x.o;                                                              \
+    DeviceCsr *c = x.c;                                                                     \
+    const hipDeviceProp_t &prop = *x.prop;                                                  \
+    ff_plan *pl = x.pl;                                                                     \
+    const int64_t N = c->N, B = c->B, nnz = c->nnz, R = x.R;                                \
+    const bool weighted = pl->weighted != 0;                                                \
+    ff_plan_info &inf = pl->info;                                                           \
+    const int64_t n_slots = inf.slot_end - inf.slot_begin;                                  \
+    int64_t *d_indptr = pl->d_indptr;                                                       \
+    int32_t *d_ids = pl->d_ids;                                                             \
+    double *d_abnd = pl->d_abnd, *d_len = pl->d_len;                                        \
+    Scratch<int32_t> &row_of = x.row_of;                                                    \
+    std::vector<int32_t> &branch_of_row = x.branch_of_row;                                  \
+    Quant &q = x.q;                                                                         \
+    (void)o; (void)prop; (void)N; (void)B; (void)nnz; (void)R; (void)weighted; (void)n_slots; \
+    (void)d_indptr; (void)d_ids; (void)d_abnd; (void)d_len; (void)row_of; (void)branch_of_row; (void)q
+
+
+int compact_branches(StageCtx &x, char *err, size_t errlen)
+{
+    x.R = x.c->B;
+    FF_STAGE_NAMES;
     // Branch compaction.  A branch no sample has a flat node on is a zero row of the staged
     // matrix and adds |0 - 0| (or +0.0) to every pair: with a reference phylogeny much larger
     // than what the samples cover, most rows are like that.  Rows are renumbered over the
     // branches in use (ascending, so EXACT64 keeps the reference's order) when that drops
     // at least a tenth of them.  R = staged rows.
-    int64_t R = B;
-    Scratch<int32_t> row_of;
-    std::vector<int32_t> h_row_of, branch_of_row;
+    std::vector<int32_t> h_row_of;
     if (env_int("FF_COMPACT", 1) != 0 && B > 0 && nnz > 0) {
         Scratch<unsigned char> mark;
         FF_HIP(mark.alloc((size_t)B));
@@ -600,14 +614,275 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
                     h_row_of[(size_t)b] = (int32_t)branch_of_row.size();
                     branch_of_row.push_back((int32_t)b);
                 }
-            R = used;
+            x.R = used;
             FF_HIP(row_of.alloc((size_t)B));
             FF_HIP(hipMemcpy(row_of.p, h_row_of.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice));
         }
     }
+    return FF_OK;
+}
+
+// FIXED32 unweighted on the matrix cores: presence / digit planes, sample-major, and the MFMA schedule.
+int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
+{
+    FF_STAGE_NAMES;
+    // presence / digit planes, sample-major, zero padded to whole tiles and slabs
+    pl->mfma = true;
+    inf.kernel = FF_KERNEL_MFMA_I8;
+    inf.lengths_exact = q.lengths_exact;
+    inf.scale_log2 = q.e;
+    uint32_t kmax = 0;
+    for (uint32_t k : q.klen) kmax = std::max(kmax, k);
+    int digits = 1;
+    while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
+    pl->m_digits = digits;
+    inf.n_digits = digits;
+    const int64_t n8 = round_up(N, M_TILE_I);
+    const int64_t ldb = round_up(R, M_KSLAB);  // whole slabs
+    pl->m_ldb = ldb;
+    pl->m_plane = n8 * ldb;
+    inf.ld = n8;
+    inf.rows_padded = ldb;
+    const size_t plane_bytes = (size_t)n8 * (size_t)ldb;
+    inf.staged_bytes = (double)plane_bytes * (1 + digits);
+    FF_ALLOC(pl->d_P8, plane_bytes, "the presence plane");
+    FF_ALLOC(pl->d_K8, plane_bytes * (size_t)digits, "the branch-length digit planes");
+    FF_HIP(hipMemset(pl->d_P8, 0, plane_bytes));
+    FF_HIP(hipMemset(pl->d_K8, 0, plane_bytes * (size_t)digits));
+    FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
+    FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
+    Scratch<uint32_t> klen;
+    FF_HIP(klen.alloc((size_t)B));
+    FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+    if (nnz > 0)
+        stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, row_of.p, pl->d_P8,
+                                                             pl->d_K8, ldb, pl->m_plane, pl->d_W);
+    FF_HIP(hipGetLastError());
+    FF_HIP(hipDeviceSynchronize());
+    klen.release();
+    const int64_t slabs = ldb / M_KSLAB;
+    const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
+    pl->n_mgroups = G;
+    std::vector<MItem> mi;
+    std::vector<int32_t> mptr;
+    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, digits, G, &mi, &mptr);
+    pl->n_mitems = (int)mi.size();
+    inf.n_tiles = n_mtiles;
+    inf.n_items = (int64_t)mi.size();
+    inf.n_wave_slots = (int64_t)G * 8;
+    inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)ldb * digits;
+    FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
+    FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
+    if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
+    pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
+    return FF_OK;
+}
+
+// FIXED32 on the vector ALU: the branch-major u32 matrix, column sums, the sparse decision, the wave schedule.
+int stage_for_sad(StageCtx &x, char *err, size_t errlen)
+{
+    FF_STAGE_NAMES;
+    const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
+    const int64_t rows = round_up(R, 2 * KSTEP);
+    inf.ld = ld;
+    inf.rows_padded = rows;
+    inf.lengths_exact = weighted ? 0 : q.lengths_exact;
+    const size_t qt_bytes = sizeof(uint32_t) * (size_t)(rows + SLACK_ROWS) * (size_t)ld;
+    inf.staged_bytes = (double)qt_bytes;
+    FF_ALLOC(pl->d_QT, qt_bytes, "the staged branch x sample matrix");
+    FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
+    Scratch<uint32_t> klen;
+    if (!weighted) {
+        FF_HIP(klen.alloc((size_t)B));
+        if (B > 0) FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+    }
+    std::vector<unsigned long long> hW((size_t)ld);
+    int e = q.e;
+    for (int attempt = 0;; ++attempt) {
+        FF_HIP(hipMemset(pl->d_QT, 0, qt_bytes));
+        FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
+        if (N > 0 && nnz > 0)
+            stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, klen.p,
+                                                                    weighted ? 1 : 0, e, row_of.p, pl->d_QT, ld);
+        if (rows > 0) {
+            const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
+            dim3 grid((unsigned)(ld / 64), (unsigned)((rows + rpb - 1) / rpb));
+            colsum_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, rpb, pl->d_W);
+        }
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipMemcpy(hW.data(), pl->d_W, sizeof(unsigned long long) * (size_t)ld, hipMemcpyDeviceToHost));
+        unsigned long long wmax = 0;
+        for (auto w : hW) wmax = std::max(wmax, w);
+        if (wmax <= 2147483647ull) break;
+        if (!weighted || attempt >= 3)
+            return ff::fail(FF_ERR_INTERNAL, err, errlen, "FIXED32 staging overflow (max column sum %llu)", wmax);
+        --e;  // rounding pushed a column over the bound: drop one bit
+    }
+    klen.release();
+    inf.scale_log2 = e;
+    // schedule
+    std::vector<Tile> tiles;
+    build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
+    inf.n_tiles = (int64_t)tiles.size();
+    int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
+    if (wgs_per_cu > 2) wgs_per_cu = 2;
+    pl->n_workgroups = prop.multiProcessorCount * wgs_per_cu;
+    pl->sync_trips = env_int("FF_SYNC_TRIPS", 16);
+    // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
+    pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
+    // activity of every (i-block, branch row): decides between the dense and the
+    // sparse-aware kernel
+    if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
+        const int64_t n_iblocks = ld / TILE_I, words = (rows + SLACK_ROWS + 63) / 64;
+        Scratch<unsigned long long> act64;
+        FF_HIP(act64.alloc((size_t)(n_iblocks * words)));
+        build_activity_kernel<<<dim3((unsigned)words, (unsigned)n_iblocks), dim3(64)>>>(pl->d_QT, ld, rows, words,
+                                                                                        act64.p);
+        FF_HIP(hipGetLastError());
+        std::vector<unsigned long long> a64((size_t)(n_iblocks * words));
+        FF_HIP(hipMemcpy(a64.data(), act64.p, sizeof(unsigned long long) * a64.size(), hipMemcpyDeviceToHost));
+        act64.release();
+        // only the i-blocks this shard's tiles use count for the decision
+        const int64_t ib0 = inf.row_begin / TILE_I, ib1 = (inf.row_end + TILE_I - 1) / TILE_I;
+        int64_t active = 0;
+        for (int64_t ib = ib0; ib < ib1; ++ib)
+            for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
+        const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
+        const double inactive = 1.0 - (double)active / total;
+        const char *thr = getenv("FF_SPARSE_MIN");
+        // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
+        // prefetch, per-row address arithmetic), so it pays from about a quarter upwards
+        if (inactive >= (thr && *thr ? atof(thr) : 0.28)) {
+            // per i-block: the list of active rows and, every 16 rows, where the list stands
+            const int64_t marks = rows / (2 * KSTEP) + 1;
+            pl->aptr_stride = marks;
+            std::vector<uint32_t> arows, aptr((size_t)(n_iblocks * marks), 0u);
+            arows.reserve((size_t)active + 16);
+            for (int64_t ib = 0; ib < n_iblocks; ++ib)
+                for (int64_t r = 0; r <= rows; ++r) {
+                    if (r % (2 * KSTEP) == 0) aptr[(size_t)(ib * marks + r / (2 * KSTEP))] = (uint32_t)arows.size();
+                    if (r < rows && ((a64[(size_t)(ib * words + r / 64)] >> (r % 64)) & 1ull)) arows.push_back((uint32_t)r);
+                }
+            if (arows.size() >= 0xFFFFFFF0ull)
+                return ff::fail(FF_ERR_INTERNAL, err, errlen, "active-row list too long");
+            arows.resize(arows.size() + 16, (uint32_t)rows);
+            pl->zero_row = (int32_t)rows;  // first slack row: zero in every column
+            FF_HIP(hipMalloc(&pl->d_arows, sizeof(uint32_t) * arows.size()));
+            FF_HIP(hipMemcpy(pl->d_arows, arows.data(), sizeof(uint32_t) * arows.size(), hipMemcpyHostToDevice));
+            FF_HIP(hipMalloc(&pl->d_aptr16, sizeof(uint32_t) * aptr.size()));
+            FF_HIP(hipMemcpy(pl->d_aptr16, aptr.data(), sizeof(uint32_t) * aptr.size(), hipMemcpyHostToDevice));
+            FF_HIP(hipMalloc(&pl->d_cs16, sizeof(uint32_t) * (size_t)(marks * ld)));
+            prefix16_kernel<<<dim3((unsigned)((ld + 63) / 64)), dim3(64)>>>(pl->d_QT, ld, rows, pl->d_cs16);
+            FF_HIP(hipGetLastError());
+            pl->sparse = true;
+            inf.kernel = FF_KERNEL_SAD_U32_SPARSE;
+            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_sparse_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+        }
+    }
+    // work schedule: 8 waves per workgroup for the register-buffered and the sparse-aware
+    // kernel, 12 for the LDS-staged one
+    pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
+    if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
+    const int U = pl->n_workgroups * pl->waves_per_wg;
+    inf.n_wave_slots = U;
+    std::vector<Item> items;
+    std::vector<int32_t> item_ptr;
+    build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg);
+    inf.n_items = (int64_t)items.size();
+    FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
+    FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
+    if (!items.empty())
+        FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
+    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
+    if (env_int("FF_STAMPS", 0)) {
+        FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
+        FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
+    }
+    if (pl->waves_per_wg == L_WAVES_PER_WG) {
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    }
+    else
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    return FF_OK;
+}
+
+// EXACT64: the branch-major binary64 matrix and its tiles.
+int stage_for_exact64(StageCtx &x, char *err, size_t errlen)
+{
+    FF_STAGE_NAMES;
+    const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
+    inf.ld = ld;
+    inf.rows_padded = R;
+    const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(R, 1) * (size_t)ld;
+    inf.staged_bytes = (double)dt_bytes;
+    FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
+    FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
+    if (N > 0 && nnz > 0)
+        stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,
+                                                                row_of.p, pl->d_DT, ld);
+    FF_HIP(hipGetLastError());
+    if (row_of.p) {  // the walk reads treeDists by staged row
+        std::vector<double> lr((size_t)R);
+        for (int64_t r = 0; r < R; ++r) lr[(size_t)r] = c->h_len[(size_t)branch_of_row[(size_t)r]];
+        FF_HIP(hipMalloc(&pl->d_len_rows, sizeof(double) * (size_t)R));
+        FF_HIP(hipMemcpy(pl->d_len_rows, lr.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice));
+    }
+    std::vector<Tile> tiles;
+    build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
+    inf.n_tiles = inf.n_items = (int64_t)tiles.size();
+    inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)R;
+    std::vector<XTile> xt(tiles.size());
+    for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
+    // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
+    if (xt.size() >= ((size_t)1 << 26))
+        return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
+                        xt.size(), ((size_t)1 << 26) - 1);
+    pl->n_xtiles = (int)xt.size();
+    FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
+    if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
+    inf.n_wave_slots = (int64_t)xt.size();
+    return FF_OK;
+}
+
+// Stages the device-resident flat nodes and builds the schedule.  Takes ownership of *c.
+int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, ff_plan *pl, char *err,
+               size_t errlen)
+{
+    const int64_t N = c->N, B = c->B;
+    const bool weighted = pl->weighted != 0;
+    ff_plan_info &inf = pl->info;
+    const int64_t n_slots = inf.slot_end - inf.slot_begin;
+    pl->d_len = c->d_len;  // the plan owns the device arrays from here on
+    pl->d_indptr = c->d_indptr;
+    pl->d_ids = c->d_ids;
+    pl->d_abnd = c->d_abnd;
+    c->d_len = nullptr;
+    c->d_indptr = nullptr;
+    c->d_ids = nullptr;
+    c->d_abnd = nullptr;
+
+    StageCtx x;
+    x.o = o;
+    x.c = c;
+    x.prop = &prop;
+    x.pl = pl;
+    int rc = compact_branches(x, err, errlen);
+    if (rc) return rc;
+    const int64_t R = x.R;
+    Quant &q = x.q;
     inf.n_rows = R;
 
-    Quant q;
     int prec = o->precision;
     // AUTO: problems small enough that the binary64 walk costs about a millisecond
     // get the reference's exact roundings (this covers all of the reference's own
@@ -628,222 +903,10 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     inf.kernel = prec == FF_PRECISION_EXACT64 ? FF_KERNEL_EXACT_F64 : FF_KERNEL_SAD_U32;
 
     const bool use_mfma = prec == FF_PRECISION_FIXED32 && !weighted && env_int("FF_UNWEIGHTED_MFMA", 1) != 0 && N > 0 && B > 0;
-    if (use_mfma) {
-        // presence / digit planes, sample-major, zero padded to whole tiles and slabs
-        pl->mfma = true;
-        inf.kernel = FF_KERNEL_MFMA_I8;
-        inf.lengths_exact = q.lengths_exact;
-        inf.scale_log2 = q.e;
-        uint32_t kmax = 0;
-        for (uint32_t k : q.klen) kmax = std::max(kmax, k);
-        int digits = 1;
-        while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
-        pl->m_digits = digits;
-        inf.n_digits = digits;
-        const int64_t n8 = round_up(N, M_TILE_I);
-        const int64_t ldb = round_up(R, M_KSLAB);  // whole slabs
-        pl->m_ldb = ldb;
-        pl->m_plane = n8 * ldb;
-        inf.ld = n8;
-        inf.rows_padded = ldb;
-        const size_t plane_bytes = (size_t)n8 * (size_t)ldb;
-        inf.staged_bytes = (double)plane_bytes * (1 + digits);
-        FF_ALLOC(pl->d_P8, plane_bytes, "the presence plane");
-        FF_ALLOC(pl->d_K8, plane_bytes * (size_t)digits, "the branch-length digit planes");
-        FF_HIP(hipMemset(pl->d_P8, 0, plane_bytes));
-        FF_HIP(hipMemset(pl->d_K8, 0, plane_bytes * (size_t)digits));
-        FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
-        FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
-        Scratch<uint32_t> klen;
-        FF_HIP(klen.alloc((size_t)B));
-        FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
-        if (nnz > 0)
-            stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, row_of.p, pl->d_P8,
-                                                                 pl->d_K8, ldb, pl->m_plane, pl->d_W);
-        FF_HIP(hipGetLastError());
-        FF_HIP(hipDeviceSynchronize());
-        klen.release();
-        const int64_t slabs = ldb / M_KSLAB;
-        const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
-        pl->n_mgroups = G;
-        std::vector<MItem> mi;
-        std::vector<int32_t> mptr;
-        const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, digits, G, &mi, &mptr);
-        pl->n_mitems = (int)mi.size();
-        inf.n_tiles = n_mtiles;
-        inf.n_items = (int64_t)mi.size();
-        inf.n_wave_slots = (int64_t)G * 8;
-        inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)ldb * digits;
-        FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
-        FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
-        if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
-        FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
-        pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-        FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
-    } else if (prec == FF_PRECISION_FIXED32) {
-        const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
-        const int64_t rows = round_up(R, 2 * KSTEP);
-        inf.ld = ld;
-        inf.rows_padded = rows;
-        inf.lengths_exact = weighted ? 0 : q.lengths_exact;
-        const size_t qt_bytes = sizeof(uint32_t) * (size_t)(rows + SLACK_ROWS) * (size_t)ld;
-        inf.staged_bytes = (double)qt_bytes;
-        FF_ALLOC(pl->d_QT, qt_bytes, "the staged branch x sample matrix");
-        FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
-        Scratch<uint32_t> klen;
-        if (!weighted) {
-            FF_HIP(klen.alloc((size_t)B));
-            if (B > 0) FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
-        }
-        std::vector<unsigned long long> hW((size_t)ld);
-        int e = q.e;
-        for (int attempt = 0;; ++attempt) {
-            FF_HIP(hipMemset(pl->d_QT, 0, qt_bytes));
-            FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
-            if (N > 0 && nnz > 0)
-                stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, klen.p,
-                                                                        weighted ? 1 : 0, e, row_of.p, pl->d_QT, ld);
-            if (rows > 0) {
-                const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
-                dim3 grid((unsigned)(ld / 64), (unsigned)((rows + rpb - 1) / rpb));
-                colsum_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, rpb, pl->d_W);
-            }
-            FF_HIP(hipGetLastError());
-            FF_HIP(hipMemcpy(hW.data(), pl->d_W, sizeof(unsigned long long) * (size_t)ld, hipMemcpyDeviceToHost));
-            unsigned long long wmax = 0;
-            for (auto w : hW) wmax = std::max(wmax, w);
-            if (wmax <= 2147483647ull) break;
-            if (!weighted || attempt >= 3)
-                return ff::fail(FF_ERR_INTERNAL, err, errlen, "FIXED32 staging overflow (max column sum %llu)", wmax);
-            --e;  // rounding pushed a column over the bound: drop one bit
-        }
-        klen.release();
-        inf.scale_log2 = e;
-        // schedule
-        std::vector<Tile> tiles;
-        build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
-        inf.n_tiles = (int64_t)tiles.size();
-        int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
-        if (wgs_per_cu < 1) wgs_per_cu = 1;
-        if (wgs_per_cu > 2) wgs_per_cu = 2;
-        pl->n_workgroups = prop.multiProcessorCount * wgs_per_cu;
-        pl->sync_trips = env_int("FF_SYNC_TRIPS", 16);
-        // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
-        pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
-        // activity of every (i-block, branch row): decides between the dense and the
-        // sparse-aware kernel
-        if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
-            const int64_t n_iblocks = ld / TILE_I, words = (rows + SLACK_ROWS + 63) / 64;
-            Scratch<unsigned long long> act64;
-            FF_HIP(act64.alloc((size_t)(n_iblocks * words)));
-            build_activity_kernel<<<dim3((unsigned)words, (unsigned)n_iblocks), dim3(64)>>>(pl->d_QT, ld, rows, words,
-                                                                                            act64.p);
-            FF_HIP(hipGetLastError());
-            std::vector<unsigned long long> a64((size_t)(n_iblocks * words));
-            FF_HIP(hipMemcpy(a64.data(), act64.p, sizeof(unsigned long long) * a64.size(), hipMemcpyDeviceToHost));
-            act64.release();
-            // only the i-blocks this shard's tiles use count for the decision
-            const int64_t ib0 = inf.row_begin / TILE_I, ib1 = (inf.row_end + TILE_I - 1) / TILE_I;
-            int64_t active = 0;
-            for (int64_t ib = ib0; ib < ib1; ++ib)
-                for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
-            const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
-            const double inactive = 1.0 - (double)active / total;
-            const char *thr = getenv("FF_SPARSE_MIN");
-            // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
-            // prefetch, per-row address arithmetic), so it pays from about a quarter upwards
-            if (inactive >= (thr && *thr ? atof(thr) : 0.28)) {
-                // per i-block: the list of active rows and, every 16 rows, where the list stands
-                const int64_t marks = rows / (2 * KSTEP) + 1;
-                pl->aptr_stride = marks;
-                std::vector<uint32_t> arows, aptr((size_t)(n_iblocks * marks), 0u);
-                arows.reserve((size_t)active + 16);
-                for (int64_t ib = 0; ib < n_iblocks; ++ib)
-                    for (int64_t r = 0; r <= rows; ++r) {
-                        if (r % (2 * KSTEP) == 0) aptr[(size_t)(ib * marks + r / (2 * KSTEP))] = (uint32_t)arows.size();
-                        if (r < rows && ((a64[(size_t)(ib * words + r / 64)] >> (r % 64)) & 1ull)) arows.push_back((uint32_t)r);
-                    }
-                if (arows.size() >= 0xFFFFFFF0ull)
-                    return ff::fail(FF_ERR_INTERNAL, err, errlen, "active-row list too long");
-                arows.resize(arows.size() + 16, (uint32_t)rows);
-                pl->zero_row = (int32_t)rows;  // first slack row: zero in every column
-                FF_HIP(hipMalloc(&pl->d_arows, sizeof(uint32_t) * arows.size()));
-                FF_HIP(hipMemcpy(pl->d_arows, arows.data(), sizeof(uint32_t) * arows.size(), hipMemcpyHostToDevice));
-                FF_HIP(hipMalloc(&pl->d_aptr16, sizeof(uint32_t) * aptr.size()));
-                FF_HIP(hipMemcpy(pl->d_aptr16, aptr.data(), sizeof(uint32_t) * aptr.size(), hipMemcpyHostToDevice));
-                FF_HIP(hipMalloc(&pl->d_cs16, sizeof(uint32_t) * (size_t)(marks * ld)));
-                prefix16_kernel<<<dim3((unsigned)((ld + 63) / 64)), dim3(64)>>>(pl->d_QT, ld, rows, pl->d_cs16);
-                FF_HIP(hipGetLastError());
-                pl->sparse = true;
-                inf.kernel = FF_KERNEL_SAD_U32_SPARSE;
-                FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_sparse_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-            }
-        }
-        // work schedule: 8 waves per workgroup for the register-buffered and the sparse-aware
-        // kernel, 12 for the LDS-staged one
-        pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-        if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
-        const int U = pl->n_workgroups * pl->waves_per_wg;
-        inf.n_wave_slots = U;
-        std::vector<Item> items;
-        std::vector<int32_t> item_ptr;
-        build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg);
-        inf.n_items = (int64_t)items.size();
-        FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
-        FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
-        if (!items.empty())
-            FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
-        FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
-        FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
-        if (env_int("FF_STAMPS", 0)) {
-            FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
-            FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
-        }
-        if (pl->waves_per_wg == L_WAVES_PER_WG) {
-            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-        }
-        else
-            FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-    } else {
-        const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
-        inf.ld = ld;
-        inf.rows_padded = R;
-        const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(R, 1) * (size_t)ld;
-        inf.staged_bytes = (double)dt_bytes;
-        FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
-        FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
-        if (N > 0 && nnz > 0)
-            stage_exact64_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, weighted ? 1 : 0,
-                                                                    row_of.p, pl->d_DT, ld);
-        FF_HIP(hipGetLastError());
-        if (row_of.p) {  // the walk reads treeDists by staged row
-            std::vector<double> lr((size_t)R);
-            for (int64_t r = 0; r < R; ++r) lr[(size_t)r] = c->h_len[(size_t)branch_of_row[(size_t)r]];
-            FF_HIP(hipMalloc(&pl->d_len_rows, sizeof(double) * (size_t)R));
-            FF_HIP(hipMemcpy(pl->d_len_rows, lr.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice));
-        }
-        std::vector<Tile> tiles;
-        build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
-        inf.n_tiles = inf.n_items = (int64_t)tiles.size();
-        inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)R;
-        std::vector<XTile> xt(tiles.size());
-        for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
-        // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
-        if (xt.size() >= ((size_t)1 << 26))
-            return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
-                            xt.size(), ((size_t)1 << 26) - 1);
-        pl->n_xtiles = (int)xt.size();
-        FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
-        if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
-        inf.n_wave_slots = (int64_t)xt.size();
-    }
+    if (use_mfma) rc = stage_for_mfma(x, err, errlen);
+    else if (prec == FF_PRECISION_FIXED32) rc = stage_for_sad(x, err, errlen);
+    else rc = stage_for_exact64(x, err, errlen);
+    if (rc) return rc;
     FF_HIP(hipDeviceSynchronize());
     // FIXED32 keeps the flat nodes resident for refine_exact_kernel unless the integer
     // sums are exact already (unweighted with lengths on the binary grid)
