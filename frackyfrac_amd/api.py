@@ -313,6 +313,13 @@ class Plan:
     def n_slots(self) -> int:
         return int(self.info.slot_end - self.info.slot_begin)
 
+    def set_shard(self, rank: int, world: int) -> None:
+        """Re-targets the staged plan at shard `rank` of `world` (ff_plan_set_shard): same staged
+        matrix, new schedule and accumulators; n_slots and info change."""
+        err = L.errbuf()
+        L.check(L.lib().ff_plan_set_shard(self._h, int(rank), int(world), err, L.ERRLEN), err)
+        L.lib().ff_plan_info_get(self._h, ctypes.byref(self.info))
+
     def run(self, d_out_ptr: int, stream: int = 0, timed: bool = False) -> None:
         """One pass of the hot path; d_out_ptr is a device pointer to n_slots doubles,
         stream a hipStream_t handle (0 = null stream).  Asynchronous."""

@@ -16,6 +16,17 @@ int unifrac_leaves_info(const ff_tree *, int64_t, const int64_t *, const int64_t
 {
     return fail(FF_ERR_DEVICE, err, errlen, "device stub");
 }
+ShardRunner::ShardRunner(const ff_tree *tree, int64_t n, const int64_t *lp, const int64_t *li, const double *lv, int un,
+                         const ff_options &opt)
+    : tree_(tree), n_(n), lp_(lp), li_(li), lv_(lv), unnorm_(un), opt_(opt)
+{
+}
+ShardRunner::~ShardRunner() {}
+int ShardRunner::create(int32_t, int32_t, int, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
+int ShardRunner::run(int32_t, int32_t, double *, ff_plan_info *, char *err, size_t errlen)
+{
+    return fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
 }  // namespace ff
 
 extern "C" int ff_unifrac_dists(const ff_problem *, const ff_options *, double *, char *err, size_t errlen)

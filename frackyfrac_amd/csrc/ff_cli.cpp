@@ -9,6 +9,7 @@
 // Extensions (not in the reference): -precision auto|fixed32|exact64, -stats, -gpus N.
 #include <chrono>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 
 #include "ff_host.hpp"
@@ -270,6 +271,14 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         return die(err);
     }
     ff_plan_info info{};
+    // one runner per device slot: stage A and the staging happen once, later passes re-target the plan
+    std::vector<std::unique_ptr<ff::ShardRunner>> runners;
+    for (int64_t g = 0; g < G; ++g) {
+        ff_options o = opt;
+        o.device = (int32_t)(g % ndev);
+        runners.emplace_back(new ff::ShardRunner(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
+                                                 f.nnorm ? 1 : 0, o));
+    }
     std::vector<std::vector<double>> sets[2] = {std::vector<std::vector<double>>((size_t)G),
                                                 std::vector<std::vector<double>>((size_t)G)};
     double t_dist = 0, t_write = 0;  // time the main thread computed / waited for the writer
@@ -298,9 +307,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
                 } catch (const std::bad_alloc &) {
                     r = ff::fail(FF_ERR_INTERNAL, e, sizeof e, "out of host memory for %lld distances", (long long)(b - a));
                 }
-                if (r == 0)
-                    r = ff::unifrac_leaves_info(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(), f.nnorm ? 1 : 0,
-                                                &o, bufs[(size_t)g].data(), &infos[(size_t)g], e, sizeof e, true);
+                if (r == 0) r = runners[(size_t)g]->run(o.rank, o.world, bufs[(size_t)g].data(), &infos[(size_t)g], e, sizeof e);
             } else {
                 snprintf(e, sizeof e, "bad shard %d of %d", o.rank, o.world);
             }
@@ -343,6 +350,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         rc = wr_rc;
         snprintf(err, sizeof err, "%s", wr_err);
     }
+    runners.clear();
     ff_tree_free(tree);
     if (rc == 0) rc = writer.close(err, sizeof err);
     if (rc) return die(err);

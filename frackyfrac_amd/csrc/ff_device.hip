@@ -63,6 +63,7 @@ struct ff_plan {
     uint32_t *d_num = nullptr;
     Item *d_items = nullptr;
     int32_t *d_item_ptr = nullptr;
+    int32_t shard_rank = 0, shard_world = 1;
     int n_workgroups = 0;
     int waves_per_wg = WAVES_PER_WG;
     size_t lds_bytes = 0;
@@ -121,7 +122,7 @@ namespace {
             return ff::fail(FF_ERR_DEVICE, err, errlen,                                            \
                             "HIP: %s: cannot allocate %.2f GB for %s (shard %d of %d; more shards " \
                             "make it smaller)", hipGetErrorString(e_), (double)(bytes) / 1e9, what, \
-                            (int)o->rank, (int)o->world);                                          \
+                            (int)pl->shard_rank, (int)pl->shard_world);                            \
         }                                                                                          \
     } while (0)
 
@@ -318,6 +319,8 @@ void plan_free_device(ff_plan *pl)
 }
 
 // Picks the device (it must be a gfx950) and fills the shard geometry.
+int set_shard_geometry(ff_plan *pl, int32_t rank, int32_t world, char *err, size_t errlen);
+
 int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDeviceProp_t *prop, char *err,
                size_t errlen)
 {
@@ -342,11 +345,9 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
     inf.n_samples = N;
     inf.n_branches = B;
     inf.n_compute_units = prop->multiProcessorCount;
-    int rc = ff_shard_rows(N, o->rank, o->world, &inf.row_begin, &inf.row_end);
-    if (rc) return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
-    inf.slot_begin = inf.row_begin > 0 ? inf.row_begin * (inf.row_begin - 1) / 2 : 0;
-    inf.slot_end = inf.row_end > 0 ? inf.row_end * (inf.row_end - 1) / 2 : 0;
-    return FF_OK;
+    pl->shard_rank = o->rank;
+    pl->shard_world = o->world;
+    return set_shard_geometry(pl, o->rank, o->world, err, errlen);
 }
 
 // Host flat nodes -> device (the inner-seam entry: ff_plan_create / ff_unifrac_dists).
@@ -554,6 +555,142 @@ int csr_from_leaves(const ff_tree *t, int64_t N, const int64_t *leaf_ptr, const 
     return FF_OK;
 }
 
+// ---- The shard-dependent part of a plan: work schedule and accumulators --------------------
+// (rebuilt by ff_plan_set_shard; the staged matrix does not depend on the shard)
+
+template <typename T> void free_and_null(T *&p)
+{
+    (void)hipFree(p);
+    p = nullptr;
+}
+
+int set_shard_geometry(ff_plan *pl, int32_t rank, int32_t world, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    int rc = ff_shard_rows(inf.n_samples, rank, world, &inf.row_begin, &inf.row_end);
+    if (rc) return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", rank, world);
+    inf.slot_begin = inf.row_begin > 0 ? inf.row_begin * (inf.row_begin - 1) / 2 : 0;
+    inf.slot_end = inf.row_end > 0 ? inf.row_end * (inf.row_end - 1) / 2 : 0;
+    return FF_OK;
+}
+
+int schedule_sad(ff_plan *pl, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    const int64_t N = inf.n_samples, rows = inf.rows_padded, n_slots = inf.slot_end - inf.slot_begin;
+    free_and_null(pl->d_items);
+    free_and_null(pl->d_item_ptr);
+    free_and_null(pl->d_num);
+    free_and_null(pl->d_stamps);
+    std::vector<Tile> tiles;
+    build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
+    inf.n_tiles = (int64_t)tiles.size();
+    // 8 waves per workgroup for the register-buffered and the sparse-aware kernel, 12 for the
+    // three-waves-per-SIMD variants
+    pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
+    if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
+    const int U = pl->n_workgroups * pl->waves_per_wg;
+    inf.n_wave_slots = U;
+    std::vector<Item> items;
+    std::vector<int32_t> item_ptr;
+    build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg);
+    inf.n_items = (int64_t)items.size();
+    FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
+    FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
+    if (!items.empty())
+        FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
+    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
+    if (env_int("FF_STAMPS", 0)) {
+        FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
+        FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
+    }
+    if (pl->waves_per_wg == L_WAVES_PER_WG) {
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    } else if (pl->sparse) {
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_sparse_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    } else {
+        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    }
+    return FF_OK;
+}
+
+int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    const int64_t N = inf.n_samples, n_slots = inf.slot_end - inf.slot_begin;
+    free_and_null(pl->d_mitems);
+    free_and_null(pl->d_mitem_ptr);
+    free_and_null(pl->d_num);
+    const int64_t slabs = pl->m_ldb / M_KSLAB;
+    const int G = inf.n_compute_units;  // one 8-wave workgroup per CU
+    pl->n_mgroups = G;
+    std::vector<MItem> mi;
+    std::vector<int32_t> mptr;
+    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr);
+    pl->n_mitems = (int)mi.size();
+    inf.n_tiles = n_mtiles;
+    inf.n_items = (int64_t)mi.size();
+    inf.n_wave_slots = (int64_t)G * 8;
+    inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)pl->m_ldb * pl->m_digits;
+    FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
+    FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
+    if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
+    FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
+    pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
+    return FF_OK;
+}
+
+int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    free_and_null(pl->d_xtiles);
+    std::vector<Tile> tiles;
+    build_tiles(inf.n_samples, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
+    inf.n_tiles = inf.n_items = (int64_t)tiles.size();
+    inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)inf.n_rows;
+    std::vector<XTile> xt(tiles.size());
+    for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
+    // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
+    if (xt.size() >= ((size_t)1 << 26))
+        return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
+                        xt.size(), ((size_t)1 << 26) - 1);
+    pl->n_xtiles = (int)xt.size();
+    FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
+    if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
+    inf.n_wave_slots = (int64_t)xt.size();
+    return FF_OK;
+}
+
+// The queue of pairs to recompute exactly holds up to an eighth of the shard (at least 2^20).
+int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
+{
+    const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
+    free_and_null(pl->d_refine_list);
+    pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
+    FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)std::max<unsigned long long>(pl->refine_cap, 1)));
+    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long)));
+    FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long)));
+    return FF_OK;
+}
+
+int schedule_for_shard(ff_plan *pl, char *err, size_t errlen)
+{
+    int rc = pl->mfma ? schedule_mfma(pl, err, errlen)
+             : pl->info.precision == FF_PRECISION_FIXED32 ? schedule_sad(pl, err, errlen)
+                                                          : schedule_exact64(pl, err, errlen);
+    if (rc == FF_OK && pl->refine) rc = alloc_refine_queue(pl, err, errlen);
+    return rc;
+}
+
 // What the staging steps of a plan share.
 struct StageCtx {
     const ff_options *o;
@@ -660,26 +797,7 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
     FF_HIP(hipGetLastError());
     FF_HIP(hipDeviceSynchronize());
     klen.release();
-    const int64_t slabs = ldb / M_KSLAB;
-    const int G = prop.multiProcessorCount;  // one 8-wave workgroup per CU
-    pl->n_mgroups = G;
-    std::vector<MItem> mi;
-    std::vector<int32_t> mptr;
-    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, digits, G, &mi, &mptr);
-    pl->n_mitems = (int)mi.size();
-    inf.n_tiles = n_mtiles;
-    inf.n_items = (int64_t)mi.size();
-    inf.n_wave_slots = (int64_t)G * 8;
-    inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)ldb * digits;
-    FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
-    FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
-    if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
-    FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
-    pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
-    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
-    return FF_OK;
+    return schedule_mfma(pl, err, errlen);
 }
 
 // FIXED32 on the vector ALU: the branch-major u32 matrix, column sums, the sparse decision, the wave schedule.
@@ -724,10 +842,6 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     }
     klen.release();
     inf.scale_log2 = e;
-    // schedule
-    std::vector<Tile> tiles;
-    build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
-    inf.n_tiles = (int64_t)tiles.size();
     int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
     if (wgs_per_cu < 1) wgs_per_cu = 1;
     if (wgs_per_cu > 2) wgs_per_cu = 2;
@@ -785,36 +899,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
         }
     }
-    // work schedule: 8 waves per workgroup for the register-buffered and the sparse-aware
-    // kernel, 12 for the LDS-staged one
-    pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-    if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
-    const int U = pl->n_workgroups * pl->waves_per_wg;
-    inf.n_wave_slots = U;
-    std::vector<Item> items;
-    std::vector<int32_t> item_ptr;
-    build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg);
-    inf.n_items = (int64_t)items.size();
-    FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
-    FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
-    if (!items.empty())
-        FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
-    FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
-    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
-    if (env_int("FF_STAMPS", 0)) {
-        FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
-        FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
-    }
-    if (pl->waves_per_wg == L_WAVES_PER_WG) {
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-    }
-    else
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
-    return FF_OK;
+    return schedule_sad(pl, err, errlen);
 }
 
 // EXACT64: the branch-major binary64 matrix and its tiles.
@@ -838,21 +923,7 @@ int stage_for_exact64(StageCtx &x, char *err, size_t errlen)
         FF_HIP(hipMalloc(&pl->d_len_rows, sizeof(double) * (size_t)R));
         FF_HIP(hipMemcpy(pl->d_len_rows, lr.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice));
     }
-    std::vector<Tile> tiles;
-    build_tiles(N, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
-    inf.n_tiles = inf.n_items = (int64_t)tiles.size();
-    inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)R;
-    std::vector<XTile> xt(tiles.size());
-    for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
-    // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
-    if (xt.size() >= ((size_t)1 << 26))
-        return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
-                        xt.size(), ((size_t)1 << 26) - 1);
-    pl->n_xtiles = (int)xt.size();
-    FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
-    if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
-    inf.n_wave_slots = (int64_t)xt.size();
-    return FF_OK;
+    return schedule_exact64(pl, err, errlen);
 }
 
 // Stages the device-resident flat nodes and builds the schedule.  Takes ownership of *c.
@@ -862,7 +933,6 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     const int64_t N = c->N, B = c->B;
     const bool weighted = pl->weighted != 0;
     ff_plan_info &inf = pl->info;
-    const int64_t n_slots = inf.slot_end - inf.slot_begin;
     pl->d_len = c->d_len;  // the plan owns the device arrays from here on
     pl->d_indptr = c->d_indptr;
     pl->d_ids = c->d_ids;
@@ -910,13 +980,10 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     FF_HIP(hipDeviceSynchronize());
     // FIXED32 keeps the flat nodes resident for refine_exact_kernel unless the integer
     // sums are exact already (unweighted with lengths on the binary grid)
-    if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && n_slots > 0 &&
-        env_int("FF_REFINE", 1)) {
+    if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && env_int("FF_REFINE", 1)) {
         pl->refine = true;
-        pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
-        FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)pl->refine_cap));
-        FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long)));
-        FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long)));
+        rc = alloc_refine_queue(pl, err, errlen);
+        if (rc) return rc;
     } else {
         (void)hipFree(pl->d_indptr);
         (void)hipFree(pl->d_ids);
@@ -1047,6 +1114,25 @@ int ff_plan_info_get(const ff_plan *pl, ff_plan_info *info)
     if (!pl || !info) return FF_ERR_ARG;
     *info = pl->info;
     return FF_OK;
+}
+
+int ff_plan_set_shard(ff_plan *pl, int32_t rank, int32_t world, char *err, size_t errlen)
+{
+    if (!pl) return ff::fail(FF_ERR_ARG, err, errlen, "null plan");
+    if (world < 1 || rank < 0 || rank >= world) return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", rank, world);
+    int cur = -1;
+    FF_HIP(hipGetDevice(&cur));
+    if (cur != pl->device) FF_HIP(hipSetDevice(pl->device));
+    FF_HIP(hipDeviceSynchronize());  // runs of the old shard may still read the schedule
+    int rc = set_shard_geometry(pl, rank, world, err, errlen);
+    if (rc == FF_OK) {
+        pl->shard_rank = rank;
+        pl->shard_world = world;
+        rc = schedule_for_shard(pl, err, errlen);
+    }
+    if (rc == FF_OK) FF_HIP(hipDeviceSynchronize());
+    if (cur != pl->device) (void)hipSetDevice(cur);
+    return rc;
 }
 
 int ff_plan_run(ff_plan *pl, void *stream, double *d_out, char *err, size_t errlen)
@@ -1243,6 +1329,74 @@ int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recr
     if (info_out && pl) *info_out = pl->info;
     ff_plan_destroy(pl);
     return rc;
+}
+
+ff::ShardRunner::ShardRunner(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr, const int64_t *leaf_idx,
+                             const double *leaf_val, int leave_unnormalized, const ff_options &opt)
+    : tree_(tree), n_(n_samples), lp_(leaf_ptr), li_(leaf_idx), lv_(leaf_val), unnorm_(leave_unnormalized), opt_(opt)
+{
+}
+
+ff::ShardRunner::~ShardRunner()
+{
+    if (pl_) {
+        int cur = -1;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != pl_->device && hipSetDevice(pl_->device) == hipSuccess;
+        (void)hipFree(d_out_);
+        ff_plan_destroy(pl_);
+        if (sw) (void)hipSetDevice(cur);
+    }
+}
+
+int ff::ShardRunner::create(int32_t rank, int32_t world, int precision, char *err, size_t errlen)
+{
+    if (pl_) ff_plan_destroy(pl_);
+    pl_ = nullptr;
+    ff_options o = opt_;
+    o.rank = rank;
+    o.world = world;
+    o.precision = precision;
+    return ff_plan_create_from_leaves(tree_, n_, lp_, li_, lv_, unnorm_, &o, &pl_, err, errlen);
+}
+
+int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info *info, char *err, size_t errlen)
+{
+    int rc = pl_ ? ff_plan_set_shard(pl_, rank, world, err, errlen) : create(rank, world, opt_.precision, err, errlen);
+    if (rc) return rc;
+    // (a pass runs on a thread of its own: the buffers below belong on the plan's device)
+    if (hipSetDevice(pl_->device) != hipSuccess) return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot select device %d", pl_->device);
+    const int64_t n_slots = pl_->info.slot_end - pl_->info.slot_begin;
+    if (n_slots > 0) {
+        if (!out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+        if (n_slots > d_out_cap_) {
+            (void)hipFree(d_out_);
+            d_out_ = nullptr;
+            d_out_cap_ = 0;
+            hipError_t he = hipMalloc(&d_out_, sizeof(double) * (size_t)n_slots);
+            if (he != hipSuccess) {
+                (void)hipGetLastError();
+                return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: %s: cannot allocate %.2f GB for the results of shard %d of %d",
+                                hipGetErrorString(he), 8e-9 * (double)n_slots, (int)rank, (int)world);
+            }
+            d_out_cap_ = n_slots;
+        }
+        rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);
+        int64_t queued = 0, cap = 0;
+        if (rc == FF_OK && ff_plan_refined_pairs(pl_, &queued, &cap) == FF_OK && queued > cap) {
+            // mostly replicates: binary64 from here on (run_plan_to_host does the same for one shard)
+            opt_.precision = FF_PRECISION_EXACT64;
+            rc = create(rank, world, FF_PRECISION_EXACT64, err, errlen);
+            if (rc == FF_OK) rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);
+        }
+        if (rc) return rc;
+        hipError_t he = hipMemcpy(out, d_out_, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            (void)hipGetLastError();
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
+        }
+    }
+    if (info) *info = pl_->info;
+    return FF_OK;
 }
 
 int ff::device_count()

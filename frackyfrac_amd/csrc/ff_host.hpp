@@ -50,6 +50,33 @@ int unifrac_leaves_info(const ff_tree *tree, int64_t n_samples, const int64_t *l
                         bool shard_local = false);
 int run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recreate_exact64, double *out,
                      ff_plan_info *info, char *err, size_t errlen, bool shard_local = false);
+// One device's worker for a pair space that is computed shard by shard (the CLI's passes):
+// stage A and the staging happen once, every further shard only re-targets the plan
+// (ff_plan_set_shard).  If a shard's refinement queue overflows (a data set of replicates) the
+// runner switches to EXACT64 for good.
+class ShardRunner {
+public:
+    ShardRunner(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr, const int64_t *leaf_idx,
+                const double *leaf_val, int leave_unnormalized, const ff_options &opt);
+    ~ShardRunner();
+    ShardRunner(const ShardRunner &) = delete;
+    ShardRunner &operator=(const ShardRunner &) = delete;
+    // distances of shard `rank` of `world` into out[0 .. slot_end - slot_begin) (host memory)
+    int run(int32_t rank, int32_t world, double *out, ff_plan_info *info, char *err, size_t errlen);
+
+private:
+    int create(int32_t rank, int32_t world, int precision, char *err, size_t errlen);
+    const ff_tree *tree_;
+    int64_t n_;
+    const int64_t *lp_, *li_;
+    const double *lv_;
+    int unnorm_;
+    ff_options opt_;
+    ff_plan *pl_ = nullptr;
+    double *d_out_ = nullptr;
+    int64_t d_out_cap_ = 0;
+};
+
 // Number of HIP devices visible (0 when there is none).
 int device_count();
 // Brings the HIP context of the first `want` devices up (errors are left for the first real call).

@@ -158,6 +158,12 @@ int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int
 void ff_plan_destroy(ff_plan *plan);
 int ff_plan_info_get(const ff_plan *plan, ff_plan_info *info);
 
+/* Re-targets a staged plan at shard `rank` of `world`: the staged matrix stays where it is, the
+ * work schedule and the accumulators are rebuilt (milliseconds).  Lets one staging serve every
+ * shard of a pair space too large for one pass (the lazy iter.Seq of unifrac.go:209-228 becomes
+ * a loop over shards), or a rank take over another rank's rows.  Synchronises the device. */
+int ff_plan_set_shard(ff_plan *plan, int32_t rank, int32_t world, char *err, size_t errlen);
+
 /*
  * One pass of the hot path over the staged inputs: launches the pair kernels on
  * `stream` (a hipStream_t; NULL = the null stream) and returns without

@@ -637,6 +637,45 @@ def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch,
         assert np.array_equal(a.abnd, b.abnd)
 
 
+@pytest.mark.parametrize("case", ["weighted-fixed32", "unweighted-mfma", "unweighted-sad", "weighted-exact64", "sparse"])
+def test_one_staging_serves_every_shard(monkeypatch, case):
+    """ff_plan_set_shard: the staged matrix stays, schedule and accumulators are rebuilt; every
+    shard of 1, 2 and 7 reproduces its slice of the whole, in any order, back and forth."""
+    import torch
+
+    weighted = case.startswith("weighted") or case == "sparse"
+    prec = "exact64" if case.endswith("exact64") else "fixed32"
+    if case == "unweighted-sad":
+        monkeypatch.setenv("FF_UNWEIGHTED_MFMA", "0")
+    if case == "sparse":
+        nodes, ip, on, ft = synth_problem(330, 6000, 0.004, 12)
+    else:
+        nodes, ip, on, ft = synth_problem(330, 700, 0.2, 12)
+    n = 330
+    plan = ff.Plan(nodes, weighted, precision=prec)
+    assert plan.info.kernel == {"weighted-fixed32": 0, "unweighted-mfma": 2, "unweighted-sad": 0, "weighted-exact64": 1,
+                                "sparse": 3}[case]
+    def run():
+        out = torch.full((max(plan.n_slots, 1),), np.nan, dtype=torch.float64, device="cuda")
+        if plan.n_slots:
+            plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        return out[:plan.n_slots].cpu().numpy()
+    whole = run()
+    assert np.array_equal(whole, ff.unifrac_dists(nodes, weighted, precision=prec), equal_nan=True)
+    for world in (7, 2, 1):
+        got = np.full(ff.num_pairs(n), np.nan)
+        for r in reversed(range(world)):
+            plan.set_shard(r, world)
+            a, b = ff.shard_slots(n, r, world)
+            assert (plan.info.slot_begin, plan.info.slot_end) == (a, b) and plan.n_slots == b - a
+            got[a:b] = run()
+        assert np.array_equal(got, whole, equal_nan=True)
+    with pytest.raises(L.FFError):
+        plan.set_shard(3, 3)
+    plan.close()
+
+
 def test_out_of_device_memory_is_an_error_not_a_crash():
     """600,000 samples = 1.8e11 pairs: the accumulators alone would take 720 GB.  The plan
     must fail with a message, free what it had staged, and leave the device usable."""
