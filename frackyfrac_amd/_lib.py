@@ -66,6 +66,7 @@ SIGNATURES = {
     "ff_plan_timing_collect": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int32)]),
     "ff_plan_refined_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "ff_plan_set_shard": (c_int, [c_void_p, c_int32, c_int32, c_char_p, c_size_t]),
+    "ff_plan_run_host": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_tree_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_tree_read_file": (c_int, [c_char_p, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_tree_free": (None, [c_void_p]),

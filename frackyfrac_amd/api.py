@@ -320,6 +320,14 @@ class Plan:
         L.check(L.lib().ff_plan_set_shard(self._h, int(rank), int(world), err, L.ERRLEN), err)
         L.lib().ff_plan_info_get(self._h, ctypes.byref(self.info))
 
+    def run_host(self) -> np.ndarray:
+        """The current shard's distances as a host array (ff_plan_run_host): blocking, no device
+        memory on the caller's side."""
+        out = np.empty(self.n_slots, dtype=np.float64)
+        err = L.errbuf()
+        L.check(L.lib().ff_plan_run_host(self._h, out.ctypes.data, err, L.ERRLEN), err)
+        return out
+
     def run(self, d_out_ptr: int, stream: int = 0, timed: bool = False) -> None:
         """One pass of the hot path; d_out_ptr is a device pointer to n_slots doubles,
         stream a hipStream_t handle (0 = null stream).  Asynchronous."""

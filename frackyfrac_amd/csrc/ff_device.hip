@@ -64,6 +64,8 @@ struct ff_plan {
     Item *d_items = nullptr;
     int32_t *d_item_ptr = nullptr;
     int32_t shard_rank = 0, shard_world = 1;
+    double *d_host_out = nullptr;  // ff_plan_run_host's device buffer
+    int64_t host_out_cap = 0;
     int n_workgroups = 0;
     int waves_per_wg = WAVES_PER_WG;
     size_t lds_bytes = 0;
@@ -311,6 +313,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_len_rows);
+    (void)hipFree(pl->d_host_out);
     (void)hipFree(pl->d_xtiles);
     for (auto &e : pl->events) {
         (void)hipEventDestroy(e.first);
@@ -1139,6 +1142,35 @@ int ff_plan_run(ff_plan *pl, void *stream, double *d_out, char *err, size_t errl
 {
     if (!pl) return ff::fail(FF_ERR_ARG, err, errlen, "null plan");
     return plan_run_impl(pl, (hipStream_t)stream, d_out, false, err, errlen);
+}
+
+int ff_plan_run_host(ff_plan *pl, double *out, char *err, size_t errlen)
+{
+    if (!pl) return ff::fail(FF_ERR_ARG, err, errlen, "null plan");
+    const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
+    if (n_slots <= 0) return FF_OK;
+    if (!out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+    int cur = -1;
+    FF_HIP(hipGetDevice(&cur));
+    if (cur != pl->device) FF_HIP(hipSetDevice(pl->device));
+    if (n_slots > pl->host_out_cap) {
+        (void)hipFree(pl->d_host_out);
+        pl->d_host_out = nullptr;
+        pl->host_out_cap = 0;
+        FF_ALLOC(pl->d_host_out, sizeof(double) * (size_t)n_slots, "the results");
+        pl->host_out_cap = n_slots;
+    }
+    int rc = plan_run_impl(pl, nullptr, pl->d_host_out, false, err, errlen);
+    if (rc == FF_OK) {
+        FF_HIP(hipMemcpy(out, pl->d_host_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost));
+        int64_t queued = 0, cap = 0;
+        if (ff_plan_refined_pairs(pl, &queued, &cap) == FF_OK && queued > cap)
+            rc = ff::fail(FF_ERR_PRECISION, err, errlen,
+                          "%lld nearly identical pairs, %lld can be re-computed exactly: stage this problem with "
+                          "FF_PRECISION_EXACT64", (long long)queued, (long long)cap);
+    }
+    if (cur != pl->device) (void)hipSetDevice(cur);
+    return rc;
 }
 
 int ff_plan_run_timed(ff_plan *pl, void *stream, double *d_out, char *err, size_t errlen)

@@ -39,7 +39,9 @@ typedef enum ff_status {
     FF_ERR_SPECIES = 3, /* validateSpecies failure                                  */
     FF_ERR_DEVICE = 4,  /* no GPU, HIP error, out of device memory                  */
     FF_ERR_IO = 5,      /* file open/read/write                                     */
-    FF_ERR_INTERNAL = 6
+    FF_ERR_INTERNAL = 6,
+    FF_ERR_PRECISION = 7 /* ff_plan_run_host: more nearly identical pairs than the FIXED32 plan can
+                            re-compute exactly (a data set of replicates); stage an EXACT64 plan */
 } ff_status;
 
 /* ------------------------------------------------------------------------- *
@@ -171,6 +173,11 @@ int ff_plan_set_shard(ff_plan *plan, int32_t rank, int32_t world, char *err, siz
  * doubles: d_out[k - slot_begin] receives the distance of global slot k.
  */
 int ff_plan_run(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
+
+/* ff_plan_run for callers without device memory of their own (a cgo host): runs the current
+ * shard on the null stream, waits, and copies its slot_end - slot_begin distances to `out`
+ * (HOST memory).  Returns FF_ERR_PRECISION instead of results that could miss the tolerance. */
+int ff_plan_run_host(ff_plan *plan, double *out, char *err, size_t errlen);
 
 /*
  * Like ff_plan_run but brackets the dominant kernel (the pair-tile reduction) with

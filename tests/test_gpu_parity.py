@@ -670,6 +670,7 @@ def test_one_staging_serves_every_shard(monkeypatch, case):
             a, b = ff.shard_slots(n, r, world)
             assert (plan.info.slot_begin, plan.info.slot_end) == (a, b) and plan.n_slots == b - a
             got[a:b] = run()
+            assert np.array_equal(plan.run_host(), got[a:b], equal_nan=True)   # ff_plan_run_host: the same, to host memory
         assert np.array_equal(got, whole, equal_nan=True)
     with pytest.raises(L.FFError):
         plan.set_shard(3, 3)
