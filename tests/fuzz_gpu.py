@@ -1,7 +1,7 @@
 """Randomised parity sweep on a GPU box: random shapes (1..700 samples, 2..4000 leaves), densities,
 leaf subsets (compaction), empty and duplicated samples, -l, shards, every precision -- each case
 against the oracle (bit-exact for EXACT64 and unweighted, 1e-6 relative for weighted FIXED32).
-Usage: fuzz_gpu.py SEED CASES   (12,300 cases ran clean at the end of round 1)"""
+Usage: python tests/fuzz_gpu.py SEED CASES  (a script, not collected by pytest)   (12,300 cases ran clean at the end of round 1)"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import frackyfrac_amd as ff
