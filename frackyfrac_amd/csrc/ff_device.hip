@@ -90,6 +90,9 @@ struct ff_plan {
     int m_digits = 0;
     MItem *d_mitems = nullptr;
     int32_t *d_mitem_ptr = nullptr;
+    uint32_t *d_partial = nullptr;  // small problems: private partial tiles of the ranges
+    int32_t *d_ptiles = nullptr, *d_ptile_ptr = nullptr;
+    int n_ptiles = 0;
     int n_mitems = 0, n_mgroups = 0;
     // EXACT64
     double *d_DT = nullptr;
@@ -310,6 +313,9 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_K8);
     (void)hipFree(pl->d_mitems);
     (void)hipFree(pl->d_mitem_ptr);
+    (void)hipFree(pl->d_partial);
+    (void)hipFree(pl->d_ptiles);
+    (void)hipFree(pl->d_ptile_ptr);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_len_rows);
@@ -630,12 +636,27 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_mitems);
     free_and_null(pl->d_mitem_ptr);
     free_and_null(pl->d_num);
+    free_and_null(pl->d_partial);
+    free_and_null(pl->d_ptiles);
+    free_and_null(pl->d_ptile_ptr);
+    pl->n_ptiles = 0;
     const int64_t slabs = pl->m_ldb / M_KSLAB;
     const int G = inf.n_compute_units;  // one 8-wave workgroup per CU
     pl->n_mgroups = G;
     std::vector<MItem> mi;
     std::vector<int32_t> mptr;
-    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr);
+    std::vector<int32_t> ptiles, pptr;
+    const bool want_partials = env_int("FF_MFMA_PARTIALS", 1) != 0;
+    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr,
+                                                 want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr);
+    if (!pptr.empty()) {
+        pl->n_ptiles = (int)pptr.size() - 1;
+        FF_HIP(hipMalloc(&pl->d_partial, sizeof(uint32_t) * (size_t)pptr.back() * M_TILE_I * M_TILE_J));
+        FF_HIP(hipMalloc(&pl->d_ptiles, sizeof(int32_t) * ptiles.size()));
+        FF_HIP(hipMalloc(&pl->d_ptile_ptr, sizeof(int32_t) * pptr.size()));
+        FF_HIP(hipMemcpy(pl->d_ptiles, ptiles.data(), sizeof(int32_t) * ptiles.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(pl->d_ptile_ptr, pptr.data(), sizeof(int32_t) * pptr.size(), hipMemcpyHostToDevice));
+    }
     pl->n_mitems = (int)mi.size();
     inf.n_tiles = n_mtiles;
     inf.n_items = (int64_t)mi.size();
@@ -1038,7 +1059,10 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             if (pl->n_mitems > 0)
                 pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
                     pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
-                    inf.row_begin, inf.row_end, inf.slot_begin);
+                    pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin);
+            if (pl->n_ptiles > 0)
+                reduce_partials_kernel<<<dim3(M_TILE_I * M_TILE_J / 256, (unsigned)pl->n_ptiles), dim3(256), 0, st>>>(
+                    pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin);
         } else if (inf.n_items > 0 && pl->sparse)
             pair_sad_sparse_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(512, 2)
 void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
                              int64_t plane, const MItem *__restrict__ items,
                              const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
-                             uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
-                             int64_t slot_begin)
+                             uint32_t *__restrict__ num, uint32_t *__restrict__ partial, int64_t row_begin,
+                             int64_t row_end, int64_t slot_begin)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,6 +141,27 @@ void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__rest
             }
         }
         // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
+        if (item.pad > 0) {
+            // private partial tile (small problems): this range's share of every pair of the tile,
+            // plain stores, 128-byte runs; reduce_partials_kernel applies the shard and diagonal masks
+            uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int64_t i = item.i0 + lr;
+                    const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int lc = wj * 64 + n * 32 + (lane & 31);
+                        uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
+                        if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
+                        pt[lr * M_TILE_J + lc] = wi_ + (item.first ? (uint32_t)W[item.j0 + lc] : 0u) - 2u * common;
+                    }
+                }
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -160,4 +181,19 @@ void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__rest
                 }
             }
     }
+}
+
+// Sums the private partial tiles of a small problem: tile t = (tiles[2t], tiles[2t+1]) owns the
+// partials tile_ptr[t] .. tile_ptr[t+1]; one thread per pair of the tile.
+__global__ void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t *__restrict__ tiles,
+                                       const int32_t *__restrict__ tile_ptr, uint32_t *__restrict__ num,
+                                       int64_t row_begin, int64_t row_end, int64_t slot_begin)
+{
+    const int t = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // lr * M_TILE_J + lc
+    const int64_t i = tiles[2 * t] + idx / M_TILE_J, j = tiles[2 * t + 1] + idx % M_TILE_J;
+    if (i < row_begin || i >= row_end || j >= i) return;
+    uint32_t s = 0;
+    for (int p = tile_ptr[t]; p < tile_ptr[t + 1]; ++p) s += partial[(int64_t)p * (M_TILE_I * M_TILE_J) + idx];
+    num[i * (i - 1) / 2 - slot_begin + j] = s;
 }

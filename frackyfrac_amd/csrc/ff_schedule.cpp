@@ -188,7 +188,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
 
 
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
-                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr)
+                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
+                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr)
 {
     // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
     // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
@@ -236,6 +237,14 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
             per[(size_t)g].push_back(make_item(r * G + local, 0, slabs));
         }
     const int64_t rem_units = units - rounds * G;
+    // A problem too small for even one round is all remainder: every tile is cut into about
+    // G / tiles ranges, and that many workgroups adding into the same 32,768 accumulators at
+    // once spend more time in (memory-side) atomics than in their few slabs of MFMA.  Its ranges
+    // get private partial tiles instead (MItem.pad = ordinal + 1), summed by a reduce kernel.
+    const bool private_partials = partial_tiles && partial_ptr && rounds == 0 && groups == 1 && rem_units > 0;
+    int32_t ordinal = 0;
+    if (partial_tiles) partial_tiles->clear();
+    if (partial_ptr) partial_ptr->clear();
     if (rem_units > 0) {
         const int64_t total = rem_units * slabs;
         const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
@@ -245,11 +254,22 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
             while (a2 < b2) {
                 const int64_t unit = a2 / slabs, s0 = a2 % slabs;
                 const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
-                per[(size_t)g].push_back(make_item(rounds * G + unit, s0, s1));
+                MItem itm = make_item(rounds * G + unit, s0, s1);
+                if (private_partials) {
+                    // ranges are created in ascending (unit, slab) order: a unit's ordinals are contiguous
+                    while ((int64_t)partial_ptr->size() <= unit) {
+                        partial_ptr->push_back(ordinal);
+                        partial_tiles->push_back(tiles[(size_t)partial_tiles->size() / 2].i0);
+                        partial_tiles->push_back(tiles[(size_t)partial_tiles->size() / 2].j0);
+                    }
+                    itm.pad = ++ordinal;
+                }
+                per[(size_t)g].push_back(itm);
                 a2 += s1 - s0;
             }
         }
     }
+    if (private_partials) partial_ptr->push_back(ordinal);
     std::vector<MItem> &mi = *items;
     std::vector<int32_t> &mptr = *item_ptr;
     mi.clear();
@@ -281,7 +301,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
     int64_t n = 0;
     if (kernel == FF_KERNEL_MFMA_I8) {
         std::vector<MItem> items;
-        const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, rows, n_digits, n_cu, &items, &ptr);
+        const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, rows, n_digits, n_cu, &items, &ptr, nullptr, nullptr);
         if (n_tiles_out) *n_tiles_out = nt;
         n = (int64_t)items.size();
         if (n > max_items) return -n;

@@ -54,7 +54,7 @@ struct MItem {
     int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
     int32_t d0, nd;  // nd in {1, 2}
     int32_t first;
-    int32_t pad;
+    int32_t pad;     // 0: add into num[] atomically; p > 0: store into private partial tile p - 1
 };
 static_assert(sizeof(MItem) == 32, "MItem must be 32 bytes");
 
@@ -70,8 +70,11 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std
                     std::vector<int32_t> *item_ptr, double *elements, int xcds = 0, int wpw = WAVES_PER_WG);
 int waves_per_wg();
 // Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
+// partial_tiles / partial_ptr (may be null): filled when the ranges get private partial tiles
+// (MItem.pad = ordinal + 1): (i0, j0) per tile and, per tile, its first ordinal (+ the total).
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
-                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr);
+                            std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
+                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr);
 
 }  // namespace sched
 }  // namespace ff
