@@ -60,7 +60,8 @@ int waves_per_wg()
 // Ranges that share a tile add their partial sums atomically; the sums are integers, so
 // the result does not depend on the order.
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
-                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw)
+                    std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw,
+                    bool two_planes)
 {
     std::vector<Tile> wide, rest;
     for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
@@ -107,7 +108,13 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                         const int u = (int)(wg * wpw + w);
                         const size_t before = per[(size_t)u].size();
                         push(u, t, std::min(rows, x * part), std::min(rows, (x + 1) * part));
-                        if (per[(size_t)u].size() > before) per[(size_t)u].back().flags |= 2u;
+                        if (per[(size_t)u].size() > before) {
+                            uint32_t &fl = per[(size_t)u].back().flags;
+                            fl |= 2u;
+                            // two halves, two planes of accumulators: each half stores its sums
+                            // plainly into its own plane instead of adding atomically
+                            if (two_planes && xcds == 2 && part < rows) fl = (fl & ~1u) | (x == 1 ? 8u : 0u);
+                        }
                     }
                 }
             done = rounds * per_round;
@@ -312,7 +319,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
         std::vector<Item> items;
         double elements = 0;
-        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg());
+        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg(), false);
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);

@@ -677,6 +677,34 @@ def test_one_staging_serves_every_shard(monkeypatch, case):
     plan.close()
 
 
+def test_two_accumulator_planes_equal_atomics(monkeypatch):
+    """4,096 samples = 1,088 pair tiles, enough for a main round: the halves of every split tile
+    store into two planes (item flag 8) instead of adding atomically.  Same distances as with
+    FF_TWO_PLANES=0, also after re-targeting the plan at shards, and the oracle's on a sample."""
+    import torch
+
+    nodes, ip, on, ft = synth_problem(4096, 300, 0.2, 31)
+    n = 4096
+    monkeypatch.setenv("FF_TWO_PLANES", "0")
+    want = ff.unifrac_dists(nodes, True, precision="fixed32")
+    monkeypatch.setenv("FF_TWO_PLANES", "1")
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.n_tiles >= 1024 and plan.info.kernel == 0
+    assert np.array_equal(plan.run_host(), want)
+    for world in (2, 3):
+        got = np.full_like(want, np.nan)
+        for r in range(world):
+            plan.set_shard(r, world)
+            a, b = ff.shard_slots(n, r, world)
+            got[a:b] = plan.run_host()
+        assert np.array_equal(got, want)
+    plan.close()
+    P = ff.num_pairs(n)
+    for a in (0, P // 2, P - 50_000):
+        ref = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 50_000)
+        assert rel_err(want[a:a + 50_000], ref) <= WEIGHTED_RTOL
+
+
 def test_out_of_device_memory_is_an_error_not_a_crash():
     """600,000 samples = 1.8e11 pairs: the accumulators alone would take 720 GB.  The plan
     must fail with a message, free what it had staged, and leave the device usable."""
