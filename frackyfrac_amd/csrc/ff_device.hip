@@ -61,7 +61,8 @@ struct ff_plan {
     uint32_t *d_QT = nullptr;
     unsigned long long *d_W = nullptr;
     uint32_t *d_num = nullptr;
-    uint32_t *d_num2 = nullptr;  // second plane (second branch half of split tiles), or null
+    int n_planes = 1;            // planes of accumulators in d_num (the ranges of a split tile own one each)
+    int64_t plane_stride = 0;
     Item *d_items = nullptr;
     int32_t *d_item_ptr = nullptr;
     int32_t shard_rank = 0, shard_world = 1;
@@ -299,7 +300,6 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_QT);
     (void)hipFree(pl->d_W);
     (void)hipFree(pl->d_num);
-    (void)hipFree(pl->d_num2);
     (void)hipFree(pl->d_items);
     (void)hipFree(pl->d_item_ptr);
     (void)hipFree(pl->d_stamps);
@@ -592,7 +592,6 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_items);
     free_and_null(pl->d_item_ptr);
     free_and_null(pl->d_num);
-    free_and_null(pl->d_num2);
     free_and_null(pl->d_stamps);
     std::vector<Tile> tiles;
     build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
@@ -605,22 +604,23 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     inf.n_wave_slots = U;
     std::vector<Item> items;
     std::vector<int32_t> item_ptr;
-    const bool two_planes = !pl->sparse && env_int("FF_TWO_PLANES", 1) != 0;
-    build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg, two_planes);
+    // up to 255 planes of accumulators (FF_PLANES; 1 = atomics only), within 1 GiB
+    int max_planes = pl->sparse ? 1 : std::min(255, std::max(1, env_int("FF_PLANES", 255)));
+    while (max_planes > 1 && (double)max_planes * 4.0 * (double)std::max<int64_t>(n_slots, 1) > 1073741824.0) --max_planes;
+    build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg,
+                   max_planes > 1 ? max_planes : 0);
     inf.n_items = (int64_t)items.size();
-    bool uses_plane2 = false;
-    for (const Item &it : items) uses_plane2 |= (it.flags & 8u) != 0;
+    pl->n_planes = 1;
+    for (const Item &it : items) pl->n_planes = std::max(pl->n_planes, (int)((it.flags >> 3) & 255u) + 1);
+    pl->plane_stride = std::max<int64_t>(n_slots, 1);
     FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
     FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
     if (!items.empty())
         FF_HIP(hipMemcpy(pl->d_items, items.data(), sizeof(Item) * items.size(), hipMemcpyHostToDevice));
     FF_HIP(hipMemcpy(pl->d_item_ptr, item_ptr.data(), sizeof(int32_t) * item_ptr.size(), hipMemcpyHostToDevice));
-    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
-    if (uses_plane2) {
-        // slots of tiles that are not split this way are never written in the second plane: zero once
-        FF_ALLOC(pl->d_num2, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the second plane of accumulators");
-        FF_HIP(hipMemset(pl->d_num2, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1)));
-    }
+    FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)pl->plane_stride * (size_t)pl->n_planes, "the pair accumulators");
+    // slots of tiles that are not split that way are never written in planes 1..: zero once
+    FF_HIP(hipMemset(pl->d_num, 0, sizeof(uint32_t) * (size_t)pl->plane_stride * (size_t)pl->n_planes));
     if (env_int("FF_STAMPS", 0)) {
         FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
         FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
@@ -1081,13 +1081,13 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         else if (inf.n_items > 0)
             (pl->waves_per_wg == L_WAVES_PER_WG ? (env_int("FF_REG12", 0) ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
-                pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->d_num2, inf.row_begin, inf.row_end,
+                pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
         const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
         if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long), st));
         finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(
-            pl->d_num, pl->d_num2, pl->d_W, pl->weighted, inf.slot_begin, n_slots, d_out, pl->refine ? pl->d_indptr : nullptr,
+            pl->d_num, pl->n_planes, pl->plane_stride, pl->d_W, pl->weighted, inf.slot_begin, n_slots, d_out, pl->refine ? pl->d_indptr : nullptr,
             pl->d_refine_list, pl->d_refine_count, pl->refine_cap);
         if (pl->refine)
             refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * 8)), dim3(64), 0, st>>>(

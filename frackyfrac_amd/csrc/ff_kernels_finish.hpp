@@ -13,7 +13,7 @@ constexpr double REFINE_REL = 0.5e-6;   // half of the 1e-6 relative bar of BASE
 constexpr double REFINE_SIGMAS = 6.0;
 
 __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
-                                      const uint32_t *__restrict__ num2,  // second plane of sums, or null
+                                      int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
                                       const unsigned long long *__restrict__ W, int weighted,
                                       int64_t slot_begin, int64_t n_slots,
                                       double *__restrict__ out,
@@ -27,7 +27,9 @@ __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
          t += (int64_t)gridDim.x * blockDim.x) {
         int64_t i, j;
         slot_to_pair(slot_begin + t, &i, &j);
-        const unsigned long long u = num2 ? (unsigned long long)(uint32_t)(num[t] + num2[t]) : num[t];
+        uint32_t u32 = num[t];
+        for (int q = 1; q < n_planes; ++q) u32 += num[(int64_t)q * plane_stride + t];
+        const unsigned long long u = u32;
         const unsigned long long w = W[i] + W[j];
         double d;
         if (weighted) {

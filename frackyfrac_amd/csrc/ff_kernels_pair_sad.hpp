@@ -19,7 +19,7 @@ template <int NC> __device__ __forceinline__ RowVec<NC> load_row(const uint32_t 
 // One work item: a 32 x (64*NC) pair tile over the branch rows [k0, k1).
 template <int NC, int KS = KSTEP>
 __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
-                                         uint32_t *__restrict__ num, uint32_t *__restrict__ num2,
+                                         uint32_t *__restrict__ num, int64_t plane_stride,
                                          int64_t row_begin, int64_t row_end,
                                          int64_t slot_begin, int sync_trips, int lane)
 {
@@ -95,9 +95,9 @@ __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_
     // epilogue: slot of (i, j) is i(i-1)/2 + j (common.IterPairs, common.go:21-31)
     const int64_t j = item.j0 + NC * lane;
     const bool atomic = item.flags & 1u;
-    // flag bit 3: this range is the tile's second half and owns the second plane of accumulators
+    // flag bits 3..10: the plane of accumulators this range owns among the ranges of its tile
     // (plain stores instead of memory-side atomics; finish_fixed32_kernel adds the planes)
-    uint32_t *dst = (item.flags & 8u) ? num2 : num;
+    uint32_t *dst = num + (int64_t)((item.flags >> 3) & 255u) * plane_stride;
 #pragma unroll
     for (int r = 0; r < TILE_I; ++r) {
         const int64_t i = item.i0 + r;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void run_item(const uint32_t *__restrict__ QT, int64_
 __global__ __launch_bounds__(WAVES_PER_WG * 64, 2)
 void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                      const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                     uint32_t *__restrict__ num, uint32_t *__restrict__ num2, int64_t row_begin, int64_t row_end,
+                     uint32_t *__restrict__ num, int64_t plane_stride, int64_t row_begin, int64_t row_end,
                      int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
 {
     const int lane = threadIdx.x & 63;
@@ -138,9 +138,9 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
-            run_item<2>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane);
+            run_item<2>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
         else
-            run_item<4>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane);
+            run_item<4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
     }
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -149,7 +149,7 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
 __global__ __launch_bounds__(L_WAVES_PER_WG * 64)
 void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
                      const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                     uint32_t *__restrict__ num, uint32_t *__restrict__ num2, int64_t row_begin, int64_t row_end,
+                     uint32_t *__restrict__ num, int64_t plane_stride, int64_t row_begin, int64_t row_end,
                      int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
 {
     const int lane = threadIdx.x & 63;
@@ -161,9 +161,9 @@ void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
-            run_item<2, 4>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane);
+            run_item<2, 4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
         else
-            run_item<4, 4>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane);
+            run_item<4, 4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
     }
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -181,7 +181,7 @@ void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
 // Same tiles, same integers.
 template <int NC>
 __device__ __forceinline__ void run_item_lds(const uint32_t *__restrict__ QT, int64_t ld, const Item item,
-                                             uint32_t *__restrict__ num, uint32_t *__restrict__ num2,
+                                             uint32_t *__restrict__ num, int64_t plane_stride,
                                              int64_t row_begin, int64_t row_end,
                                              int64_t slot_begin, int sync_trips, int lane,
                                              uint32_t __attribute__((address_space(3))) *ring)
@@ -279,9 +279,9 @@ __device__ __forceinline__ void run_item_lds(const uint32_t *__restrict__ QT, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int64_t j = item.j0 + NC * lane;
     const bool atomic = item.flags & 1u;
-    // flag bit 3: this range is the tile's second half and owns the second plane of accumulators
+    // flag bits 3..10: the plane of accumulators this range owns among the ranges of its tile
     // (plain stores instead of memory-side atomics; finish_fixed32_kernel adds the planes)
-    uint32_t *dst = (item.flags & 8u) ? num2 : num;
+    uint32_t *dst = num + (int64_t)((item.flags >> 3) & 255u) * plane_stride;
 #pragma unroll
     for (int r = 0; r < TILE_I; ++r) {
         const int64_t i = item.i0 + r;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void run_item_lds(const uint32_t *__restrict__ QT, in
 __global__ __launch_bounds__(L_WAVES_PER_WG * 64)
 void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                          const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
-                         uint32_t *__restrict__ num, uint32_t *__restrict__ num2, int64_t row_begin, int64_t row_end,
+                         uint32_t *__restrict__ num, int64_t plane_stride, int64_t row_begin, int64_t row_end,
                          int64_t slot_begin, unsigned long long *__restrict__ stamps, int sync_trips)
 {
     extern __shared__ uint32_t lds_ring[];  // L_WAVES_PER_WG rings of L_RING KiB
@@ -316,9 +316,9 @@ void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
-            run_item_lds<2>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane, ring);
+            run_item_lds<2>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane, ring);
         else
-            run_item_lds<4>(QT, ld, item, num, num2, row_begin, row_end, slot_begin, sync_trips, lane, ring);
+            run_item_lds<4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane, ring);
     }
     if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
 }

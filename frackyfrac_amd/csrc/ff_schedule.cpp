@@ -61,7 +61,7 @@ int waves_per_wg()
 // the result does not depend on the order.
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                     std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw,
-                    bool two_planes)
+                    int max_planes)
 {
     std::vector<Tile> wide, rest;
     for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
@@ -111,9 +111,9 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                         if (per[(size_t)u].size() > before) {
                             uint32_t &fl = per[(size_t)u].back().flags;
                             fl |= 2u;
-                            // two halves, two planes of accumulators: each half stores its sums
-                            // plainly into its own plane instead of adding atomically
-                            if (two_planes && xcds == 2 && part < rows) fl = (fl & ~1u) | (x == 1 ? 8u : 0u);
+                            // one plane of accumulators per range: each stores its sums plainly
+                            // into its own plane instead of adding atomically
+                            if (xcds <= max_planes && part < rows) fl = (fl & ~1u) | ((uint32_t)x << 3);
                         }
                     }
                 }
@@ -152,8 +152,11 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                         // neighbouring tiles (same columns -> one shared vector row per branch)
                         const int u = (int)(sidx * per_round + q);
                         push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
-                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1)
-                            per[(size_t)u].back().flags |= 2u;
+                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1) {
+                            uint32_t &fl = per[(size_t)u].back().flags;
+                            fl |= 2u;
+                            if (S > 1 && S <= max_planes) fl = (fl & ~1u) | ((uint32_t)sidx << 3);
+                        }
                     }
                 }
             done = rounds * per_round;
@@ -319,7 +322,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
         std::vector<Item> items;
         double elements = 0;
-        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg(), false);
+        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg(), 0);
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);

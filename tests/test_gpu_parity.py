@@ -680,14 +680,14 @@ def test_one_staging_serves_every_shard(monkeypatch, case):
 def test_two_accumulator_planes_equal_atomics(monkeypatch):
     """4,096 samples = 1,088 pair tiles, enough for a main round: the halves of every split tile
     store into two planes (item flag 8) instead of adding atomically.  Same distances as with
-    FF_TWO_PLANES=0, also after re-targeting the plan at shards, and the oracle's on a sample."""
+    FF_PLANES=1 (atomics only), also after re-targeting the plan at shards, and the oracle's on a sample."""
     import torch
 
     nodes, ip, on, ft = synth_problem(4096, 300, 0.2, 31)
     n = 4096
-    monkeypatch.setenv("FF_TWO_PLANES", "0")
+    monkeypatch.setenv("FF_PLANES", "1")
     want = ff.unifrac_dists(nodes, True, precision="fixed32")
-    monkeypatch.setenv("FF_TWO_PLANES", "1")
+    monkeypatch.setenv("FF_PLANES", "255")
     plan = ff.Plan(nodes, True, precision="fixed32")
     assert plan.info.n_tiles >= 1024 and plan.info.kernel == 0
     assert np.array_equal(plan.run_host(), want)
