@@ -95,6 +95,7 @@ struct ff_plan {
     uint32_t *d_partial = nullptr;  // small problems: private partial tiles of the ranges
     int32_t *d_ptiles = nullptr, *d_ptile_ptr = nullptr;
     int n_ptiles = 0;
+    bool m_all_private = false;  // every item has a private partial tile
     int n_mitems = 0, n_mgroups = 0;
     // EXACT64
     double *d_DT = nullptr;
@@ -678,7 +679,11 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
     FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
     pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
-    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel),
+    pl->m_all_private = !mi.empty();
+    for (const MItem &it : mi) pl->m_all_private = pl->m_all_private && it.pad > 0;
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
     return FF_OK;
@@ -1068,7 +1073,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->mfma) {
             if (pl->n_mitems > 0)
-                pair_common_mfma_kernel<<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
+                (pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>)
+                    <<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
                     pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin);
             if (pl->n_ptiles > 0)

@@ -55,6 +55,10 @@ __device__ __forceinline__ void mfma_wait_vmcnt(int pieces_in_flight_allowed)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ALL_PRIVATE: every item of the launch has a private partial tile (a problem smaller than one
+// round); the epilogue is then the plain stores alone, which keeps that variant's code small --
+// the kernel's speed on such problems turned out to depend on it (35 vs 50 us at C2).
+template <bool ALL_PRIVATE>
 __global__ __launch_bounds__(512, 2)
 void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__restrict__ K8, int64_t ldb,
                              int64_t plane, const MItem *__restrict__ items,
@@ -141,43 +145,33 @@ void pair_common_mfma_kernel(const int8_t *__restrict__ P8, const int8_t *__rest
             }
         }
         // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31
-        if (item.pad > 0) {
-            // private partial tile (small problems): this range's share of every pair of the tile,
-            // plain stores, 128-byte runs; reduce_partials_kernel applies the shard and diagonal masks
-            uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int64_t i = item.i0 + lr;
-                    const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int lc = wj * 64 + n * 32 + (lane & 31);
-                        uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
-                        if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
-                        pt[lr * M_TILE_J + lc] = wi_ + (item.first ? (uint32_t)W[item.j0 + lc] : 0u) - 2u * common;
-                    }
-                }
-            continue;
-        }
+        // pad > 0: this range's share goes to its private partial tile, every element, plain stores
+        // (reduce_partials_kernel applies the shard and diagonal masks); pad < 0: the tile's only
+        // item stores into num[]; pad == 0: atomic add into num[]
+        const bool priv = ALL_PRIVATE || item.pad > 0;
+        uint32_t *pt = partial + (int64_t)(priv ? item.pad - 1 : 0) * (M_TILE_I * M_TILE_J);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t i = item.i0 + wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i < row_begin || i >= row_end) continue;
+                const int lr = wi * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t i = item.i0 + lr;
+                if (!priv && (i < row_begin || i >= row_end)) continue;
                 const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const int64_t j = item.j0 + wj * 64 + n * 32 + (lane & 31);
-                    if (j >= i) continue;
+                    const int lc = wj * 64 + n * 32 + (lane & 31);
+                    const int64_t j = item.j0 + lc;
+                    if (!priv && j >= i) continue;
                     uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
                     if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
                     // this item's share of result = W_i + W_j - 2 * common, modulo 2^32
                     const uint32_t v = wi_ + (item.first ? (uint32_t)W[j] : 0u) - 2u * common;
-                    if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
+                    if (priv) pt[lr * M_TILE_J + lc] = v;
+                    else if constexpr (!ALL_PRIVATE) {
+                        if (item.pad < 0) num[i * (i - 1) / 2 - slot_begin + j] = v;
+                        else if (v) atomicAdd(&num[i * (i - 1) / 2 - slot_begin + j], v);
+                    }
                 }
             }
     }

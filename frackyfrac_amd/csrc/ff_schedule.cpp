@@ -244,14 +244,17 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     for (int64_t r = 0; r < rounds; ++r)
         for (int g = 0; g < G; ++g) {
             const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
-            per[(size_t)g].push_back(make_item(r * G + local, 0, slabs));
+            MItem itm = make_item(r * G + local, 0, slabs);
+            if (partial_tiles && partial_ptr && groups == 1) itm.pad = -1;
+            per[(size_t)g].push_back(itm);
         }
     const int64_t rem_units = units - rounds * G;
-    // A problem too small for even one round is all remainder: every tile is cut into about
-    // G / tiles ranges, and that many workgroups adding into the same 32,768 accumulators at
-    // once spend more time in (memory-side) atomics than in their few slabs of MFMA.  Its ranges
-    // get private partial tiles instead (MItem.pad = ordinal + 1), summed by a reduce kernel.
-    const bool private_partials = partial_tiles && partial_ptr && rounds == 0 && groups == 1 && rem_units > 0;
+    // Device-scope atomics across XCDs are performed at the memory side and are slow (a problem
+    // too small for even one round, all remainder, spent two thirds of its kernel in them).  With
+    // one digit group a tile of a main round has a single item, which stores plainly
+    // (MItem.pad = -1); the ranges of the remainder get private partial tiles instead
+    // (MItem.pad = ordinal + 1), summed by a reduce kernel.
+    const bool private_partials = partial_tiles && partial_ptr && groups == 1;
     int32_t ordinal = 0;
     if (partial_tiles) partial_tiles->clear();
     if (partial_ptr) partial_ptr->clear();
@@ -268,9 +271,10 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
                 if (private_partials) {
                     // ranges are created in ascending (unit, slab) order: a unit's ordinals are contiguous
                     while ((int64_t)partial_ptr->size() <= unit) {
+                        const size_t t = (size_t)((rounds * G + (int64_t)partial_ptr->size()) % (int64_t)tiles.size());
                         partial_ptr->push_back(ordinal);
-                        partial_tiles->push_back(tiles[(size_t)partial_tiles->size() / 2].i0);
-                        partial_tiles->push_back(tiles[(size_t)partial_tiles->size() / 2].j0);
+                        partial_tiles->push_back(tiles[t].i0);
+                        partial_tiles->push_back(tiles[t].j0);
                     }
                     itm.pad = ++ordinal;
                 }
@@ -279,7 +283,7 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
             }
         }
     }
-    if (private_partials) partial_ptr->push_back(ordinal);
+    if (private_partials && !partial_ptr->empty()) partial_ptr->push_back(ordinal);
     std::vector<MItem> &mi = *items;
     std::vector<int32_t> &mptr = *item_ptr;
     mi.clear();

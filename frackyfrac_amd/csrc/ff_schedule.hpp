@@ -54,7 +54,8 @@ struct MItem {
     int32_t k0, k1;  // bytes (= branches), multiples of M_KSLAB
     int32_t d0, nd;  // nd in {1, 2}
     int32_t first;
-    int32_t pad;     // 0: add into num[] atomically; p > 0: store into private partial tile p - 1
+    int32_t pad;     // 0: add into num[] atomically; -1: store into num[] (the tile's only item);
+                     // p > 0: store into private partial tile p - 1
 };
 static_assert(sizeof(MItem) == 32, "MItem must be 32 bytes");
 
