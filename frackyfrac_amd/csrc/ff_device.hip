@@ -606,7 +606,7 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     std::vector<Item> items;
     std::vector<int32_t> item_ptr;
     // up to 255 planes of accumulators (FF_PLANES; 1 = atomics only), within 1 GiB
-    int max_planes = pl->sparse ? 1 : std::min(255, std::max(1, env_int("FF_PLANES", 255)));
+    int max_planes = std::min(255, std::max(1, env_int("FF_PLANES", 255)));
     while (max_planes > 1 && (double)max_planes * 4.0 * (double)std::max<int64_t>(n_slots, 1) > 1073741824.0) --max_planes;
     build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg,
                    max_planes > 1 ? max_planes : 0);
@@ -1083,7 +1083,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         } else if (inf.n_items > 0 && pl->sparse)
             pair_sad_sparse_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
-                pl->zero_row, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin);
+                pl->zero_row, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end, inf.slot_begin);
         else if (inf.n_items > 0)
             (pl->waves_per_wg == L_WAVES_PER_WG ? (env_int("FF_REG12", 0) ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(

@@ -340,7 +340,7 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
                                                 const uint32_t *__restrict__ arows,
                                                 const uint32_t *__restrict__ aptr16, int64_t aptr_stride,
                                                 const uint32_t *__restrict__ cs16, int32_t zero_row,
-                                                uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                                                uint32_t *__restrict__ num, int64_t plane_stride, int64_t row_begin, int64_t row_end,
                                                 int64_t slot_begin, int lane)
 {
     typedef const uint32_t __attribute__((address_space(4))) *const_u32_ptr;
@@ -423,6 +423,7 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
         for (int c = 0; c < NC; ++c) rj[c] = hi.v[c] - lo.v[c] - z[c];
     }
     const bool atomic = item.flags & 1u;
+    uint32_t *dst = num + (int64_t)((item.flags >> 3) & 255u) * plane_stride;  // the range's plane
 #pragma unroll
     for (int r = 0; r < TILE_I; ++r) {
         const int64_t i = item.i0 + r;
@@ -435,7 +436,7 @@ __device__ __forceinline__ void run_item_sparse(const uint32_t *__restrict__ QT,
             if (atomic) {
                 if (val) atomicAdd(&num[base + c], val);
             } else {
-                num[base + c] = val;
+                dst[base + c] = val;
             }
         }
     }
@@ -446,7 +447,7 @@ void pair_sad_sparse_kernel(const uint32_t *__restrict__ QT, int64_t ld,
                             const Item *__restrict__ items, const int32_t *__restrict__ item_ptr,
                             const uint32_t *__restrict__ arows, const uint32_t *__restrict__ aptr16,
                             int64_t aptr_stride, const uint32_t *__restrict__ cs16, int32_t zero_row,
-                            uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end,
+                            uint32_t *__restrict__ num, int64_t plane_stride, int64_t row_begin, int64_t row_end,
                             int64_t slot_begin)
 {
     const int lane = threadIdx.x & 63;
@@ -456,10 +457,10 @@ void pair_sad_sparse_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
-            run_item_sparse<2>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
+            run_item_sparse<2>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, plane_stride, row_begin, row_end,
                                slot_begin, lane);
         else
-            run_item_sparse<4>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, row_begin, row_end,
+            run_item_sparse<4>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, plane_stride, row_begin, row_end,
                                slot_begin, lane);
     }
 }
