@@ -1,0 +1,45 @@
+"""Randomised parity sweep at sizes where the main rounds of the schedules are in play (3,000 to
+9,000 samples): random shapes, densities, shard counts, weighted and unweighted, FIXED32 against
+the oracle on 200,000 sampled pairs per case (1e-6 relative / bit-exact for dyadic unweighted).
+Usage: python tests/fuzz_big_gpu.py SEED CASES   (a script, not collected by pytest)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frackyfrac_amd as ff
+from frackyfrac_amd import synth
+from oracle import oracle as O
+
+seed0, ncase = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+t0 = time.time()
+for case in range(ncase):
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.integers(3000, 9000))
+    leaves = int(rng.choice([300, 1000, 3000]))
+    dens = float(rng.choice([0.02, 0.1, 0.4]))
+    weighted = bool(rng.random() < 0.6)
+    world = int(rng.choice([1, 1, 2, 3]))
+    tree, ptr, idx, val = synth.make(n, leaves, dens, int(rng.integers(1, 1 << 30)))
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    P = ff.num_pairs(n)
+    got = np.full(P, np.nan)
+    for r in range(world):
+        ff.unifrac_dists(nodes, weighted, precision="fixed32", rank=r, world=world, out=got)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    ok = not np.isnan(got).any()
+    for q in range(4):
+        a = int((P - 50_000) * q // 3)
+        want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=16, pair_begin=a, pair_end=a + 50_000)
+        g = got[a:a + 50_000]
+        if weighted:
+            rel = np.abs(g - want) / np.where(want == 0, 1, np.abs(want))
+            ok = ok and bool(rel.max() <= 1e-6)
+        else:
+            ok = ok and bool(np.array_equal(g, want))
+    if not ok:
+        bad += 1
+        print("CASE", seed0 + case, "n", n, "leaves", leaves, "dens", dens, "weighted", weighted, "world", world, "MISMATCH", flush=True)
+    print("case", case, "n", n, "leaves", leaves, "w", weighted, "world", world, "%.0fs" % (time.time() - t0), "bad", bad, flush=True)
+print("done", ncase, "bad", bad)
