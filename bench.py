@@ -2,23 +2,39 @@
 """bench.py -- throughput of the UniFrac pair reduction (the hot path) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--precision fixed32]
+                    [--scaling weak|strong] [--no-secondary] [--no-cpu-baseline]
 
 A "step" is one pass of the hot path over one batch of synthetic input: the pair
 kernels over this rank's row shard of the staged matrix (already resident in HBM)
-plus, for N > 1, the gather of the result slices to rank 0 over RCCL.  N = 1 runs
-BASELINE.json's headline configuration C3 (weighted UniFrac, 4096 samples x
-10k-leaf tree).  For N > 1 the run is launched by torch.distributed.run, one rank
-per GPU, and scales WEAKLY: the sample count grows as 4096*sqrt(N) so that every
-GPU keeps C3's pair count; `value` is all ranks' pairs / max-over-ranks time.
+plus, for N > 1, the gather of the result slices to rank 0.  N = 1 runs BASELINE.json's
+headline configuration C3 (weighted UniFrac, 4096 samples x 10k-leaf tree).
 
-Prints ONE JSON line on rank 0 (see the task contract); `roofline` describes the
-dominant kernel (pair_sad_kernel), timed with HIP events around every launch of
-the timed region (ff_plan_run_timed / ff_plan_timing_collect).
+N > 1: one rank per GPU under torch.distributed.run.  Started WITHOUT that launcher
+(`python bench.py --gpus 8 ...`, the way the N = 1 run is started) this process launches
+it itself: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child BEFORE importing torch or touching HIP, relays rank 0's JSON line and exit code, and
+never uses the GPU.  The primary line scales WEAKLY by default (samples = 4096*sqrt(N), so
+every GPU keeps C3's pair count; `--scaling strong` keeps 4096 samples); `value` is all
+ranks' pairs / max-over-ranks time.
+
+`secondary` carries the other claimed numbers under the same clock, each with its own
+`config.workload`, `dtype`, `ms_per_step` and `roofline`:
+  N = 1: C3 in EXACT64 (the reference's binary64 roundings), C3 unweighted (int8 matrix
+         cores), C2 (BASELINE configs[1]), C4 and C5 on one GPU;
+  N > 1: BASELINE configs[3] and [4] -- C4 and C5 at their stated sizes, row shards over
+         the N GPUs (strong by construction), with the gather transport that ran.
+
+Prints ONE JSON line on rank 0; `roofline` describes the dominant kernel, timed with HIP
+events around every launch of the timed region on the stream it is launched on
+(ff_plan_run_timed / ff_plan_timing_collect).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -52,9 +68,10 @@ def host_cores():
     return n
 
 
-def cpu_baseline(nodes, weighted, budget_s=15.0):
-    """The oracle's merge walk (C restatement of frcfrc/unifrac.go:144-228) on the
-    host cores, over a bounded prefix of the pairs in IterPairs order."""
+def cpu_baseline(nodes, weighted, budget_s=18.0):
+    """The oracle's merge walk (C restatement of frcfrc/unifrac.go:144-228) on the host
+    cores, over a bounded prefix of the pairs in IterPairs order: one thread (the reference's
+    default, frcfrc.go:24 `-p 1`) and all cores, median of 3 runs each."""
     from oracle import oracle as O
 
     cores = host_cores()
@@ -63,19 +80,218 @@ def cpu_baseline(nodes, weighted, budget_s=15.0):
     onodes["abnd"] = nodes.abnd
     n = nodes.n_samples
     P = n * (n - 1) // 2
-    probe = min(P, 4000 * cores)
+
+    def timed(count, threads):
+        t0 = time.perf_counter()
+        O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, weighted, nthreads=threads, pair_begin=0, pair_end=count)
+        return max(time.perf_counter() - t0, 1e-6)
+
+    def leg(threads):
+        # rows get longer as the prefix grows (later rows hold more pairs of the same cost), so
+        # cost per pair is flat: size the sample for a sixth of the budget from a probe's rate
+        probe = min(P, 2000 * threads)
+        dt = timed(probe, threads)
+        count = int(min(P, max(probe, probe / dt * budget_s / 6.0)))
+        runs = sorted(timed(count, threads) for _ in range(3))
+        return count, statistics.median(runs), runs
+
+    c1, t1, r1 = leg(1)
+    ca, ta, ra = leg(cores)
+    return {"value": ca / ta, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "first %d of %d pairs in IterPairs order, median of 3 runs (%.2f / %.2f / %.2f s), "
+                      "oracle/unifrac_oracle.c merge walk (C restatement of the reference algorithm, %d threads)"
+                      % (ca, P, ra[0], ra[1], ra[2], cores),
+            "single_thread": {"value": c1 / t1, "unit": "pairs/s", "cores": 1,
+                              "sample": "first %d of %d pairs, median of 3 runs (%.2f / %.2f / %.2f s)"
+                                        % (c1, P, r1[0], r1[1], r1[2])}}
+
+
+# ---- self-launch ------------------------------------------------------------------------
+
+def launch_command(n_gpus, argv, port):
+    """The child a plain `python bench.py --gpus N` starts: torch.distributed.run with one rank
+    per GPU, this file and the same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """Runs the N-rank job as a child and relays rank 0's JSON line and the exit code.  The
+    parent imports neither torch nor the engine and never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = launch_command(n_gpus, argv, port)
+    log("bench.py: launching %d ranks: %s" % (n_gpus, " ".join(cmd)))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            log(ln)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if r.returncode else (0 if lines else 1)
+
+
+# ---- one measurement ----------------------------------------------------------------------
+
+class Ctx:
+    pass
+
+
+def make_problem(ctx, workload, n_samples=None):
+    """Synthetic inputs of one configuration (frackyfrac_amd/synth.py), stage A on the host."""
+    import frackyfrac_amd as ff
+    from frackyfrac_amd import synth
+
+    if workload in synth.CONFIGS:
+        cfg = dict(synth.CONFIGS[workload])
+        name = workload
+    else:
+        ns, nl = workload.lower().split("x")
+        cfg = dict(n_samples=int(ns), n_leaves=int(nl), density=0.10, weighted=True, seed=synth.SEED_BASE + 77)
+        name = "custom"
+    if n_samples is not None:
+        cfg["n_samples"] = n_samples
     t0 = time.perf_counter()
-    O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, weighted, nthreads=cores, pair_begin=0, pair_end=probe)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    # rows get longer as the prefix grows (later rows hold more pairs of the same cost),
-    # so cost per pair is flat: size the sample for the budget from the probe rate
-    count = int(min(P, max(probe, probe / dt * budget_s)))
+    tree, ptr, idx, val = synth.make(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)        # stage A on the host
+    cfg["prep_s"] = time.perf_counter() - t0
+    cfg["name"] = name
+    return cfg, nodes
+
+
+def barrier(ctx):
+    # every rank first drains its own streams (with the "ipc" transport a peer's slice
+    # reaches the root from the PEER's copy stream), then all meet
+    ctx.torch.cuda.synchronize()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+    ctx.torch.cuda.synchronize()
+
+
+def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, traffic):
+    """Roofline of the dominant kernel from the ALGORITHMIC work of one launch."""
+    from frackyfrac_amd._lib import KERNEL_NAMES
+
+    elem_bytes = 4 if info.precision == 1 else 8
+    # per pair 8 + (elem*N*B + 4*B + 4*N)/P bytes: one f64 result + the pair's share of one
+    # compulsory read of the staged matrix, lengths and row sums
+    alg_bytes = 8.0 * shard_pairs + elem_bytes * float(n_samples) * B + 4.0 * B + 4.0 * n_samples
+    sec = max(kernel_ms, 1e-9) * 1e-3
+    hbm = {"bound": "hbm", "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
+    common = {"kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
+    common.update(traffic or {"traffic": None})
+    if info.kernel == 2:
+        # unweighted on the matrix cores: one multiply-add per branch and pair is the
+        # algorithmic work (the base-128 digit passes are the implementation's)
+        achieved = 2.0 * B * shard_pairs / sec / 1e12
+        return dict({"bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                     "frac": achieved / MFMA_I8_PEAK_TOPS, "digits": int(info.n_digits),
+                     "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs)}, **common)
+    if info.kernel == 1:
+        # EXACT64: the reference's roundings need six unfused binary64 operations per branch and
+        # pair (numer: sub, mul by |.|, add; denom: add, mul, add; unifrac.go:191-192); the FP64
+        # vector rate is half the FP32 one (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s)
+        achieved = 6.0 * B * shard_pairs / sec / 1e12
+        return dict({"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS / 2, "unit": "T f64 op/s",
+                     "frac": achieved / (VALU_PEAK_TLANEOPS / 2),
+                     "algorithmic": "6*B unfused binary64 ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs)},
+                    **common)
+    achieved = 2.0 * B * shard_pairs / sec / 1e12
+    return dict({"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                 "frac": achieved / VALU_PEAK_TLANEOPS,
+                 "algorithmic": "2*B lane-ops per pair (SURVEY 8d), B=%d, %d pairs per launch" % (B, shard_pairs)},
+                **common)
+
+
+def traffic_of(name, world, info, weighted):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/traffic.json: value, the counter file it came from, the commit it was taken at).
+    A constant of the profiled build, not a measurement of this run -- hence the source."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        e = t.get("%s_n%d_k%d%s" % (name, world, int(info.kernel), "" if weighted else "_unweighted"))
+        if e:
+            return {"traffic": e["bytes"], "traffic_source": "%s @ %s (2*FETCH_SIZE + WRITE_SIZE, separate --pmc pass)"
+                                                             % (e["source"], e["commit"])}
+    except Exception:
+        pass
+    return None
+
+
+def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
+    """Stages the problem on this rank, runs `warmup` untimed and `steps` timed steps, returns
+    rank 0's entry (None on other ranks)."""
+    import frackyfrac_amd as ff
+    from frackyfrac_amd.distributed import ShardedRun
+
+    torch, dist = ctx.torch, ctx.dist
+    n_samples, B = nodes.n_samples, nodes.n_branches
+    P = ff.num_pairs(n_samples)
     t0 = time.perf_counter()
-    O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, weighted, nthreads=cores, pair_begin=0, pair_end=count)
-    dt = time.perf_counter() - t0
-    return {"value": count / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "first %d of %d pairs in IterPairs order, %.1f s, oracle/unifrac_oracle.c merge walk "
-                      "(C restatement of the reference algorithm, %d threads)" % (count, P, dt, cores)}
+    run = ShardedRun(nodes, weighted, ctx.rank, ctx.world, precision=precision, device=ctx.local_rank)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t0
+    info = run.plan.info
+    if ctx.world > 1 and ctx.rank == 1 and run.ipc_gbps is not None:
+        log("rank 1: ipc slice copy into the root's buffer %.1f GB/s (all peers at once)" % run.ipc_gbps)
+    if ctx.rank == 0:
+        log("workload %s: N=%d leaves=%d B=%d nnz=%d pairs=%d | prep %.2fs stage(H2D+quantise) %.3fs | "
+            "precision=%s scale=2^%d kernel=%d tiles=%d items=%d wave_slots=%d%s" %
+            (cfg["name"], n_samples, cfg["n_leaves"], B, len(nodes.branch_id), P, cfg["prep_s"], t_stage,
+             {1: "fixed32", 2: "exact64"}[info.precision], info.scale_log2, info.kernel, info.n_tiles, info.n_items,
+             info.n_wave_slots,
+             (" | gather: %s%s" % (run.transport, (" (ipc not used: %s)" % run.transport_note) if run.transport_note else ""))
+             if ctx.world > 1 else ""))
+    for _ in range(warmup):
+        run.step()
+    barrier(ctx)
+    run.timing_collect()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(steps):
+        res = run.step(timed=True)
+    barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    kernel_ms_total, launches = run.timing_collect()
+    if ctx.world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    run.check_precision()  # queue overflow / audit failure on ANY rank raises on every rank
+    entry = None
+    if ctx.rank == 0:
+        kernel_ms = kernel_ms_total / max(launches, 1)
+        # cheap sanity on the result of the last step (not a parity test: tests/ does that);
+        # every slot, so a slice that never arrived from its rank cannot go unnoticed
+        lo, hi = float(res.min().item()), float(res.max().item())
+        assert not bool(torch.isnan(res).any().item()), "NaN in the gathered result"
+        assert 0.0 <= lo and hi <= 1.0, "distance outside [0, 1]"
+        n_audit, bad, worst = run.plan.audit()
+        entry = {"value": P / (elapsed / steps), "unit": "pairs/s", "steps": steps, "warmup": warmup,
+                 "ms_per_step": elapsed / steps * 1e3,
+                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8"}[int(info.kernel)],
+                 "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
+                                        "leaf density %.2f, seed 0x%X" %
+                                        (cfg["name"], n_samples, cfg["n_leaves"], B,
+                                         "weighted" if weighted else "unweighted", cfg["density"], cfg["seed"]),
+                            "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
+                            "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (ctx.world, run.transport)},
+                 "roofline": roofline_of(info, B, n_samples, run.n_slots, kernel_ms, launches, weighted,
+                                         traffic_of(cfg["name"], ctx.world, info, weighted))}
+        if n_audit:
+            entry["audit"] = {"pairs": n_audit, "failed": bad, "worst_rel_err": worst}
+        if ctx.world > 1:
+            entry["gather"] = {"transport": run.transport, "ipc_probe_GBps_rank1": ctx.ipc_gbps_rank1(run)}
+    else:
+        ctx.ipc_gbps_rank1(run)
+    run.close()
+    return entry
 
 
 def main():
@@ -85,187 +301,122 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", help="C2|C3|C4|C5 or SAMPLESxLEAVES (e.g. 2048x5000)")
     ap.add_argument("--precision", default="fixed32", choices=["auto", "fixed32", "exact64"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = samples grow as sqrt(N) (per-GPU pairs fixed), strong = the workload's own size")
     ap.add_argument("--unweighted", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="only the primary line")
+    ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--end-to-end", action="store_true", help="also time ff_unifrac_dists through host buffers")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks that all use GPU 0 with gloo as control plane (RCCL refuses two ranks on "
                          "one device): exercises the sharded code path on a one-GPU box; not a measurement")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
     import frackyfrac_amd as ff
-    from frackyfrac_amd import synth
-    from frackyfrac_amd.distributed import ShardedRun
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    ctx = Ctx()
+    ctx.torch, ctx.dist = torch, dist
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx.rehearse = args.rehearse_on_one_gpu
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if ctx.rehearse:
+        ctx.local_rank = 0
+    torch.cuda.set_device(ctx.local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
+        if ctx.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", ctx.local_rank))
 
-    # ---- workload -----------------------------------------------------------
-    if args.workload in synth.CONFIGS:
-        cfg = dict(synth.CONFIGS[args.workload])
-        name = args.workload
-    else:
-        ns, nl = args.workload.lower().split("x")
-        cfg = dict(n_samples=int(ns), n_leaves=int(nl), density=0.10, weighted=True, seed=synth.SEED_BASE + 77)
-        name = "custom"
+    def ipc_gbps_rank1(run):
+        """Rank 1's probe of the ipc transport (GB/s into the root's buffer), known on rank 0."""
+        if world == 1:
+            return None
+        box = [run.ipc_gbps if rank == 1 else None]
+        dist.broadcast_object_list(box, src=1)
+        v = box[0]
+        return None if v is None or v == float("inf") else v
+
+    ctx.ipc_gbps_rank1 = ipc_gbps_rank1
+
+    # ---- primary: BASELINE's metric on its configuration --------------------------------
+    from frackyfrac_amd import synth
+
+    n_override = None
+    if world > 1 and args.scaling == "weak" and args.workload in synth.CONFIGS:
+        n_override = int(round(synth.CONFIGS[args.workload]["n_samples"] * math.sqrt(world) / 32.0)) * 32
+    elif world > 1 and args.scaling == "weak":
+        n_override = int(round(int(args.workload.lower().split("x")[0]) * math.sqrt(world) / 32.0)) * 32
+    cfg, nodes = make_problem(ctx, args.workload, n_override)
     weighted = cfg["weighted"] and not args.unweighted
-    base_samples = cfg["n_samples"]
-    n_samples = base_samples if world == 1 else int(round(base_samples * math.sqrt(world) / 32.0)) * 32
-    t0 = time.perf_counter()
-    tree, ptr, idx, val = synth.make(n_samples, cfg["n_leaves"], cfg["density"], cfg["seed"])
-    T = ff.parse_newick(tree.newick())
-    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)        # stage A on the host
-    t_prep = time.perf_counter() - t0
-    B = nodes.n_branches
-    P = ff.num_pairs(n_samples)
-    t0 = time.perf_counter()
-    run = ShardedRun(nodes, weighted, rank, world, precision=args.precision, device=local_rank)
-    torch.cuda.synchronize()
-    t_stage = time.perf_counter() - t0
-    info = run.plan.info
-    if world > 1 and rank == 1 and run.ipc_gbps is not None:
-        log("rank 1: ipc slice copy into the root's buffer %.1f GB/s (all peers at once)" % run.ipc_gbps)
-    if rank == 0 and world > 1:
-        log("gather transport: %s%s" % (run.transport, (" (ipc not used: %s)" % run.transport_note) if run.transport_note else ""))
-    if rank == 0:
-        log("workload %s: N=%d leaves=%d B=%d nnz=%d pairs=%d | prep %.2fs stage(H2D+quantise) %.3fs | "
-            "precision=%s scale=2^%d tiles=%d items=%d wave_slots=%d" %
-            (name, n_samples, cfg["n_leaves"], B, len(nodes.branch_id), P, t_prep, t_stage,
-             {1: "fixed32", 2: "exact64"}[info.precision], info.scale_log2, info.n_tiles, info.n_items,
-             info.n_wave_slots))
-
-    def barrier():
-        # every rank first drains its own streams (with the "ipc" transport a peer's slice
-        # reaches the root from the PEER's copy stream), then all meet
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        run.step()
-    barrier()
-    run.timing_collect()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = run.step(timed=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = run.timing_collect()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup)
 
     e2e = None
     if rank == 0 and world == 1 and args.end_to_end:
         # Host-buffer entry point (ff_unifrac_dists): upload of the flat nodes over PCIe,
         # staging, the pair kernels and the download of the distances.  Never `value`.
+        P = ff.num_pairs(nodes.n_samples)
         out_host = np.empty(P, dtype=np.float64)
-        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=local_rank, out=out_host)  # warm
+        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=ctx.local_rank, out=out_host)  # warm
         t0 = time.perf_counter()
-        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=local_rank, out=out_host)
+        ff.unifrac_dists(nodes, weighted, precision=args.precision, device=ctx.local_rank, out=out_host)
         e2e = time.perf_counter() - t0
         log("end-to-end through host buffers (H2D %d MB + stage + kernels + D2H %d MB): %.1f ms = %.3g pairs/s" %
             ((len(nodes.branch_id) * 12) >> 20, (P * 8) >> 20, e2e * 1e3, P / e2e))
 
+    out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = P / (elapsed / args.steps)
-        # ---- roofline of the dominant kernel (this rank's launch) -------------
-        shard_pairs = run.n_slots
-        kernel_ms = kernel_ms_total / max(launches, 1)
-        elem_bytes = 4 if info.precision == 1 else 8
-        # per pair 2*B lane-ops (subtract + |x|-accumulate per branch) and
-        # 8 + (elem*N*B + 4*B + 4*N)/P bytes (one f64 result + the pair's share of one
-        # compulsory read of the staged matrix, lengths and row sums)
-        from frackyfrac_amd._lib import KERNEL_NAMES
-        alg_bytes = 8.0 * shard_pairs + elem_bytes * float(n_samples) * B + 4.0 * B + 4.0 * n_samples
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and info.kernel in (0, 3) and weighted:
-            try:
-                traffic = json.load(open(tpath)).get("%s_n%d" % (name, world))
-            except Exception:
-                traffic = None
-        hbm = {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-               "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-               "algorithmic_bytes": alg_bytes}
-        if info.kernel == 2:
-            # unweighted on the matrix cores: one multiply-add per branch and pair is the
-            # algorithmic work (the base-128 digit passes are the implementation's)
-            flops = 2.0 * B * shard_pairs
-            achieved = flops / (kernel_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                        "frac": achieved / MFMA_I8_PEAK_TOPS, "traffic": traffic, "kernel": KERNEL_NAMES[2],
-                        "kernel_ms": kernel_ms, "launches": launches, "digits": int(info.n_digits),
-                        "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs),
-                        "hbm": hbm}
-        elif info.kernel == 1:
-            # EXACT64: the reference's roundings need six unfused binary64 operations per branch and
-            # pair (numer: sub, mul by |.|, add; denom: add, mul, add; unifrac.go:191-192); the FP64
-            # vector rate is half the FP32 one (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s)
-            ops = 6.0 * B * shard_pairs
-            achieved_t = ops / (kernel_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu", "achieved": achieved_t, "peak": VALU_PEAK_TLANEOPS / 2, "unit": "T f64 op/s",
-                        "frac": achieved_t / (VALU_PEAK_TLANEOPS / 2), "traffic": traffic,
-                        "kernel": KERNEL_NAMES[1], "kernel_ms": kernel_ms, "launches": launches,
-                        "algorithmic": "6*B unfused binary64 ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs),
-                        "hbm": hbm}
-        else:
-            laneops = 2.0 * B * shard_pairs
-            achieved_tl = laneops / (kernel_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu", "achieved": achieved_tl, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                        "frac": achieved_tl / VALU_PEAK_TLANEOPS, "traffic": traffic,
-                        "kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches,
-                        "algorithmic": "2*B lane-ops per pair (SURVEY 8d), B=%d, %d pairs per launch" % (B, shard_pairs),
-                        "hbm": hbm}
         out = {"metric": "sample-pairs/sec (lower triangle), weighted UniFrac 4096 samples x 10k-leaf tree"
-                         if name == "C3" and weighted else "sample-pairs/sec (lower triangle)",
-               "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u32" if info.precision == 1 else "f64",
-               "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if args.rehearse_on_one_gpu else ""),
-               "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
-                                      "leaf density %.2f, seed 0x%X" %
-                                      (name, n_samples, cfg["n_leaves"], B, "weighted" if weighted else "unweighted",
-                                       cfg["density"], cfg["seed"]),
-                          "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
-                          "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (world, run.transport)},
-               "roofline": roofline}
+                         if cfg["name"] == "C3" and weighted else "sample-pairs/sec (lower triangle)",
+               "value": primary["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": primary["ms_per_step"], "higher_is_better": True,
+               "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": primary["dtype"],
+               "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if ctx.rehearse else ""),
+               "config": primary["config"], "roofline": primary["roofline"]}
+        for k in ("audit", "gather"):
+            if k in primary:
+                out[k] = primary[k]
         if e2e is not None:
             out["host_buffers_ms"] = e2e * 1e3  # PCIe-inclusive, informational
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
-        # cheap sanity on the result of the last step (not a parity test: tests/ does that)
-        # (every slot, so a slice that never arrived from its rank cannot go unnoticed)
-        lo, hi = float(res.min().item()), float(res.max().item())
-        assert not bool(torch.isnan(res).any().item()), "NaN in the gathered result"
-        assert 0.0 <= lo and hi <= 1.0000001, "distance outside [0, 1]"
+
+    # ---- secondary: the other claimed numbers, same clock ------------------------------------
+    if not args.no_secondary and args.workload == "C3" and not args.unweighted and args.precision == "fixed32":
+        sec = []
+        k, w = max(1, min(args.secondary_steps, args.steps)), 1
+        if world == 1:
+            sec.append(measure(ctx, cfg, nodes, True, "exact64", k, w))       # the reference-width figure
+            sec.append(measure(ctx, cfg, nodes, False, "fixed32", max(k, args.steps), w))  # int8 matrix cores
+            del nodes
+            for wl, wtd, steps in (("C2", False, max(k, args.steps)), ("C4", True, k), ("C5", True, k)):
+                c2, n2 = make_problem(ctx, wl)
+                sec.append(measure(ctx, c2, n2, wtd, "fixed32", steps, w))
+                del n2
+        else:
+            del nodes
+            for wl in ("C4", "C5"):     # BASELINE configs[3], [4] at their stated sizes over the N GPUs
+                c2, n2 = make_problem(ctx, wl)
+                sec.append(measure(ctx, c2, n2, True, "fixed32", k, w))
+                del n2
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    run.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

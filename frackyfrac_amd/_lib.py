@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfrackyfrac_amd.so")
 FRCFRC_PATH = os.path.join(_HERE, "lib", "frcfrc")
 
 FF_OK = 0
-FF_ERR_ARG, FF_ERR_PARSE, FF_ERR_SPECIES, FF_ERR_DEVICE, FF_ERR_IO, FF_ERR_INTERNAL = 1, 2, 3, 4, 5, 6
+FF_ERR_ARG, FF_ERR_PARSE, FF_ERR_SPECIES, FF_ERR_DEVICE, FF_ERR_IO, FF_ERR_INTERNAL, FF_ERR_PRECISION = 1, 2, 3, 4, 5, 6, 7
 PRECISION_AUTO, PRECISION_FIXED32, PRECISION_EXACT64 = 0, 1, 2
 PRECISION_NAMES = {"auto": 0, "fixed32": 1, "exact64": 2}
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     "ff_plan_run_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_plan_timing_collect": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int32)]),
     "ff_plan_refined_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    "ff_plan_audit": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),
     "ff_plan_set_shard": (c_int, [c_void_p, c_int32, c_int32, c_char_p, c_size_t]),
     "ff_plan_run_host": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_tree_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),

@@ -354,6 +354,28 @@ class Plan:
         return q.value, c.value
 
 
+    def audit(self) -> Tuple[int, int, float]:
+        """(audited pairs, how many of them the last completed run missed by more than 0.5e-6
+        relative, worst relative error over the sample) -- ff_plan_audit."""
+        n, bad, worst = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        rc = L.lib().ff_plan_audit(self._h, ctypes.byref(n), ctypes.byref(bad), ctypes.byref(worst))
+        if rc:
+            raise FFError(rc, "ff_plan_audit failed")
+        return n.value, bad.value, worst.value
+
+    def check_precision(self) -> None:
+        """Raises FFError(FF_ERR_PRECISION) unless the last completed run keeps FIXED32's
+        promise: refinement queue not overflowed, audit sample within its bar."""
+        queued, cap = self.refined_pairs()
+        if queued > cap:
+            raise FFError(L.FF_ERR_PRECISION, "%d nearly identical pairs, %d can be re-computed exactly: "
+                          "stage this problem with precision='exact64'" % (queued, cap))
+        n, bad, worst = self.audit()
+        if bad:
+            raise FFError(L.FF_ERR_PRECISION, "%d of %d audited pairs missed the tolerance (worst %.2e): "
+                          "stage this problem with precision='exact64'" % (bad, n, worst))
+
+
 def format_float(f: float) -> str:
     """fmt.Fprintln's rendering of a float64, without the newline."""
     buf = ctypes.create_string_buffer(40)

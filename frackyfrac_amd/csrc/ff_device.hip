@@ -31,6 +31,7 @@
 #include <string>
 #include <vector>
 
+#include "ff_dither.hpp"
 #include "ff_host.hpp"
 #include "ff_schedule.hpp"
 
@@ -83,8 +84,13 @@ struct ff_plan {
     int64_t *d_indptr = nullptr;
     int32_t *d_ids = nullptr;
     double *d_abnd = nullptr;
-    unsigned long long *d_refine_list = nullptr, *d_refine_count = nullptr;
+    unsigned long long *d_refine_list = nullptr;
+    unsigned long long *d_refine_count = nullptr;  // [0] pairs queued, [1] audited pairs that failed, [2] max audited error (double bits)
     unsigned long long refine_cap = 0;
+    double *d_wex = nullptr;          // binary64 weights of the samples (exact_weight_kernel); null: integer denominators
+    int64_t *d_audit_slots = nullptr;  // run-time audit: sampled slots of the shard and their binary64 distances
+    double *d_audit_exact = nullptr;
+    int n_audit = 0;
     // FIXED32 unweighted on the matrix cores
     bool mfma = false;
     int8_t *d_P8 = nullptr, *d_K8 = nullptr;
@@ -289,8 +295,9 @@ Quant choose_quant(const DeviceCsr &c, bool weighted)
         q.e = ex - 1;
         q.lengths_exact = 0;
     }
+    // the branch's shared rounding offset (ff_dither.hpp); an exact length is its own integer
     for (int64_t b = 0; b < B; ++b)
-        q.klen[(size_t)b] = (uint32_t)std::llrint(std::ldexp(c.h_len[(size_t)b], q.e));
+        q.klen[(size_t)b] = (uint32_t)(int64_t)std::floor(std::ldexp(c.h_len[(size_t)b], q.e) + ff::branch_dither(b));
     q.fixed_ok = true;
     return q;
 }
@@ -312,6 +319,9 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_abnd);
     (void)hipFree(pl->d_refine_list);
     (void)hipFree(pl->d_refine_count);
+    (void)hipFree(pl->d_wex);
+    (void)hipFree(pl->d_audit_slots);
+    (void)hipFree(pl->d_audit_exact);
     (void)hipFree(pl->d_P8);
     (void)hipFree(pl->d_K8);
     (void)hipFree(pl->d_mitems);
@@ -710,15 +720,40 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
     return FF_OK;
 }
 
-// The queue of pairs to recompute exactly holds up to an eighth of the shard (at least 2^20).
+// The queue of pairs to recompute exactly holds up to an eighth of the shard (at least 2^20);
+// next to it the run-time audit's sample of the shard and its binary64 distances.
 int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
 {
     const int64_t n_slots = pl->info.slot_end - pl->info.slot_begin;
     free_and_null(pl->d_refine_list);
+    free_and_null(pl->d_audit_slots);
+    free_and_null(pl->d_audit_exact);
+    pl->n_audit = 0;
     pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
     FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)std::max<unsigned long long>(pl->refine_cap, 1)));
-    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long)));
-    FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long)));
+    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * 3));
+    FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long) * 3));
+    if (n_slots > 0 && env_int("FF_AUDIT", 1) != 0) {
+        const int n = (int)std::min<int64_t>(AUDIT_PAIRS, n_slots);
+        std::vector<int64_t> slots((size_t)n);
+        uint64_t x = 0x5EEDF4ACull ^ (uint64_t)pl->info.slot_begin;
+        for (int q = 0; q < n; ++q) {  // splitmix64
+            uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            slots[(size_t)q] = n_slots <= AUDIT_PAIRS ? q : (int64_t)(z % (uint64_t)n_slots);
+        }
+        FF_HIP(hipMalloc(&pl->d_audit_slots, sizeof(int64_t) * (size_t)n));
+        FF_HIP(hipMalloc(&pl->d_audit_exact, sizeof(double) * (size_t)n));
+        FF_HIP(hipMemcpy(pl->d_audit_slots, slots.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
+        audit_exact_kernel<<<dim3((unsigned)n), dim3(64)>>>(pl->d_audit_slots, pl->d_indptr, pl->d_ids, pl->d_abnd,
+                                                             pl->d_len, pl->weighted, pl->info.slot_begin,
+                                                             pl->d_audit_exact);
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipDeviceSynchronize());  // runs may come on any stream
+        pl->n_audit = n;
+    }
     return FF_OK;
 }
 
@@ -1018,6 +1053,15 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     else rc = stage_for_exact64(x, err, errlen);
     if (rc) return rc;
     FF_HIP(hipDeviceSynchronize());
+    // FIXED32 whose integers carry a rounding (weighted; unweighted with lengths off the binary
+    // grid) divides by binary64 weights, so that only the numerator's rounding reaches a distance
+    if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && N > 0) {
+        FF_HIP(hipMalloc(&pl->d_wex, sizeof(double) * (size_t)N));
+        exact_weight_kernel<<<dim3((unsigned)N), dim3(256)>>>(pl->d_indptr, pl->d_ids, pl->d_abnd, pl->d_len,
+                                                               weighted ? 1 : 0, pl->d_wex);
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipDeviceSynchronize());
+    }
     // FIXED32 keeps the flat nodes resident for refine_exact_kernel unless the integer
     // sums are exact already (unweighted with lengths on the binary grid)
     if (prec == FF_PRECISION_FIXED32 && (weighted || !inf.lengths_exact) && env_int("FF_REFINE", 1)) {
@@ -1091,14 +1135,17 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
         const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
-        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long), st));
+        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long) * 3, st));
         finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(
-            pl->d_num, pl->n_planes, pl->plane_stride, pl->d_W, pl->weighted, inf.slot_begin, n_slots, d_out, pl->refine ? pl->d_indptr : nullptr,
-            pl->d_refine_list, pl->d_refine_count, pl->refine_cap);
+            pl->d_num, pl->n_planes, pl->plane_stride, pl->d_W, pl->d_wex, inf.scale_log2, pl->weighted, inf.slot_begin, n_slots, d_out,
+            pl->refine ? pl->d_indptr : nullptr, pl->d_refine_list, pl->d_refine_count, pl->refine_cap);
         if (pl->refine)
             refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * 8)), dim3(64), 0, st>>>(
                 pl->d_refine_list, pl->d_refine_count, pl->refine_cap, pl->d_indptr, pl->d_ids, pl->d_abnd,
                 pl->d_len, pl->weighted, inf.slot_begin, d_out);
+        if (pl->refine && pl->n_audit > 0)
+            audit_compare_kernel<<<dim3((unsigned)((pl->n_audit + 255) / 256)), dim3(256), 0, st>>>(
+                pl->d_audit_slots, pl->d_audit_exact, pl->n_audit, d_out, pl->d_refine_count);
     } else {
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->n_xtiles > 0) {
@@ -1115,6 +1162,30 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (timed) FF_HIP(hipEventRecord(ev1, st));
     }
     FF_HIP(hipGetLastError());
+    return FF_OK;
+}
+
+// After a completed FIXED32 run: did it deliver what the tolerance promises?  Not when more pairs
+// were queued for the binary64 walk than the queue holds, or when a pair of the audit sample is
+// further than AUDIT_REL from its binary64 value.  `why` gets the sentence for the caller.
+int plan_fixed32_verdict(ff_plan *pl, bool *ok, std::string *why)
+{
+    *ok = true;
+    if (!pl->refine) return FF_OK;
+    unsigned long long c[3] = {0, 0, 0};
+    if (hipMemcpy(c, pl->d_refine_count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
+    char buf[256];
+    if (c[0] > pl->refine_cap) {
+        snprintf(buf, sizeof buf, "%llu nearly identical pairs, %llu can be re-computed exactly", c[0], pl->refine_cap);
+        *ok = false;
+    } else if (c[1] > 0) {
+        double worst;
+        memcpy(&worst, &c[2], sizeof worst);
+        snprintf(buf, sizeof buf, "%llu of %d audited pairs are further than %.1e from their binary64 value (worst %.2e)",
+                 c[1], pl->n_audit, AUDIT_REL, worst);
+        *ok = false;
+    }
+    if (!*ok && why) *why = buf;
     return FF_OK;
 }
 
@@ -1204,11 +1275,10 @@ int ff_plan_run_host(ff_plan *pl, double *out, char *err, size_t errlen)
     int rc = plan_run_impl(pl, nullptr, pl->d_host_out, false, err, errlen);
     if (rc == FF_OK) {
         FF_HIP(hipMemcpy(out, pl->d_host_out, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost));
-        int64_t queued = 0, cap = 0;
-        if (ff_plan_refined_pairs(pl, &queued, &cap) == FF_OK && queued > cap)
-            rc = ff::fail(FF_ERR_PRECISION, err, errlen,
-                          "%lld nearly identical pairs, %lld can be re-computed exactly: stage this problem with "
-                          "FF_PRECISION_EXACT64", (long long)queued, (long long)cap);
+        bool ok = true;
+        std::string why;
+        if (plan_fixed32_verdict(pl, &ok, &why) == FF_OK && !ok)
+            rc = ff::fail(FF_ERR_PRECISION, err, errlen, "%s: stage this problem with FF_PRECISION_EXACT64", why.c_str());
     }
     if (cur != pl->device) (void)hipSetDevice(cur);
     return rc;
@@ -1229,6 +1299,21 @@ int ff_plan_refined_pairs(ff_plan *pl, int64_t *queued, int64_t *capacity)
     unsigned long long n = 0;
     if (hipMemcpy(&n, pl->d_refine_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
     *queued = (int64_t)n;
+    return FF_OK;
+}
+
+int ff_plan_audit(ff_plan *pl, int64_t *checked, int64_t *failed, double *max_rel_err)
+{
+    if (!pl || !checked || !failed || !max_rel_err) return FF_ERR_ARG;
+    *checked = 0;
+    *failed = 0;
+    *max_rel_err = 0.0;
+    if (!pl->refine || pl->n_audit <= 0) return FF_OK;
+    unsigned long long c[3] = {0, 0, 0};
+    if (hipMemcpy(c, pl->d_refine_count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
+    *checked = pl->n_audit;
+    *failed = (int64_t)c[1];
+    memcpy(max_rel_err, &c[2], sizeof(double));
     return FF_OK;
 }
 
@@ -1382,10 +1467,10 @@ int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recr
             return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: hipMalloc(out) failed: %s", hipGetErrorString(he));
         }
         rc = ff_plan_run(pl, nullptr, d_out, err, errlen);
-        int64_t queued = 0, cap = 0;
-        if (rc == FF_OK && ff_plan_refined_pairs(pl, &queued, &cap) == FF_OK && queued > cap) {
-            // more nearly-equal pairs than the refinement queue holds: the data set is
-            // mostly replicates -- run the whole shard in binary64 instead
+        bool ok = true;
+        if (rc == FF_OK && plan_fixed32_verdict(pl, &ok, nullptr) == FF_OK && !ok) {
+            // more nearly-equal pairs than the refinement queue holds (the data set is mostly
+            // replicates), or the audit sample missed its bar: run the whole shard in binary64
             ff_plan_destroy(pl);
             pl = nullptr;
             rc = recreate_exact64(&pl);
@@ -1454,9 +1539,9 @@ int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info 
             d_out_cap_ = n_slots;
         }
         rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);
-        int64_t queued = 0, cap = 0;
-        if (rc == FF_OK && ff_plan_refined_pairs(pl_, &queued, &cap) == FF_OK && queued > cap) {
-            // mostly replicates: binary64 from here on (run_plan_to_host does the same for one shard)
+        bool ok = true;
+        if (rc == FF_OK && plan_fixed32_verdict(pl_, &ok, nullptr) == FF_OK && !ok) {
+            // mostly replicates, or a failed audit: binary64 from here on (run_plan_to_host does the same for one shard)
             opt_.precision = FF_PRECISION_EXACT64;
             rc = create(rank, world, FF_PRECISION_EXACT64, err, errlen);
             if (rc == FF_OK) rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);

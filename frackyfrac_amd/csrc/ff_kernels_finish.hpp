@@ -4,17 +4,25 @@
 
 // Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
 //
-// Rounding every staged value to an integer leaves U with an error of about
-// sqrt((k_i + k_j) / 12) units (k = flat nodes of the sample).  Where U is so small
-// that this could exceed REFINE_REL of U -- nearly identical samples -- the pair is
-// queued for refine_exact_kernel, which recomputes it with the reference's own
-// binary64 merge walk; all other pairs already meet the tolerance.
-constexpr double REFINE_REL = 0.5e-6;   // half of the 1e-6 relative bar of BASELINE.json
-constexpr double REFINE_SIGMAS = 6.0;
+// U(i,j) is a sum of k <= k_i + k_j terms (k_s = flat nodes of sample s), each an unbiased
+// estimate of l_b * |x_i(b) - x_j(b)| * 2^e with an error inside (-1, 1) that is independent
+// from branch to branch (the per-branch offset of the staging, ff_dither.hpp).  Hoeffding's
+// bound for such a sum: P(|error| >= t) <= 2 exp(-2 t^2 / k).  The denominator is binary64
+// (exact_weight_kernel), so the relative error of a distance is that of U alone.  A pair whose
+// U is so small that REFINE_C * sqrt(k) units could exceed 1e-6 of it -- nearly identical
+// samples -- is queued for refine_exact_kernel, which recomputes it with the reference's own
+// binary64 merge walk.  For every other pair the 1e-6 bar of BASELINE.json is missed with
+// probability <= 2 exp(-2 * 25) = 4e-22, and half of it (what the run-time audit checks) with
+// probability <= 2 exp(-12.5) per pair in the worst case of the bound, ~1e-9 for typical
+// variances -- and that only for the pairs right at the threshold.
+constexpr double REFINE_BAR = 1e-6;   // the relative bar of BASELINE.json ("within 1e-6 relative for weighted")
+constexpr double REFINE_C = 5.0;
 
 __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
                                       int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
-                                      const unsigned long long *__restrict__ W, int weighted,
+                                      const unsigned long long *__restrict__ W,
+                                      const double *__restrict__ wex,  // binary64 weights (null: the integer sums are exact)
+                                      int scale_log2, int weighted,
                                       int64_t slot_begin, int64_t n_slots,
                                       double *__restrict__ out,
                                       const int64_t *__restrict__ indptr,  // null: no refinement
@@ -32,22 +40,110 @@ __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         const unsigned long long u = u32;
         const unsigned long long w = W[i] + W[j];
         double d;
-        if (weighted) {
-            d = (double)u / (double)w;                 // numer / denom
+        if (u == w || !wex) {
+            // u == w: no branch carries both samples (integer identity): exactly 1, or 0/0 = NaN
+            // when both are empty (unifrac.go:169,204)
+            if (weighted) {
+                d = (double)u / (double)w;                 // numer / denom
+            } else {
+                const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
+                d = (double)u / (double)(u + common);      // result / (result + common)
+            }
         } else {
-            const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
-            d = (double)u / (double)(u + common);      // result / (result + common)
+            const double s = ldexp(wex[i] + wex[j], scale_log2);
+            d = weighted ? (double)u / s                   // numer / denom
+                         : 2.0 * (double)u / (s + (double)u);  // result / (result + common), common = (s - result) / 2
+            d = fmin(d, 1.0);  // the integer numerator may pass the binary64 denominator by its rounding
         }
         out[t] = d;
         if (indptr && w != 0) {
             const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
-            const double err = REFINE_SIGMAS * sqrt(k * (1.0 / 12.0)) + 1.0;
-            if ((double)u * REFINE_REL < err) {
+            if ((double)u * REFINE_BAR < REFINE_C * sqrt(k) + 2.0) {
                 const unsigned long long at = atomicAdd(refine_count, 1ull);
                 if (at < refine_cap) refine_list[at] = (unsigned long long)t;
             }
         }
     }
+}
+
+// ---- Run-time audit of FIXED32 ------------------------------------------------------------
+// A fixed pseudo-random sample of the shard's pairs is computed in binary64 when the shard is
+// scheduled (audit_exact_kernel: the inputs of a plan do not change between runs) and compared
+// with what every run delivers (audit_compare_kernel, a few microseconds).  A sampled pair
+// further than AUDIT_REL from its binary64 value fails the run: the blocking entry points then
+// repeat the shard in EXACT64 or return FF_ERR_PRECISION (ff_plan_audit for asynchronous
+// callers).  The staging's error model makes that a < 1e-9 event per sampled pair; the audit is
+// there for what a model cannot promise.
+constexpr double AUDIT_REL = 0.5e-6;
+constexpr int AUDIT_PAIRS = 4096;
+
+// Position of id b in ids[lo, hi) (ascending), or -1.
+__device__ __forceinline__ int64_t find_branch(const int32_t *__restrict__ ids, int64_t lo, int64_t hi, int32_t b)
+{
+    const int64_t end = hi;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ids[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < end && ids[lo] == b) ? lo : -1;
+}
+
+// One wave per sampled pair: the sums of unifrac.go:144-205 in binary64, lanes striding over
+// the flat nodes of either sample and looking the branch up in the other.  Not the reference's
+// ORDER of additions (the differences are ~1e-15 relative, nine orders below what is checked).
+__global__ __launch_bounds__(64)
+void audit_exact_kernel(const int64_t *__restrict__ slots, const int64_t *__restrict__ indptr,
+                        const int32_t *__restrict__ branch_id, const double *__restrict__ abnd,
+                        const double *__restrict__ tree_dists, int weighted, int64_t slot_begin,
+                        double *__restrict__ exact)
+{
+    int64_t si, sj;
+    slot_to_pair(slot_begin + slots[blockIdx.x], &si, &sj);
+    const int64_t i0 = indptr[si], i1 = indptr[si + 1], j0 = indptr[sj], j1 = indptr[sj + 1];
+    double x = 0.0, y = 0.0;  // numer/denom or result/common
+    for (int64_t t = i0 + threadIdx.x; t < i1; t += 64) {
+        const int32_t b = branch_id[t];
+        const double l = tree_dists[b];
+        const int64_t p = find_branch(branch_id, j0, j1, b);
+        if (weighted) {
+            const double a = abnd[t];
+            if (p >= 0) { x += l * fabs(a - abnd[p]); y += l * (a + abnd[p]); }
+            else { x += l * a; y += l * a; }
+        } else {
+            if (p >= 0) y += l; else x += l;
+        }
+    }
+    for (int64_t t = j0 + threadIdx.x; t < j1; t += 64) {
+        const int32_t b = branch_id[t];
+        if (find_branch(branch_id, i0, i1, b) >= 0) continue;  // counted above
+        const double l = tree_dists[b];
+        if (weighted) { x += l * abnd[t]; y += l * abnd[t]; } else { x += l; }
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        x += __shfl_xor(x, m);
+        y += __shfl_xor(y, m);
+    }
+    if (threadIdx.x == 0) exact[blockIdx.x] = weighted ? x / y : x / (x + y);
+}
+
+// counters[1] += sampled pairs further than AUDIT_REL from their binary64 value,
+// counters[2] = max over the sample of the relative error (bits of a non-negative double).
+__global__ void audit_compare_kernel(const int64_t *__restrict__ slots, const double *__restrict__ exact, int n,
+                                     const double *__restrict__ out, unsigned long long *__restrict__ counters)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const double want = exact[q], got = out[slots[q]];
+    double rel;
+    if (want != want) rel = got != got ? 0.0 : INFINITY;
+    else if (want == 0.0) rel = got == 0.0 ? 0.0 : INFINITY;
+    else rel = fabs(got - want) / fabs(want);
+    if (!(rel <= AUDIT_REL)) {
+        if (rel != rel) rel = INFINITY;
+        atomicAdd(&counters[1], 1ull);
+    }
+    atomicMax(&counters[2], (unsigned long long)__double_as_longlong(rel));
 }
 
 // The reference's merge walk (unifrac.go:144-205) for the queued pairs, one thread per

@@ -18,6 +18,7 @@ __device__ __forceinline__ void sad_u32_acc(uint32_t s, uint32_t v, uint32_t &ac
 }
 
 // Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
+// Weighted values are rounded with the branch's shared offset (ff_dither.hpp): q = floor(v + u_b).
 __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
                                      const int32_t *__restrict__ branch_id,
                                      const double *__restrict__ abnd,
@@ -33,12 +34,36 @@ __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
         uint32_t q;
         if (weighted) {
             const double x = branch_len[b] * abnd[t];  // treeDists[id] * abnd (unifrac.go:180)
-            q = (uint32_t)(unsigned long long)rint(ldexp(x, e));
+            q = (uint32_t)(unsigned long long)floor(ldexp(x, e) + ff::branch_dither(b));
         } else {
             q = klen[b];
         }
         QT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = q;
     }
+}
+
+// The binary64 side of a FIXED32 distance: wex_s = sum_b l_b * x_s(b) (weighted: the sample's share
+// of every denominator, unifrac.go:181,187,192) or sum_b l_b over its flat nodes (unweighted:
+// result + common = (wex_i + wex_j + result) / 2).  One workgroup per sample; a fixed tree of
+// additions, so the value does not depend on the launch.  Only the integer NUMERATOR carries the
+// staging's rounding; the denominator comes from here (finish_fixed32_kernel).
+__global__ __launch_bounds__(256)
+void exact_weight_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                         const double *__restrict__ abnd, const double *__restrict__ branch_len,
+                         int weighted, double *__restrict__ wex)
+{
+    __shared__ double part[256];
+    const int64_t s = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += 256)
+        acc += branch_len[branch_id[t]] * (weighted ? abnd[t] : 1.0);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wex[s] = part[0];
 }
 
 // Branch compaction: which branches carry a flat node of any sample.

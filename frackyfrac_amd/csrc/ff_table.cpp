@@ -21,8 +21,9 @@ const size_t MAX_LINE = (size_t)1 << 25;  // sc.Buffer(nil, 1<<25), parser.go:14
 
 inline bool is_space(char c)
 {
-    // regexp \S+ (parser.go:17) splits on the RE2 \s class: \t \n \f \r and space
-    return c == ' ' || c == '\t' || c == '\n' || c == '\f' || c == '\r' || c == '\v';
+    // regexp \S+ (parser.go:17) splits on the RE2 \s class: \t \n \f \r and space -- NOT \v,
+    // which stays inside a token (and then fails ParseFloat or the species lookup)
+    return c == ' ' || c == '\t' || c == '\n' || c == '\f' || c == '\r';
 }
 
 // bufio.ScanLines: lines end at '\n', one trailing '\r' is dropped, a final

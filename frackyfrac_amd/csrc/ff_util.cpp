@@ -35,6 +35,10 @@ std::string go_quote(const std::string &s)
         case '\n': o += "\\n"; break;
         case '\t': o += "\\t"; break;
         case '\r': o += "\\r"; break;
+        case '\a': o += "\\a"; break;  // strconv.Quote's mnemonic escapes
+        case '\b': o += "\\b"; break;
+        case '\f': o += "\\f"; break;
+        case '\v': o += "\\v"; break;
         default:
             if (c < 0x20 || c == 0x7f) {
                 snprintf(tmp, sizeof tmp, "\\x%02x", c);

@@ -238,6 +238,28 @@ class ShardedRun:
         if self.world > 1:
             dist.barrier(group=self.group)
 
+    def check_precision(self):
+        """After wait(): does every rank's last run keep FIXED32's promise (refinement queue not
+        overflowed, audit sample within its bar -- Plan.check_precision)?  The verdict is taken
+        jointly: if any rank's shard fails, FFError(FF_ERR_PRECISION) is raised on EVERY rank, so
+        that all of them re-stage in EXACT64 together (unifrac_dists_sharded does)."""
+        from ._lib import FF_ERR_PRECISION, FFError
+
+        self.torch.cuda.synchronize(self.device)
+        msg = ""
+        for p in self.plans:
+            try:
+                p.check_precision()
+            except FFError as e:
+                if e.code != FF_ERR_PRECISION:
+                    raise
+                msg = str(e)
+        if self.world > 1:
+            if not self._flag_all(msg == ""):
+                raise FFError(FF_ERR_PRECISION, msg or "another rank's shard missed the FIXED32 tolerance")
+        elif msg:
+            raise FFError(FF_ERR_PRECISION, msg)
+
     @property
     def n_slots(self) -> int:
         return sum(p.n_slots for p in self.plans)
@@ -311,12 +333,22 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if compute is None:
-        run = ShardedRun(nodes, weighted, rank, world, precision=precision, root=root, group=group)
-        res = run.step()
-        run.wait()
-        out = res.cpu().numpy() if res is not None else None
-        run.close()
-        return out
+        from ._lib import FF_ERR_PRECISION, FFError
+
+        for attempt in (precision, "exact64"):
+            run = ShardedRun(nodes, weighted, rank, world, precision=attempt, root=root, group=group)
+            try:
+                res = run.step()
+                run.wait()
+                run.check_precision()  # joint: raises on every rank or on none
+                return res.cpu().numpy() if res is not None else None
+            except FFError as e:
+                if e.code != FF_ERR_PRECISION or attempt == "exact64":
+                    raise
+                # a shard somewhere holds mostly replicates (or failed its audit): every rank
+                # stages again in binary64, as ff_unifrac_dists does for one device
+            finally:
+                run.close()
     local = compute(nodes, weighted, rank, world)
     res = gather_slices(local, nodes.n_samples, rank, world, root, None, group)
     return res.numpy() if res is not None else None

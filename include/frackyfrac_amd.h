@@ -41,7 +41,8 @@ typedef enum ff_status {
     FF_ERR_IO = 5,      /* file open/read/write                                     */
     FF_ERR_INTERNAL = 6,
     FF_ERR_PRECISION = 7 /* ff_plan_run_host: more nearly identical pairs than the FIXED32 plan can
-                            re-compute exactly (a data set of replicates); stage an EXACT64 plan */
+                            re-compute exactly (a data set of replicates), or its run-time audit
+                            failed (ff_plan_audit); stage an EXACT64 plan */
 } ff_status;
 
 /* ------------------------------------------------------------------------- *
@@ -68,7 +69,10 @@ typedef enum ff_precision {
     FF_PRECISION_AUTO = 0,    /* EXACT64 when pairs*branches <= 2^32 (about a millisecond) or
                                  when FIXED32 is not applicable, else FIXED32                 */
     FF_PRECISION_FIXED32 = 1, /* 32-bit fixed point, integer sums: order-independent, exact
-                                 for unweighted whenever all branch lengths are k * 2^-e;
+                                 for unweighted whenever all branch lengths are k * 2^-e,
+                                 else within 1e-6 relative (per-branch shared rounding offset,
+                                 binary64 denominators, exact re-computation of near-equal
+                                 pairs, run-time audit);
                                  weighted runs on the vector ALU (v_sad_u32), unweighted on
                                  the int8 matrix cores (same integers, same results)          */
     FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
@@ -119,7 +123,7 @@ typedef struct ff_tree ff_tree; /* section 2 */
 /* What the staging decided; read back with ff_plan_info. */
 typedef struct ff_plan_info {
     int32_t precision;        /* FF_PRECISION_FIXED32 or FF_PRECISION_EXACT64 actually used   */
-    int32_t scale_log2;       /* FIXED32: values are round(x * 2^scale_log2)                  */
+    int32_t scale_log2;       /* FIXED32: values are floor(x * 2^scale_log2 + u_branch)       */
     int32_t lengths_exact;    /* FIXED32 unweighted: 1 if every branch length is an exact
                                  multiple of 2^-scale_log2 (results then bit-exact)           */
     int32_t n_compute_units;  /* CUs of the device                                            */
@@ -197,6 +201,17 @@ int ff_plan_timing_collect(ff_plan *plan, double *total_ms, int32_t *launches);
  * value (ff_unifrac_dists then repeats the shard in EXACT64 by itself).
  */
 int ff_plan_refined_pairs(ff_plan *plan, int64_t *queued, int64_t *capacity);
+
+/*
+ * FIXED32's run-time audit.  When a shard is scheduled, a fixed pseudo-random sample of its
+ * pairs (up to 4096) is computed in binary64 on the device; every run compares what it
+ * delivered for them.  After a run has completed: the sample size, how many sampled pairs were
+ * further than 0.5e-6 (relative) from their binary64 value, and the largest relative error seen.
+ * failed > 0 means the run must not be trusted to the 1e-6 bar: ff_plan_run_host returns
+ * FF_ERR_PRECISION, ff_unifrac_dists / ff_unifrac / the CLI repeat the shard in EXACT64.
+ * checked == 0 when the plan's integers are exact (EXACT64; unweighted on the binary grid).
+ */
+int ff_plan_audit(ff_plan *plan, int64_t *checked, int64_t *failed, double *max_rel_err);
 
 /* ------------------------------------------------------------------------- *
  * 2. Host surface either side of the hot path

@@ -39,7 +39,9 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libunifrac_oracle.so")
 # Loaders -- parser/parser.go
 # ----------------------------------------------------------------------------
 
-_SPLITTER = re.compile(r"\S+")  # parser/parser.go:17
+# parser/parser.go:17 `\S+`: Go's regexp is RE2, whose \s is exactly [\t\n\f\r ] -- a vertical tab
+# (or a Unicode space) stays INSIDE a token there, unlike Python's \s
+_SPLITTER = re.compile(r"[^\t\n\f\r ]+")
 
 
 class OracleError(Exception):
@@ -50,6 +52,8 @@ def _go_float(tok: str) -> float:
     """strconv.ParseFloat(tok, 64) for the spellings a table can hold."""
     t = tok.replace("_", "x")  # Go accepts '_' only with base prefixes; reject
     try:
+        if any(c.isspace() for c in t):  # Python's float() strips white space, ParseFloat does not
+            raise ValueError(tok)
         if t.lower().lstrip("+-") in ("inf", "infinity", "nan"):
             return float(t)
         if t.lower().lstrip("+-").startswith("0x"):
@@ -58,7 +62,7 @@ def _go_float(tok: str) -> float:
             return float.fromhex(t)
         return float(t)
     except ValueError:
-        raise OracleError('strconv.ParseFloat: parsing "%s": invalid syntax' % tok)
+        raise OracleError('strconv.ParseFloat: parsing %s: invalid syntax' % go_quote(tok))
 
 
 def _go_f(f: float) -> str:
@@ -245,8 +249,11 @@ def validate_species(abnd: Sequence[Dict[str, float]], tree: Node) -> None:
 
 
 def go_quote(s: str) -> str:
-    """%q for the printable-ASCII names tables hold."""
-    return '"' + s.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    """strconv.Quote / %q: mnemonic escapes for BEL BS FF LF CR TAB VT, backslash-x-hex for the
+    other control bytes, printable text as it is."""
+    esc = {'"': '\\"', "\\": "\\\\", "\a": "\\a", "\b": "\\b", "\f": "\\f", "\n": "\\n", "\r": "\\r",
+           "\t": "\\t", "\v": "\\v"}
+    return '"' + "".join(esc.get(c, "\\x%02x" % ord(c) if (ord(c) < 0x20 or ord(c) == 0x7f) else c) for c in s) + '"'
 
 
 @dataclass

@@ -1,0 +1,156 @@
+"""FIXED32 on inputs that correlate rounding residuals: equal branch lengths (unit-length
+taxonomy trees, cladograms) with repeated counts (singletons).  With round-to-nearest
+staging thousands of branches shared one residual and the error of a weighted distance
+grew like k instead of sqrt(k): 2.7e-6 on case (a) below, no pair queued for refinement
+(round-1 VERDICT, "What's weak" #1; tools/emulate_fixed32.py reproduces it on the CPU).
+The staging now rounds with one offset per branch shared by all samples and divides by
+binary64 weights; these tests hold every pair of those inputs to the 1e-6 bar of
+unifracDistWeighted (frcfrc/unifrac.go:174-205) against the oracle, through the C ABI
+and through the frcfrc command.  Needs an MI355X: `pytest -m gpu`."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import frackyfrac_amd as ff
+from frackyfrac_amd import _lib as L
+from frackyfrac_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+WEIGHTED_RTOL = 1e-6  # north_star: "within 1e-6 relative for weighted"
+
+
+def low_diversity(ns, nl, dens, lengths, counts, seed=5):
+    """synth.make's tree and presence pattern with every branch length replaced by `lengths`
+    (scalar or array; the root keeps 0) and the counts drawn from a narrow set."""
+    tree, ptr, idx, val = synth.make(ns, nl, dens, seed)
+    rng = np.random.default_rng(11)
+    tree.branch_len[:] = lengths
+    tree.branch_len[0] = 0.0
+    if counts == "ones":
+        val = np.ones_like(val)
+    elif counts == "low":  # 70 % 1, 21 % 2, the rest 3..5
+        r = rng.random(len(val))
+        val = np.where(r < 0.70, 1.0, np.where(r < 0.91, 2.0, 3.0 + np.floor(3 * rng.random(len(val)))))
+    return tree, ptr, idx, val
+
+
+def both_sides(tree, ptr, idx, val, leave):
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val, leave_unnormalized=leave)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 2 if leave else 0)
+    return nodes, ip, on, ft
+
+
+def rel_err(got, want):
+    assert not np.isnan(want).any() and not np.isnan(got).any()
+    return np.abs(got - want) / np.abs(want)
+
+
+CASES = {
+    "a_unit_lengths_counts_1": dict(ns=8, nl=10000, dens=0.3, lengths=1.0, counts="ones"),
+    "b_tenth_lengths_counts_1_2": dict(ns=8, nl=10000, dens=0.3, lengths=0.1, counts="low"),
+    "b2_unit_lengths_counts_1_2": dict(ns=8, nl=10000, dens=0.3, lengths=1.0, counts="low"),
+    "c_50k_leaves_5pct": dict(ns=8, nl=50000, dens=0.05, lengths=0.1, counts="low"),
+    "d_more_samples": dict(ns=96, nl=4000, dens=0.3, lengths=1.0, counts="ones"),
+}
+
+
+@pytest.mark.parametrize("leave", [False, True], ids=["normalised", "-l"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_fixed32_weighted_low_diversity_every_pair(case, leave):
+    nodes, ip, on, ft = both_sides(*low_diversity(**CASES[case]), leave)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=4)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.precision == L.PRECISION_FIXED32
+    got = plan.run_host()  # FF_ERR_PRECISION would raise: neither queue overflow nor audit failure
+    err = rel_err(got, want)
+    assert err.max() <= WEIGHTED_RTOL, (case, leave, float(err.max()), int(err.argmax()))
+    n, bad, worst = plan.audit()
+    assert n == min(4096, len(want)) and bad == 0 and worst <= 0.5e-6
+    # the audit sample covers every pair here (fewer than 4096): its worst error is the one measured
+    # (to the ~1e-15 by which its order of additions differs from the oracle's)
+    assert worst <= err.max() * 1.001 + 1e-12
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["a_unit_lengths_counts_1", "b_tenth_lengths_counts_1_2"])
+def test_fixed32_low_diversity_through_the_cli(tmp_path, case):
+    """The command with -precision fixed32 (what AUTO selects at scale) on the same inputs,
+    normalised and -l, against the oracle's values."""
+    tree, ptr, idx, val = low_diversity(**CASES[case])
+    (tmp_path / "t.tree").write_text(tree.newick())
+    (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr, idx, val))
+    for leave in (False, True):
+        nodes, ip, on, ft = both_sides(tree, ptr, idx, val, leave)
+        want = O.unifrac_dists(ip, on, ft.dist, True)
+        r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", *(["-l"] if leave else []), "-precision", "fixed32", "-stats",
+                            "-i", str(tmp_path / "t.sparse"), "-t", str(tmp_path / "t.tree")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert '"precision": "fixed32"' in r.stderr
+        got = np.array([float(x) for x in r.stdout.split()])
+        assert rel_err(got, want).max() <= WEIGHTED_RTOL
+
+
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_fixed32_unweighted_few_distinct_lengths(mfma, monkeypatch):
+    """Unweighted with lengths off the binary grid and only a few distinct values (every
+    internal branch 0.1, every leaf 0.3): round-to-nearest gives all leaves one residual and all
+    internal branches another, which does not cancel in result/(result+common).  Both kernels
+    (int8 matrix cores, v_sad_u32) must stay within 1e-6 of unifracDistUnweighted
+    (unifrac.go:144-171); the CLI says when unweighted is tolerance-grade."""
+    monkeypatch.setenv("FF_UNWEIGHTED_MFMA", mfma)
+    tree, ptr, idx, val = synth.make(64, 6000, 0.2, 7)
+    lengths = np.where(tree.size == 1, 0.3, 0.1)
+    tree.branch_len[:] = lengths
+    tree.branch_len[0] = 0.0
+    nodes, ip, on, ft = both_sides(tree, ptr, idx, val, False)
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=4)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.lengths_exact == 0
+    assert plan.info.kernel == (2 if mfma == "1" else 0)
+    got = plan.run_host()
+    assert rel_err(got, want).max() <= WEIGHTED_RTOL
+    n, bad, worst = plan.audit()
+    assert n == len(want) and bad == 0
+    plan.close()
+
+
+def test_disjoint_samples_are_at_distance_exactly_one():
+    """Samples that share no branch but the root (length 0): numer == denom term by term, so the
+    reference returns exactly 1 (unifrac.go:204); FIXED32 must too, although its denominator
+    is binary64 and its numerator an integer."""
+    tree, ptr, idx, val = synth.make(2, 64, 0.5, 3)
+    tree.branch_len[:] = 0.1
+    tree.branch_len[0] = 0.0
+    left = np.flatnonzero(tree.leaf_ids < 1 + tree.size[1])  # leaves under the root's first child
+    right = np.flatnonzero(tree.leaf_ids >= 1 + tree.size[1])
+    ptr = np.array([0, len(left), len(left) + len(right)], dtype=np.int64)
+    idx = np.concatenate([tree.leaf_ids[left], tree.leaf_ids[right]])
+    val = np.concatenate([np.full(len(left), 3.0), np.full(len(right), 7.0)])
+    nodes, ip, on, ft = both_sides(tree, ptr, idx, val, False)
+    # the root is a flat node of both samples, with length 0
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    assert want.tolist() == [1.0]
+    for weighted in (True, False):
+        got = ff.unifrac_dists(nodes, weighted, precision="fixed32")
+        assert got.tolist() == [1.0]
+
+
+def test_identical_samples_are_at_distance_exactly_zero():
+    """Equal values get equal integers whatever the branch's offset: replicates are at 0."""
+    tree, ptr, idx, val = low_diversity(2, 3000, 0.3, 0.1, "low")
+    a, b = slice(ptr[0], ptr[1]), slice(ptr[1], ptr[2])
+    ka, kb = int(ptr[1] - ptr[0]), int(ptr[2] - ptr[1])
+    ptr = np.array([0, ka, 2 * ka, 2 * ka + kb], dtype=np.int64)  # samples: A, A again, B
+    idx = np.concatenate([idx[a], idx[a], idx[b]])
+    val = np.concatenate([val[a], val[a], val[b]])
+    nodes, ip, on, ft = both_sides(tree, ptr, idx, val, False)
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    got = ff.unifrac_dists(nodes, True, precision="fixed32")
+    assert want[0] == 0.0 and got[0] == 0.0
+    assert rel_err(got[1:], want[1:]).max() <= WEIGHTED_RTOL

@@ -73,6 +73,7 @@ LOADER_TEXTS_DENSE = [
     "a a b\n1 2 3\n4 0 5\n",                             # duplicate header: last non-zero wins
     "x\n1e3\n+2\n0x1p-2\n",
     "a b\r\n1 2\r\n",
+    "a\vb c\n1 2\n",                                     # \v is not in RE2's \s: "a\vb" is ONE species name
 ]
 LOADER_TEXTS_SPARSE = [
     "a:11 b:222  \n  b:32 c:7\n\nd:1\tc:4\ta:10\n",     # parser_test.go:29
@@ -80,6 +81,8 @@ LOADER_TEXTS_SPARSE = [
     "c:d:e::5\n",                                         # split at the last colon
     "\n\n",
     "a:1",                                                # no trailing newline
+    "a\vb:1 c:2\n",                                       # vertical tab inside a name
+    "a:1\vb:2\n",                                         # ... is no separator: one token, name "a:1\vb"
 ]
 
 
@@ -94,8 +97,9 @@ def test_sparse_loader_matches_oracle(text):
 
 
 ERR_DENSE = ["\n1 2\n", "a b\n1\n", "a b\n1 x\n", "a b\n1 -2\n", "a b\n1 2\n\n", "a\ninf\n", "a\nnan\n",
-             "a\n1e999\n", "a b\n1 2 3\n", "a\n1_0\n", "a\n-\n", "a\n0x10\n"]
-ERR_SPARSE = ["a:1 b\n", ":1\n", "a:0\n", "a:nan\n", "a:-1\n", "a:\n", "a:1e999\n", "a:+Inf\n", "b:1 a:x:y\n"]
+             "a\n1e999\n", "a b\n1 2 3\n", "a\n1_0\n", "a\n-\n", "a\n0x10\n",
+             "a b\n1\v2 3\n"]  # a vertical tab does not split: "1\v2" is one token and not a number
+ERR_SPARSE = ["a:1 b\n", ":1\n", "a:0\n", "a:nan\n", "a:-1\n", "a:\n", "a:1e999\n", "a:+Inf\n", "b:1 a:x:y\n", "a:1\vb:x\n"]
 
 
 @pytest.mark.parametrize("text", ERR_DENSE)
