@@ -131,6 +131,8 @@ def self_launch(n_gpus, argv):
             log(ln)
     if lines:
         print(lines[-1], flush=True)
+    if os.environ.get("FF_BENCH_TRACE_IMPORTS"):  # (tests)
+        log("parent imported torch: %s" % ("torch" in sys.modules))
     return r.returncode if r.returncode else (0 if lines else 1)
 
 

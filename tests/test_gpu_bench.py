@@ -1,0 +1,56 @@
+"""bench.py end to end on the GPU box: the N = 1 line with its `secondary` entries, and the
+N > 1 path through the SELF-LAUNCH (`python bench.py --gpus 2`, no torch.distributed.run around
+it) rehearsed with two ranks on the one GPU (gloo as control plane)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_self_launch_runs_two_ranks_and_prints_one_line():
+    out, err = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--workload",
+                         "768x1500", "--no-cpu-baseline", "--no-secondary", "--scaling", "strong")
+    assert "launching 2 ranks" in err
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong"
+    assert out["config"]["pairs"] == 768 * 767 // 2
+    assert out["gather"]["transport"] in ("ipc", "nccl")
+    assert "REHEARSAL" in out["data"]
+    assert out["roofline"]["launches"] == 3 and out["roofline"]["kernel_ms"] > 0
+    # weak scaling: the sample count grows as sqrt(N), rounded to 32
+    out, _ = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--workload",
+                       "768x1500", "--no-cpu-baseline", "--no-secondary")
+    assert out["scaling"] == "weak" and out["config"]["pairs"] == 1088 * 1087 // 2
+
+
+def test_single_gpu_line_carries_the_secondary_entries():
+    out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--cpu-budget", "3")
+    assert out["n_gpus"] == 1 and out["dtype"] == "u32" and out["config"]["workload"].startswith("C3:")
+    assert out["roofline"]["kernel"] == "pair_sad_kernel" and 0.5 < out["roofline"]["frac"] < 1.0
+    assert out["audit"]["pairs"] == 4096 and out["audit"]["failed"] == 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1
+    sec = out["secondary"]
+    assert [e["config"]["workload"].split(":")[0] for e in sec] == ["C3", "C3", "C2", "C4", "C5"]
+    assert [e["dtype"] for e in sec] == ["f64", "i8", "i8", "u32", "u32"]
+    assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_kernel"
+    assert sec[1]["roofline"]["bound"] == "mfma" and "unweighted" in sec[1]["config"]["workload"]
+    assert sec[3]["config"]["pairs"] == 16384 * 16383 // 2 and sec[4]["config"]["pairs"] == 8192 * 8191 // 2
+    for e in sec:
+        assert e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < 1.0
