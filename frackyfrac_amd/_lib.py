@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfrackyfrac_amd.so")
+# FF_LIB_PATH: another build of the same library (tools/mfma_diag.py times ablated kernels from one)
+LIB_PATH = os.environ.get("FF_LIB_PATH") or os.path.join(_HERE, "lib", "libfrackyfrac_amd.so")
 FRCFRC_PATH = os.path.join(_HERE, "lib", "frcfrc")
 
 FF_OK = 0

@@ -93,8 +93,9 @@ struct ff_plan {
     int n_audit = 0;
     // FIXED32 unweighted on the matrix cores
     bool mfma = false;
-    int8_t *d_P8 = nullptr, *d_K8 = nullptr;
-    int64_t m_ldb = 0, m_plane = 0;
+    unsigned long long *d_Pbits = nullptr;  // presence, one 64-bit word per (64-branch slab, sample), slab-major
+    int8_t *d_Kd = nullptr;                 // base-128 digits of the integer branch lengths, [digit][row]
+    int64_t m_ldb = 0, m_n8 = 0;
     int m_digits = 0;
     MItem *d_mitems = nullptr;
     int32_t *d_mitem_ptr = nullptr;
@@ -322,8 +323,8 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_wex);
     (void)hipFree(pl->d_audit_slots);
     (void)hipFree(pl->d_audit_exact);
-    (void)hipFree(pl->d_P8);
-    (void)hipFree(pl->d_K8);
+    (void)hipFree(pl->d_Pbits);
+    (void)hipFree(pl->d_Kd);
     (void)hipFree(pl->d_mitems);
     (void)hipFree(pl->d_mitem_ptr);
     (void)hipFree(pl->d_partial);
@@ -663,7 +664,7 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_ptile_ptr);
     pl->n_ptiles = 0;
     const int64_t slabs = pl->m_ldb / M_KSLAB;
-    const int G = inf.n_compute_units;  // one 8-wave workgroup per CU
+    const int G = inf.n_compute_units * M_WGS_PER_CU;  // one 8-wave workgroup per CU
     pl->n_mgroups = G;
     std::vector<MItem> mi;
     std::vector<int32_t> mptr;
@@ -682,13 +683,13 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     pl->n_mitems = (int)mi.size();
     inf.n_tiles = n_mtiles;
     inf.n_items = (int64_t)mi.size();
-    inf.n_wave_slots = (int64_t)G * 8;
+    inf.n_wave_slots = (int64_t)G * (M_THREADS / 64);
     inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)pl->m_ldb * pl->m_digits;
     FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
     FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
     if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
     FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
-    pl->lds_bytes = (size_t)M_STAGES * M_STAGE;
+    pl->lds_bytes = (size_t)M_LDS_BYTES;
     pl->m_all_private = !mi.empty();
     for (const MItem &it : mi) pl->m_all_private = pl->m_all_private && it.pad > 0;
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
@@ -838,7 +839,7 @@ int compact_branches(StageCtx &x, char *err, size_t errlen)
 int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
-    // presence / digit planes, sample-major, zero padded to whole tiles and slabs
+    // presence bits (slab-major 64-bit words) and per-branch digits, zero padded to whole tiles and slabs
     pl->mfma = true;
     inf.kernel = FF_KERNEL_MFMA_I8;
     inf.lengths_exact = q.lengths_exact;
@@ -851,24 +852,39 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
     inf.n_digits = digits;
     const int64_t n8 = round_up(N, M_TILE_I);
     const int64_t ldb = round_up(R, M_KSLAB);  // whole slabs
+    const int64_t n_slabs = ldb / M_KSLAB;
     pl->m_ldb = ldb;
-    pl->m_plane = n8 * ldb;
+    pl->m_n8 = n8;
     inf.ld = n8;
     inf.rows_padded = ldb;
-    const size_t plane_bytes = (size_t)n8 * (size_t)ldb;
-    inf.staged_bytes = (double)plane_bytes * (1 + digits);
-    FF_ALLOC(pl->d_P8, plane_bytes, "the presence plane");
-    FF_ALLOC(pl->d_K8, plane_bytes * (size_t)digits, "the branch-length digit planes");
-    FF_HIP(hipMemset(pl->d_P8, 0, plane_bytes));
-    FF_HIP(hipMemset(pl->d_K8, 0, plane_bytes * (size_t)digits));
+    // (+ M_PAD_SLABS slabs of zeros behind both arrays: the kernel's prefetches run past an item's end)
+    const size_t bits_bytes = sizeof(unsigned long long) * (size_t)(n_slabs + M_PAD_SLABS) * (size_t)n8;
+    const size_t digit_bytes = (size_t)(ldb + M_PAD_SLABS * M_KSLAB) * (size_t)(digits + 1);  // (+1: a single-digit item reads its plane twice)
+    inf.staged_bytes = (double)bits_bytes + (double)digit_bytes;
+    FF_ALLOC(pl->d_Pbits, bits_bytes, "the presence bits");
+    FF_HIP(hipMalloc(&pl->d_Kd, digit_bytes));
+    FF_HIP(hipMemset(pl->d_Pbits, 0, bits_bytes));
     FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
     FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
+    {
+        // digits in the kernel's order of the 64 branches of a slab: chunk C, dword kk, byte q holds
+        // branch 32 * (C >> 1) + 8 * q + 4 * (C & 1) + kk (ff_kernels_mfma.hpp)
+        std::vector<int8_t> kd(digit_bytes, 0);
+        for (int64_t r = 0; r < R; ++r) {
+            const uint32_t k = q.klen[(size_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r])];
+            const int64_t slab = r / M_KSLAB, w = r % M_KSLAB;  // w = 32 * h + 8 * q + 4 * c1 + kk
+            const int64_t h = w >> 5, qq = (w >> 3) & 3, c1 = (w >> 2) & 1, kk = w & 3;
+            const int64_t pos = slab * M_KSLAB + (2 * h + c1) * 16 + kk * 4 + qq;
+            for (int d = 0; d < digits; ++d) kd[(size_t)d * (size_t)ldb + (size_t)pos] = (int8_t)((k >> (7 * d)) & 127u);
+        }
+        FF_HIP(hipMemcpy(pl->d_Kd, kd.data(), digit_bytes, hipMemcpyHostToDevice));
+    }
     Scratch<uint32_t> klen;
     FF_HIP(klen.alloc((size_t)B));
     FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
     if (nnz > 0)
-        stage_mfma_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, digits, row_of.p, pl->d_P8,
-                                                             pl->d_K8, ldb, pl->m_plane, pl->d_W);
+        stage_mfma_bits_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, row_of.p, pl->d_Pbits, n8,
+                                                                  n_slabs, pl->d_W);
     FF_HIP(hipGetLastError());
     FF_HIP(hipDeviceSynchronize());
     klen.release();
@@ -1116,10 +1132,27 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->mfma) {
+            auto kern = pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>;
+#ifdef FF_MFMA_DIAG  // ablations for timing only (wrong results): see the kernel's DIAG parameter
+            switch (env_int("FF_MFMA_DIAG", 0)) {
+            case 1: kern = pair_common_mfma_kernel<false, 1>; break;
+            case 2: kern = pair_common_mfma_kernel<false, 2>; break;
+            case 4: kern = pair_common_mfma_kernel<false, 4>; break;
+            case 8: kern = pair_common_mfma_kernel<false, 8>; break;
+            case 16: kern = pair_common_mfma_kernel<false, 16>; break;
+            case 6: kern = pair_common_mfma_kernel<false, 6>; break;
+            case 14: kern = pair_common_mfma_kernel<false, 14>; break;
+            case 15: kern = pair_common_mfma_kernel<false, 15>; break;
+            case 30: kern = pair_common_mfma_kernel<false, 30>; break;
+            case 31: kern = pair_common_mfma_kernel<false, 31>; break;
+            default: break;
+            }
+            if (env_int("FF_MFMA_DIAG", 0))
+                FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+#endif
             if (pl->n_mitems > 0)
-                (pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>)
-                    <<<dim3((unsigned)pl->n_mgroups), dim3(512), pl->lds_bytes, st>>>(
-                    pl->d_P8, pl->d_K8, pl->m_ldb, pl->m_plane, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
+                kern<<<dim3((unsigned)pl->n_mgroups), dim3(M_THREADS), pl->lds_bytes, st>>>(
+                    reinterpret_cast<const uint2 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin);
             if (pl->n_ptiles > 0)
                 reduce_partials_kernel<<<dim3(M_TILE_I * M_TILE_J / 256, (unsigned)pl->n_ptiles), dim3(256), 0, st>>>(

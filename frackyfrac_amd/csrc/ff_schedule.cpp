@@ -203,8 +203,7 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
 {
     // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
     // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
-    // 32 workgroups of one XCD then share their operand rows through that XCD's L2
-    // (without this every slab of every tile came over the fabric: 2.7 GB per pass).
+    // 32 workgroups of one XCD then share their operand rows through that XCD's L2.
     struct MT {
         int32_t i0, j0;
     };
@@ -315,7 +314,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
     int64_t n = 0;
     if (kernel == FF_KERNEL_MFMA_I8) {
         std::vector<MItem> items;
-        const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, rows, n_digits, n_cu, &items, &ptr, nullptr, nullptr);
+        const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, rows, n_digits, n_cu * M_WGS_PER_CU, &items, &ptr, nullptr, nullptr);
         if (n_tiles_out) *n_tiles_out = nt;
         n = (int64_t)items.size();
         if (n > max_items) return -n;

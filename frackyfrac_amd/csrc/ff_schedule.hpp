@@ -40,11 +40,11 @@ struct XTile {
 // ---- int8 MFMA kernel (pair_common_mfma_kernel) ----
 constexpr int M_TILE_I = 256;  // workgroup tile: 256 i-samples x 128 j-samples,
 constexpr int M_TILE_J = 128;  //   8 waves (4 x 2) of 64 x 64, i.e. 2 x 2 MFMA tiles per wave and digit plane
-constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps)
+constexpr int M_THREADS = 512; // two waves per SIMD
+constexpr int M_WGS_PER_CU = 1;
+constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps) = bits of a presence word
 constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
-constexpr int M_ROWS = M_TILE_I + M_ND * M_TILE_J;  // 512 operand rows per slab
-constexpr int M_STAGE = M_ROWS * M_KSLAB;           // 32 KiB per LDS stage, rows unpadded
-constexpr int M_STAGES = 4;                         // slab S lives in stage S % 4
+constexpr int M_LDS_BYTES = 512 * 2 * M_KSLAB;  // the digit table: 512 slabs x 2 planes x 64 digits (ff_kernels_mfma.hpp M_TABLE_SLABS)
 
 // One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
 // d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]

@@ -15,7 +15,7 @@ def schedule(kernel, n, rows, rb, re, n_cu, digits=2, narrow=1):
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
-    slots = n_cu * 8 if kernel == 0 else n_cu
+    slots = n_cu * 8 if kernel == 0 else n_cu  # SAD: 8 waves per CU; MFMA: one workgroup per CU
     cap = 1 << 20
     items = np.zeros((cap, 8), dtype=np.int32)
     ptr = np.zeros(slots + 1, dtype=np.int32)

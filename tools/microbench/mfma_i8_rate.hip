@@ -1,0 +1,74 @@
+// Raw v_mfma_i32_32x32x32_i8 rate: 8 accumulator tiles per wave (the product kernel's shape), one
+// or two waves per SIMD, operands in registers; optionally N plain VALU instructions per MFMA.
+// Prints cycles per MFMA per SIMD (from the in-kernel clock) and the clock held.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int WAVES, int NVALU>
+__global__ __launch_bounds__(WAVES * 64) void rate(int* out, int iters, int seed, unsigned long long* clk)
+{
+    v16i acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    v4i a[2], b[4];
+    for (int q = 0; q < 2; ++q) a[q] = v4i{(int)threadIdx.x * 0x01010101 & 0x01010101, seed & 0x01000100, 0x00010001, q};
+    for (int q = 0; q < 4; ++q) b[q] = v4i{(int)(threadIdx.x * 2654435761u) & 0x7f7f7f7f, seed * 77 & 0x7f7f7f7f, 0x01020304, q};
+    uint32_t x = threadIdx.x, y = seed;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t & 1], b[t >> 1], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NVALU; ++v) {
+                x = (x >> 3) & 0x01010101u;
+                y = (y + x) ^ 0x80808080u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a[0][3] += (int)(y & 1);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int t = (int)x + (int)y;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[q][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+    if (threadIdx.x == 0 && blockIdx.x == 7) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int WAVES, int NVALU> void run(int* d, unsigned long long* dc)
+{
+    const int iters = 20000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        rate<WAVES, NVALU><<<256, WAVES * 64>>>(d, iters, 123, dc);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    unsigned long long hc[2];
+    CK(hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost));
+    const double mfma_per_simd = (double)iters * 8 * (WAVES / 4);
+    printf("%d waves/SIMD, %d VALU pairs per MFMA: %.3f ms, %.1f cycles per MFMA per SIMD, clock %.2f GHz, %.2f POP/s\n",
+           WAVES / 4, NVALU, ms, (double)hc[0] / mfma_per_simd, (double)hc[0] / hc[1] * 0.1,
+           mfma_per_simd * 1024 * 65536.0 / ms / 1e12);
+}
+
+int main()
+{
+    int* d; CK(hipMalloc(&d, 256 * 512 * 4));
+    unsigned long long* dc; CK(hipMalloc(&dc, 16));
+    run<4, 0>(d, dc); run<8, 0>(d, dc);
+    run<8, 1>(d, dc); run<8, 2>(d, dc); run<8, 3>(d, dc); run<8, 4>(d, dc); run<8, 6>(d, dc);
+    run<4, 2>(d, dc); run<4, 4>(d, dc);
+    return 0;
+}
