@@ -76,24 +76,35 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
 
 // Persistent: workgroup g runs items[item_ptr[g] .. item_ptr[g+1]).
 //
-// 256 x 128 tile per workgroup, eight waves (4 x 2) of 64 x 64 = 2 x 2 MFMA tiles per digit plane.
-// Per slab a lane loads the presence words of its two i-samples and its two j-samples (four 8-byte
-// loads, one slab ahead) and, per k-step: reads the 2 x 16 digits of its half-wave from the LDS
-// table (two ds_read_b128, two addresses per wave: broadcast), turns the i-words into the A
-// fragments (2 instructions per dword), the j-words into byte masks 0x00 / 0xFF (3 per dword:
-// shift, and, one packed 16-bit multiply by 0x00FF) and the digits under those masks into the B
-// fragments of both planes, then issues the 8 MFMAs: about 7 vector instructions per MFMA, which
-// two waves per SIMD hide under each other's MFMAs (tools/microbench/mfma_i8_rate.hip: up to 12
-// per MFMA cost nothing).
+// 256 x 128 tile per workgroup, FOUR waves (2 x 2), one per SIMD, each 128 x 64 = 4 x 2 MFMA tiles
+// per digit plane: 256 accumulator registers per lane, which is why there is one wave per SIMD (up
+// to 512 VGPRs).  The reason for the big per-wave tile is the vector ALU: a wave64 integer
+// instruction occupies its SIMD's vector issue for about 4.4 cycles and an MFMA for 8 of its 32
+// (tools/microbench/mfma_i8_rate.hip: beyond six vector instructions per MFMA the matrix pipe
+// waits), and building the fragments costs about 1.75 instructions per A dword and 4.75 per pair of
+// B dwords (both planes share the mask).  A 64 x 64 wave tile needs 7.5 per MFMA and ran at 45
+// cycles per MFMA; with 4 x 2 tiles every B fragment serves four MFMAs per plane: 4.7 per MFMA.
+//
+// The loop runs over k-steps (two per slab).  K-step u issues the 16 MFMAs of fragment set u & 1
+// while the vector ALU builds set (u + 1) & 1, a piece of at most six instructions behind each MFMA.
+// The MFMAs are inline asm: volatile asm statements keep their program order, which is the only
+// way to hold this interleave (the compiler's own schedule is "all vector work, then all MFMAs",
+// and a pure intrinsic has no place of its own in the instruction selector's order).  The price is
+// that the compiler no longer sees matrix instructions: nothing here reads an accumulator or
+// rewrites a fragment register within 16 MFMAs of the instruction concerned, and the epilogue
+// waits out the last MFMA with explicit s_nop.
+// Inputs of a piece: the lane's presence words of i-samples `lane`, 64 + `lane` and j-sample `lane`
+// of the wave's 128 + 64 (one 512-byte load each per slab, two slabs ahead; v_permlane32_swap then
+// gives every lane the words of rows lane & 31 and 32 + (lane & 31) of each 64, which is what the
+// MFMA fragments hold) and the half-wave's 2 x 16 digits from the LDS table (two k-steps ahead).
 //
 // ALL_PRIVATE: every item of the launch has a private partial tile (a problem smaller than one
-// round); the epilogue is then the plain stores alone, which keeps that variant's code small --
-// the kernel's speed on such problems turned out to depend on it (35 vs 50 us at C2).
+// round); the epilogue is then the plain stores alone.
 // DIAG (builds with -DFF_MFMA_DIAG only; results are then WRONG, the time is what is asked for):
 // bit 1 drops the global loads inside the loop, bit 2 the expansion (vector work), bit 3 the
 // digit reads, bit 4 the MFMAs.
 template <bool ALL_PRIVATE, int DIAG = 0>
-__global__ __launch_bounds__(M_THREADS, 2)
+__global__ __launch_bounds__(M_THREADS, 1)
 void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                              const int8_t *__restrict__ Kd, int64_t ldb, const MItem *__restrict__ items,
                              const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
@@ -110,16 +121,16 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
         const MItem item = items[it];
         const int nd = item.nd;
         const int nslab = (item.k1 - item.k0) / M_KSLAB;
-        // this lane's samples: one row of the 64 x 64 sub-tile on either side
-        const uint2 *pa = Pbits + (int64_t)(item.k0 / M_KSLAB) * n8 + item.i0 + wi * 64 + lane;
+        // this lane's samples: rows `lane` and 64 + `lane` of the wave's 128 i-samples, row `lane` of its 64 j-samples
+        const uint2 *pa = Pbits + (int64_t)(item.k0 / M_KSLAB) * n8 + item.i0 + wi * 128 + lane;
         const uint2 *pb = Pbits + (int64_t)(item.k0 / M_KSLAB) * n8 + item.j0 + wj * 64 + lane;
         const int8_t *dig_src[2] = {Kd + (int64_t)item.d0 * ldb + item.k0,
                                     Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0};
-        mfma_v16i acc[M_ND][2][2];
+        mfma_v16i acc[M_ND][4][2];
 #pragma unroll
         for (int d = 0; d < M_ND; ++d)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -134,148 +145,208 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                     *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
             }
             __syncthreads();
-            // One slab: the lane's word of i-sample `lane` and of j-sample `lane` of the wave's 64 + 64
-            // (one 512-byte load each; v_permlane32_swap then gives every lane the words of rows
-            // lane & 31 and 32 + (lane & 31), which is what the MFMA fragments hold), 16 MFMAs.
-            const int8_t *tab = mfma_lds + (2 * 0 + half) * 16;
-            auto slab_step = [&](const uint2 &wx, const uint2 &wy, int sl) {
-                uint32_t xw[2][2], yw[2][2];  // [k-step][row block]
-                if constexpr (!(DIAG & 4)) {
-                    const auto x0 = __builtin_amdgcn_permlane32_swap(wx.x, wx.x, false, false);
-                    const auto x1 = __builtin_amdgcn_permlane32_swap(wx.y, wx.y, false, false);
-                    const auto y0 = __builtin_amdgcn_permlane32_swap(wy.x, wy.x, false, false);
-                    const auto y1 = __builtin_amdgcn_permlane32_swap(wy.y, wy.y, false, false);
-                    xw[0][0] = x0[0] >> sh; xw[0][1] = x0[1] >> sh; xw[1][0] = x1[0] >> sh; xw[1][1] = x1[1] >> sh;
-                    yw[0][0] = y0[0] >> sh; yw[0][1] = y0[1] >> sh; yw[1][0] = y1[0] >> sh; yw[1][1] = y1[1] >> sh;
-                } else {
-                    xw[0][0] = wx.x; xw[0][1] = wx.y; xw[1][0] = wx.x ^ 1; xw[1][1] = wx.y ^ 1;
-                    yw[0][0] = wy.x; yw[0][1] = wy.y; yw[1][0] = wy.x ^ 1; yw[1][1] = wy.y ^ 1;
-                }
-                mfma_v4i d0[2], d1[2];
-                if constexpr (!(DIAG & 8)) {
+            const int8_t *tab = mfma_lds + half * 16;
+            mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
+            mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
+            uint2 wa0[2], wa1[2], wb[2];               // [slab parity]: i-words of rows lane / 64 + lane, j-words
+            uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
+            uint32_t t[8];                             // its B masks in the making
+            uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        d0[kt] = *(const mfma_v4i *)(tab + sl * 128 + kt * 32);
-                        d1[kt] = *(const mfma_v4i *)(tab + sl * 128 + kt * 32 + 64);
-                    }
-                } else {
-                    d0[0] = d0[1] = d1[0] = d1[1] = mfma_v4i{sl, half, lane, 3};
-                }
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    mfma_v4i a[2], b0[2], b1[2];
-                    if constexpr (!(DIAG & 4)) {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) {
-                                a[q][kk] = (int)((xw[kt][q] >> kk) & 0x01010101u);
-                                const uint32_t one = (yw[kt][q] >> kk) & 0x01010101u;
-                                // bytes 0x00 / 0xFF: each 16-bit half (b0 + 256 b1) * 255 = 0x00FF b0 + 0xFF00 b1
-                                const mfma_u16x2 m16 = __builtin_bit_cast(mfma_u16x2, one) * (unsigned short)0x00FF;
-                                const uint32_t mask = __builtin_bit_cast(uint32_t, m16);
-                                b0[q][kk] = (int)((uint32_t)d0[kt][kk] & mask);
-                                b1[q][kk] = (int)((uint32_t)d1[kt][kk] & mask);
-                            }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            a[q] = mfma_v4i{(int)xw[kt][q], (int)yw[kt][q], kt, q};
-                            b0[q] = d0[kt];
-                            b1[q] = d1[kt];
-                        }
-                    }
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            if constexpr (!(DIAG & 16)) {
-                                acc[0][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b0[n], acc[0][m][n], 0, 0, 0);
-                                acc[1][m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b1[n], acc[1][m][n], 0, 0, 0);
-                            } else {
-                                acc[0][m][n][0] += a[m][0] ^ b0[n][0];
-                                acc[1][m][n][0] += a[m][1] ^ b1[n][1];
-                            }
-                        }
-                }
-            };
-            // two slabs in flight: buffers A (even slabs) and B (odd), each refilled right after its use
-            // (reads past the item's end on the last trips hit the arrays' padding and are never used)
+            for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
             const uint2 *qa = pa + (int64_t)seg * n8, *qb = pb + (int64_t)seg * n8;
-            uint2 ax = qa[0], ay = qb[0], bx = qa[n8], by = qb[n8];
+            wa0[0] = qa[0];
+            wa1[0] = qa[64];
+            wb[0] = qb[0];
+            wa0[1] = qa[n8];
+            wa1[1] = qa[n8 + 64];
+            wb[1] = qb[n8];
             qa += 2 * n8;
             qb += 2 * n8;
+            auto read_digits = [&](int set, int kstep) {  // kstep = 2 * slab + kt, within the segment
+                if constexpr (!(DIAG & 8)) {
+                    dg0[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64);
+                    dg1[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64 + 64);
+                } else {
+                    dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
+                }
+            };
+            // the words of slab parity `parity`, half `kt`, to where the fragments want them (3 swaps)
+            auto take_words = [&](int parity, int kt) {
+                const uint32_t w0 = kt ? wa0[parity].y : wa0[parity].x, w1 = kt ? wa1[parity].y : wa1[parity].x;
+                const uint32_t wy = kt ? wb[parity].y : wb[parity].x;
+                if constexpr (!(DIAG & 4)) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(wy, wy, false, false);
+                    swx[0] = s0[0]; swx[1] = s0[1]; swx[2] = s1[0]; swx[3] = s1[1];
+                    swy[0] = sy[0]; swy[1] = sy[1];
+                } else {
+                    swx[0] = w0; swx[1] = w1; swx[2] = w0 ^ 1; swx[3] = w1 ^ 1;
+                    swy[0] = wy; swy[1] = wy ^ 1;
+                }
+            };
+            // bytes 0/1 -> 0x00/0xFF: each 16-bit half (b0 + 256 b1) * 255 = 0x00FF b0 + 0xFF00 b1
+            auto ff_bytemask = [](uint32_t one) {
+                const mfma_u16x2 m16 = __builtin_bit_cast(mfma_u16x2, one) * (unsigned short)0x00FF;
+                return __builtin_bit_cast(uint32_t, m16);
+            };
+#define FF_MM(d, m, n, A, B)                                                                       \
+    if constexpr (!(DIAG & 16))                                                                    \
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[d][m][n]) : "v"(A), "v"(B)); \
+    else acc[d][m][n][0] += A[0] ^ B[0];                                                           \
+    __builtin_amdgcn_sched_barrier(0)
+#define FF_OP(stmt) if constexpr (!(DIAG & 4)) { stmt; }
+#define FF_END_PIECE() __builtin_amdgcn_sched_barrier(0)
+            // K-step `u` of the current slab pair (u = 0..3; slab sl + (u >> 1), kt = u & 1): the 16 MFMAs of
+            // set `cur`, and behind them the 72 vector operations that build set `nxt` for k-step u + 1
+            // -- per B dword pair: shift, and, byte mask, two ands with the digits; per A dword: shift,
+            // and -- dealt out LEVEL BY LEVEL (all shifts, then all ands, ...), so that no instruction
+            // waits for the one in front of it: a wave alone on its SIMD has nobody to hide a
+            // dependent chain behind.  The last slot swaps in the words of k-step u + 2.
+            auto kstep = [&](int u, int sl) {
+                const int cur = u & 1, nxt = cur ^ 1;
+                const int bp2 = ((u + 2) >> 1) & 1, bkt2 = u & 1;  // slab parity and half of k-step u + 2
+                read_digits(cur, 2 * sl + u + 2);  // set `cur` is rebuilt in the NEXT k-step, for u + 2
+                __builtin_amdgcn_sched_barrier(0);
+                FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_OP(t[0] = swy[0] >> shk[0]); FF_OP(t[1] = swy[0] >> shk[1]); FF_OP(t[2] = swy[0] >> shk[2]); FF_OP(t[3] = swy[0] >> shk[3]); FF_END_PIECE();
+                FF_MM(1, 0, 0, fa[cur][0], fb1[cur][0]); FF_OP(t[4] = swy[1] >> shk[0]); FF_OP(t[5] = swy[1] >> shk[1]); FF_OP(t[6] = swy[1] >> shk[2]); FF_OP(t[7] = swy[1] >> shk[3]); FF_OP(t[0] &= 0x01010101u); FF_END_PIECE();
+                FF_MM(0, 0, 1, fa[cur][0], fb0[cur][1]); FF_OP(t[1] &= 0x01010101u); FF_OP(t[2] &= 0x01010101u); FF_OP(t[3] &= 0x01010101u); FF_OP(t[4] &= 0x01010101u); FF_OP(t[5] &= 0x01010101u); FF_END_PIECE();
+                FF_MM(1, 0, 1, fa[cur][0], fb1[cur][1]); FF_OP(t[6] &= 0x01010101u); FF_OP(t[7] &= 0x01010101u); FF_OP(t[0] = ff_bytemask(t[0])); FF_OP(t[1] = ff_bytemask(t[1])); FF_OP(t[2] = ff_bytemask(t[2])); FF_END_PIECE();
+                FF_MM(0, 1, 0, fa[cur][1], fb0[cur][0]); FF_OP(t[3] = ff_bytemask(t[3])); FF_OP(t[4] = ff_bytemask(t[4])); FF_OP(t[5] = ff_bytemask(t[5])); FF_OP(t[6] = ff_bytemask(t[6])); FF_OP(t[7] = ff_bytemask(t[7])); FF_END_PIECE();
+                FF_MM(1, 1, 0, fa[cur][1], fb1[cur][0]); FF_OP(fb0[nxt][0][0] = (int)((uint32_t)dg0[nxt][0] & t[0])); FF_OP(fb1[nxt][0][0] = (int)((uint32_t)dg1[nxt][0] & t[0])); FF_OP(fb0[nxt][0][1] = (int)((uint32_t)dg0[nxt][1] & t[1])); FF_OP(fb1[nxt][0][1] = (int)((uint32_t)dg1[nxt][1] & t[1])); FF_END_PIECE();
+                FF_MM(0, 1, 1, fa[cur][1], fb0[cur][1]); FF_OP(fb0[nxt][0][2] = (int)((uint32_t)dg0[nxt][2] & t[2])); FF_OP(fb1[nxt][0][2] = (int)((uint32_t)dg1[nxt][2] & t[2])); FF_OP(fb0[nxt][0][3] = (int)((uint32_t)dg0[nxt][3] & t[3])); FF_OP(fb1[nxt][0][3] = (int)((uint32_t)dg1[nxt][3] & t[3])); FF_OP(fb0[nxt][1][0] = (int)((uint32_t)dg0[nxt][0] & t[4])); FF_END_PIECE();
+                FF_MM(1, 1, 1, fa[cur][1], fb1[cur][1]); FF_OP(fb1[nxt][1][0] = (int)((uint32_t)dg1[nxt][0] & t[4])); FF_OP(fb0[nxt][1][1] = (int)((uint32_t)dg0[nxt][1] & t[5])); FF_OP(fb1[nxt][1][1] = (int)((uint32_t)dg1[nxt][1] & t[5])); FF_OP(fb0[nxt][1][2] = (int)((uint32_t)dg0[nxt][2] & t[6])); FF_OP(fb1[nxt][1][2] = (int)((uint32_t)dg1[nxt][2] & t[6])); FF_END_PIECE();
+                FF_MM(0, 2, 0, fa[cur][2], fb0[cur][0]); FF_OP(fb0[nxt][1][3] = (int)((uint32_t)dg0[nxt][3] & t[7])); FF_OP(fb1[nxt][1][3] = (int)((uint32_t)dg1[nxt][3] & t[7])); FF_OP(fa[nxt][0][0] = (int)(swx[0] >> shk[0])); FF_OP(fa[nxt][0][1] = (int)(swx[0] >> shk[1])); FF_OP(fa[nxt][0][2] = (int)(swx[0] >> shk[2])); FF_END_PIECE();
+                FF_MM(1, 2, 0, fa[cur][2], fb1[cur][0]); FF_OP(fa[nxt][0][3] = (int)(swx[0] >> shk[3])); FF_OP(fa[nxt][1][0] = (int)(swx[1] >> shk[0])); FF_OP(fa[nxt][1][1] = (int)(swx[1] >> shk[1])); FF_OP(fa[nxt][1][2] = (int)(swx[1] >> shk[2])); FF_OP(fa[nxt][1][3] = (int)(swx[1] >> shk[3])); FF_END_PIECE();
+                FF_MM(0, 2, 1, fa[cur][2], fb0[cur][1]); FF_OP(fa[nxt][2][0] = (int)(swx[2] >> shk[0])); FF_OP(fa[nxt][2][1] = (int)(swx[2] >> shk[1])); FF_OP(fa[nxt][2][2] = (int)(swx[2] >> shk[2])); FF_OP(fa[nxt][2][3] = (int)(swx[2] >> shk[3])); FF_END_PIECE();
+                FF_MM(1, 2, 1, fa[cur][2], fb1[cur][1]); FF_OP(fa[nxt][3][0] = (int)(swx[3] >> shk[0])); FF_OP(fa[nxt][3][1] = (int)(swx[3] >> shk[1])); FF_OP(fa[nxt][3][2] = (int)(swx[3] >> shk[2])); FF_OP(fa[nxt][3][3] = (int)(swx[3] >> shk[3])); FF_OP(fa[nxt][0][0] &= 0x01010101); FF_END_PIECE();
+                FF_MM(0, 3, 0, fa[cur][3], fb0[cur][0]); FF_OP(fa[nxt][0][1] &= 0x01010101); FF_OP(fa[nxt][0][2] &= 0x01010101); FF_OP(fa[nxt][0][3] &= 0x01010101); FF_OP(fa[nxt][1][0] &= 0x01010101); FF_OP(fa[nxt][1][1] &= 0x01010101); FF_END_PIECE();
+                FF_MM(1, 3, 0, fa[cur][3], fb1[cur][0]); FF_OP(fa[nxt][1][2] &= 0x01010101); FF_OP(fa[nxt][1][3] &= 0x01010101); FF_OP(fa[nxt][2][0] &= 0x01010101); FF_OP(fa[nxt][2][1] &= 0x01010101); FF_OP(fa[nxt][2][2] &= 0x01010101); FF_END_PIECE();
+                FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_OP(fa[nxt][2][3] &= 0x01010101); FF_OP(fa[nxt][3][0] &= 0x01010101); FF_OP(fa[nxt][3][1] &= 0x01010101); FF_OP(fa[nxt][3][2] &= 0x01010101); FF_OP(fa[nxt][3][3] &= 0x01010101); FF_END_PIECE();
+                FF_MM(1, 3, 1, fa[cur][3], fb1[cur][1]); take_words(bp2, bkt2); FF_END_PIECE();
+            };
+            // prologue: digits of k-steps 0 and 1, fragment set 0 for k-step 0, the words of k-step 1
+            read_digits(0, 0);
+            read_digits(1, 1);
+            take_words(0, 0);
+            if constexpr (!(DIAG & 4)) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const uint32_t mask = ff_bytemask((swy[n] >> shk[kk]) & 0x01010101u);
+                        fb0[0][n][kk] = (int)((uint32_t)dg0[0][kk] & mask);
+                        fb1[0][n][kk] = (int)((uint32_t)dg1[0][kk] & mask);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)((swx[m] >> shk[kk]) & 0x01010101u);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) { fb0[0][n][kk] = dg0[0][kk]; fb1[0][n][kk] = dg1[0][kk]; }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)swx[m];
+                }
+            }
+            take_words(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             int sl = 0;
             for (; sl + 1 < nseg; sl += 2) {
-                slab_step(ax, ay, sl);
-                if constexpr (!(DIAG & 2)) {
-                    ax = qa[0];
-                    ay = qb[0];
+                kstep(0, sl);
+                kstep(1, sl);
+                if constexpr (!(DIAG & 2)) {  // slab sl's words are used up: fetch slab sl + 2 (reads past the
+                    wa0[0] = qa[0];           // item's end hit the arrays' padding and are never multiplied)
+                    wa1[0] = qa[64];
+                    wb[0] = qb[0];
                 }
-                slab_step(bx, by, sl + 1);
+                kstep(2, sl);
+                kstep(3, sl);
                 if constexpr (!(DIAG & 2)) {
-                    bx = qa[n8];
-                    by = qb[n8];
+                    wa0[1] = qa[n8];
+                    wa1[1] = qa[n8 + 64];
+                    wb[1] = qb[n8];
                 }
                 qa += 2 * n8;
                 qb += 2 * n8;
             }
-            if (sl < nseg) slab_step(ax, ay, sl);
+            if (sl < nseg) {  // odd slab count: the last slab's two k-steps (what they build is never used)
+                kstep(0, sl);
+                kstep(1, sl);
+            }
+#undef FF_MM
+#undef FF_OP
+#undef FF_END_PIECE
         }
-        // D[row][col]: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31.
-        // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
-        //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel applies
-        //        the shard and diagonal masks);   < 0  plainly into num[] (the tile's only item);
-        //   = 0  into num[] by atomic add.
-        auto share = [&](int m, int n, int r, uint32_t wsum) {
-            uint32_t common = (uint32_t)acc[0][m][n][r] << (7 * item.d0);
-            if (nd > 1) common += (uint32_t)acc[1][m][n][r] << (7 * (item.d0 + 1));
-            return wsum - 2u * common;
-        };
-        const int lc0 = wj * 64 + (lane & 31);                 // + 32 n
-        const int lr0 = wi * 64 + 4 * half;                    // + 32 m + (r & 3) + 8 (r >> 2)
-        uint32_t wj_[2] = {0u, 0u};
-        if (item.first) {
-            wj_[0] = (uint32_t)W[item.j0 + lc0];
-            wj_[1] = (uint32_t)W[item.j0 + lc0 + 32];
+        // the last MFMAs (inline asm: the compiler inserts no wait) must have written the accumulators
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // Epilogue.  The 256 accumulator tiles of a lane sit in registers that only static code can name;
+        // written out element by element with the shard / diagonal tests around each store that was
+        // 9,000 instructions per item (instruction-cache misses made it cost more than the whole
+        // loop).  Instead: common = sum of the planes goes to LDS as a plain 256 x 128 tile (the digit
+        // table is dead by now), and a short rolled loop, one row per wave and trip, applies the
+        // tests and writes whole 512-byte rows.
+        // D[row][col] of an MFMA tile: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31.
+        __syncthreads();  // every wave is done with the digit table
+        {
+            uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
+            const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        uint32_t common = (uint32_t)acc[0][m][n][r] << s0;
+                        if (nd > 1) common += (uint32_t)acc[1][m][n][r] << s1;
+                        tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
+                    }
         }
-        if (ALL_PRIVATE || item.pad > 0) {
-            uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + lc0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = lr0 + m * 32 + (r & 3) + 8 * (r >> 2);
-                    const uint32_t wi_ = item.first ? (uint32_t)W[item.i0 + lr] : 0u;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) pt[lr * M_TILE_J + 32 * n] = share(m, n, r, wi_ + wj_[n]);
-                }
-        } else if constexpr (!ALL_PRIVATE) {
-            const bool plain = item.pad < 0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // four consecutive rows: slot base of row i + 1 = that of row i, plus i
-                    const int64_t i_first = item.i0 + lr0 + m * 32 + 8 * g;
-                    int64_t base = i_first * (i_first - 1) / 2 - slot_begin + item.j0 + lc0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const int64_t i = i_first + e;
-                        if (i >= row_begin && i < row_end) {
-                            const uint32_t wi_ = item.first ? (uint32_t)W[i] : 0u;
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) {
-                                if (item.j0 + lc0 + 32 * n >= i) continue;
-                                const uint32_t v = share(m, n, r, wi_ + wj_[n]);
-                                if (plain) num[base + 32 * n] = v;
-                                else if (v) atomicAdd(&num[base + 32 * n], v);
-                            }
-                        }
-                        base += i;
+        __syncthreads();
+        {
+            // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
+            //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
+            //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
+            //        item);   = 0  into num[] by atomic add.
+            const uint2 *tile = (const uint2 *)mfma_lds;  // a lane takes columns 2 * lane, 2 * lane + 1
+            const int64_t j = item.j0 + 2 * lane;
+            uint32_t wj0 = 0u, wj1 = 0u;
+            if (item.first) {
+                wj0 = (uint32_t)W[j];
+                wj1 = (uint32_t)W[j + 1];
+            }
+            const bool priv = ALL_PRIVATE || item.pad > 0;
+            uint32_t *pt = partial + (int64_t)(priv ? item.pad - 1 : 0) * (M_TILE_I * M_TILE_J) + 2 * lane;
+            // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
+            // no trip waits for a load of its own
+            constexpr int NW = M_THREADS / 64;
+            const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
+#pragma unroll 4
+            for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                const int row = wave + NW * trip;
+                const int64_t i = item.i0 + row;
+                const uint2 c = tile[row * (M_TILE_J / 2) + lane];
+                const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                const uint32_t v0 = wi_ + wj0 - 2u * c.x, v1 = wi_ + wj1 - 2u * c.y;
+                if (priv) {
+                    *(uint2 *)(pt + row * M_TILE_J) = uint2{v0, v1};
+                } else if constexpr (!ALL_PRIVATE) {
+                    if (i < row_begin || i >= row_end) continue;
+                    uint32_t *dst = num + (i * (i - 1) / 2 - slot_begin + j);
+                    if (item.pad < 0) {
+                        if (j + 1 < i) {
+                            // (a row's slots start at i (i - 1) / 2: 8-byte aligned only for some i)
+                            dst[0] = v0;
+                            dst[1] = v1;
+                        } else if (j < i) dst[0] = v0;
+                    } else {
+                        if (j < i && v0) atomicAdd(dst, v0);
+                        if (j + 1 < i && v1) atomicAdd(dst + 1, v1);
                     }
                 }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores and atomics of this item
     }

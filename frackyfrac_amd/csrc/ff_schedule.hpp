@@ -39,12 +39,13 @@ struct XTile {
 
 // ---- int8 MFMA kernel (pair_common_mfma_kernel) ----
 constexpr int M_TILE_I = 256;  // workgroup tile: 256 i-samples x 128 j-samples,
-constexpr int M_TILE_J = 128;  //   8 waves (4 x 2) of 64 x 64, i.e. 2 x 2 MFMA tiles per wave and digit plane
-constexpr int M_THREADS = 512; // two waves per SIMD
+constexpr int M_TILE_J = 128;  //   4 waves (2 x 2) of 128 x 64, i.e. 4 x 2 MFMA tiles per wave and digit plane
+constexpr int M_THREADS = 256; // one wave per SIMD (256 accumulator registers per lane)
 constexpr int M_WGS_PER_CU = 1;
 constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps) = bits of a presence word
 constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
-constexpr int M_LDS_BYTES = 512 * 2 * M_KSLAB;  // the digit table: 512 slabs x 2 planes x 64 digits (ff_kernels_mfma.hpp M_TABLE_SLABS)
+constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB, ff_kernels_mfma.hpp
+                                                      // M_TABLE_SLABS), then the epilogue's 256 x 128 tile of 32-bit sums
 
 // One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
 // d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]

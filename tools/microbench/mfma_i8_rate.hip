@@ -1,6 +1,7 @@
 // Raw v_mfma_i32_32x32x32_i8 rate: 8 accumulator tiles per wave (the product kernel's shape), one
-// or two waves per SIMD, operands in registers; optionally N plain VALU instructions per MFMA.
-// Prints cycles per MFMA per SIMD (from the in-kernel clock) and the clock held.
+// or two waves per SIMD, operands in registers; N plain 32-bit integer VALU instructions behind each
+// MFMA (inline asm, so that none is folded away).  Prints cycles per MFMA per SIMD and the clock held:
+// how much vector work a wave can carry per MFMA before the matrix pipe starts to wait.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -26,10 +27,11 @@ __global__ __launch_bounds__(WAVES * 64) void rate(int* out, int iters, int seed
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t & 1], b[t >> 1], acc[t], 0, 0, 0);
+            asm volatile("" : "+v"(acc[t]));  // pins the MFMA here
 #pragma unroll
-            for (int v = 0; v < NVALU; ++v) {
-                x = (x >> 3) & 0x01010101u;
-                y = (y + x) ^ 0x80808080u;
+            for (int v = 0; v < NVALU; ++v) {  // 2 * NVALU vector instructions the compiler cannot fold
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(x) : "v"(y));
+                asm volatile("v_and_b32 %0, 0x01010101, %1" : "=v"(y) : "v"(x));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -58,9 +60,9 @@ template <int WAVES, int NVALU> void run(int* d, unsigned long long* dc)
     unsigned long long hc[2];
     CK(hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost));
     const double mfma_per_simd = (double)iters * 8 * (WAVES / 4);
-    printf("%d waves/SIMD, %d VALU pairs per MFMA: %.3f ms, %.1f cycles per MFMA per SIMD, clock %.2f GHz, %.2f POP/s\n",
-           WAVES / 4, NVALU, ms, (double)hc[0] / mfma_per_simd, (double)hc[0] / hc[1] * 0.1,
-           mfma_per_simd * 1024 * 65536.0 / ms / 1e12);
+    const double ghz = (double)hc[0] / hc[1] * 0.1;
+    printf("%d waves/SIMD, %2d VALU per MFMA: %.3f ms, %.1f cycles per MFMA per SIMD (wall x clock), clock %.2f GHz, %.2f POP/s\n",
+           WAVES / 4, 2 * NVALU, ms, ms * 1e-3 * ghz * 1e9 / mfma_per_simd, ghz, mfma_per_simd * 1024 * 65536.0 / ms / 1e12);
 }
 
 int main()
@@ -68,7 +70,7 @@ int main()
     int* d; CK(hipMalloc(&d, 256 * 512 * 4));
     unsigned long long* dc; CK(hipMalloc(&dc, 16));
     run<4, 0>(d, dc); run<8, 0>(d, dc);
-    run<8, 1>(d, dc); run<8, 2>(d, dc); run<8, 3>(d, dc); run<8, 4>(d, dc); run<8, 6>(d, dc);
-    run<4, 2>(d, dc); run<4, 4>(d, dc);
+    run<8, 1>(d, dc); run<8, 2>(d, dc); run<8, 3>(d, dc); run<8, 4>(d, dc); run<8, 5>(d, dc); run<8, 6>(d, dc);
+    run<4, 1>(d, dc); run<4, 2>(d, dc); run<4, 3>(d, dc); run<4, 4>(d, dc); run<4, 6>(d, dc);
     return 0;
 }
