@@ -71,6 +71,7 @@ struct ff_plan {
     int64_t host_out_cap = 0;
     int n_workgroups = 0;
     int waves_per_wg = WAVES_PER_WG;
+    bool reg12 = false;          // 12 waves per workgroup: the register-buffered kernel with 2 x 4-row buffers (else the LDS-ring one)
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
     int sync_trips = 0;                      // workgroup barrier every this many loop trips (0 = never)
@@ -609,8 +610,19 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
     inf.n_tiles = (int64_t)tiles.size();
     // 8 waves per workgroup for the register-buffered and the sparse-aware kernel, 12 for the
-    // three-waves-per-SIMD variants
+    // three-waves-per-SIMD variants.  FF_WAVES_PER_WG / FF_REG12 force one; otherwise the 12-wave
+    // register variant (pair_sad_kernel12: a third wave per SIMD, paid for with half the vector
+    // prefetch) takes shards that fill its 12 x CUs wave slots for at least two whole rounds and whose
+    // matrix is small enough for four rows of prefetch -- measured: 16384 x 10k leaves (1.3 GB, 5.4
+    // rounds) 80.3 -> 77.3 ms; one round or less (4096 samples; an eighth of 16384) and the 3.3 GB
+    // matrix of 8192 x 50k leaves lose 1-2 % with it.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
+    pl->reg12 = env_int("FF_REG12", 0) != 0;
+    if (!pl->sparse && !getenv("FF_WAVES_PER_WG") &&
+        inf.n_tiles >= 2 * (int64_t)pl->n_workgroups * L_WAVES_PER_WG && inf.staged_bytes <= 2.0e9) {
+        pl->waves_per_wg = L_WAVES_PER_WG;
+        pl->reg12 = true;
+    }
     if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
     const int U = pl->n_workgroups * pl->waves_per_wg;
     inf.n_wave_slots = U;
@@ -1162,7 +1174,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
                 pl->zero_row, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end, inf.slot_begin);
         else if (inf.n_items > 0)
-            (pl->waves_per_wg == L_WAVES_PER_WG ? (env_int("FF_REG12", 0) ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
+            (pl->waves_per_wg == L_WAVES_PER_WG ? (pl->reg12 ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);

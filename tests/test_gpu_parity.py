@@ -577,6 +577,29 @@ def test_three_waves_per_simd_kernels_give_the_same_integers(monkeypatch, reg12)
         assert np.array_equal(parts, want, equal_nan=True)
 
 
+def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
+    """A shard with at least two rounds of 12 x CUs pair tiles (and a staged matrix under 2 GB) is
+    scheduled on the 12-wave register kernel without any switch being set; the choice is
+    bit-neutral: forcing the 8-wave kernel gives the same distances."""
+    nodes, ip, on, ft = synth_problem(10240, 150, 0.2, 78)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    cus = plan.info.n_compute_units
+    assert plan.info.n_tiles >= 24 * cus and plan.info.n_wave_slots == 12 * cus and plan.info.kernel == 0
+    got = plan.run_host()
+    plan.close()
+    monkeypatch.setenv("FF_WAVES_PER_WG", "8")
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.n_wave_slots == 8 * cus
+    want = plan.run_host()
+    plan.close()
+    assert np.array_equal(got, want)
+    # a sample of pairs against the oracle
+    rng = np.random.default_rng(3)
+    for slot in rng.integers(0, len(got), size=50):
+        o = O.unifrac_dists(ip, on, ft.dist, True, pair_begin=int(slot), pair_end=int(slot) + 1)[0]
+        assert abs(got[slot] - o) <= WEIGHTED_RTOL * o
+
+
 @pytest.mark.parametrize("weighted", [True, False])
 def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch, weighted):
     """A 20,000-leaf tree of which the samples touch 4 % of the leaves: only the branches
