@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FF_LIB_PATH: another build of the same library (tools/mfma_diag.py times ablated kernels from one)
 LIB_PATH = os.environ.get("FF_LIB_PATH") or os.path.join(_HERE, "lib", "libfrackyfrac_amd.so")
 FRCFRC_PATH = os.path.join(_HERE, "lib", "frcfrc")
+SPRSPR_PATH = os.path.join(_HERE, "lib", "sprspr")
 
 FF_OK = 0
 FF_ERR_ARG, FF_ERR_PARSE, FF_ERR_SPECIES, FF_ERR_DEVICE, FF_ERR_IO, FF_ERR_INTERNAL, FF_ERR_PRECISION = 1, 2, 3, 4, 5, 6, 7
@@ -67,6 +68,12 @@ SIGNATURES = {
     "ff_plan_timing_collect": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int32)]),
     "ff_plan_refined_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "ff_plan_audit": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),
+    "ff_device_alloc": (c_int, [c_int32, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_device_free": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "ff_ipc_export": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
+    "ff_ipc_open": (c_int, [c_void_p, c_int32, POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_ipc_close": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "ff_device_copy_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_char_p, c_size_t]),
     "ff_plan_set_shard": (c_int, [c_void_p, c_int32, c_int32, c_char_p, c_size_t]),
     "ff_plan_run_host": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_tree_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
@@ -86,6 +93,8 @@ SIGNATURES = {
     "ff_table_num_samples": (c_int64, [c_void_p]),
     "ff_table_sample_size": (c_int64, [c_void_p, c_int64]),
     "ff_table_sample_entry": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_char_p), POINTER(c_double)]),
+    "ff_table_write_sparse": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t]),
+    "ff_sprspr_main": (c_int, [c_int, POINTER(c_char_p)]),
     "ff_validate_species": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_flatten": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_flatten_leaf_csr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,

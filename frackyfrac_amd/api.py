@@ -376,6 +376,61 @@ class Plan:
                           "stage this problem with precision='exact64'" % (bad, n, worst))
 
 
+class DeviceBuffer:
+    """`n` float64 of device memory owned through the C ABI (ff_device_alloc): exportable to the
+    other processes of the node (ff_ipc_export) and viewable as a torch tensor without a copy
+    (__cuda_array_interface__)."""
+
+    def __init__(self, n: int, device: int):
+        self.n, self.device = int(n), int(device)
+        p, err = ctypes.c_void_p(), L.errbuf()
+        L.check(L.lib().ff_device_alloc(self.device, 8 * max(self.n, 1), ctypes.byref(p), err, L.ERRLEN), err)
+        self.ptr = int(p.value)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.n,), "typestr": "<f8", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self):
+        import torch
+
+        return torch.as_tensor(self, device=torch.device("cuda", self.device))
+
+    def export(self) -> bytes:
+        h, err = (ctypes.c_ubyte * 64)(), L.errbuf()
+        L.check(L.lib().ff_ipc_export(ctypes.c_void_p(self.ptr), h, err, L.ERRLEN), err)
+        return bytes(h)
+
+    def free(self) -> None:
+        if getattr(self, "ptr", 0):
+            err = L.errbuf()
+            ptr, self.ptr = self.ptr, 0
+            L.check(L.lib().ff_device_free(ctypes.c_void_p(ptr), err, L.ERRLEN), err)
+
+
+class MappedBuffer:
+    """Another process's DeviceBuffer mapped into this one (ff_ipc_open)."""
+
+    def __init__(self, handle: bytes, device: int):
+        h = (ctypes.c_ubyte * 64).from_buffer_copy(handle)
+        p, err = ctypes.c_void_p(), L.errbuf()
+        L.check(L.lib().ff_ipc_open(h, int(device), ctypes.byref(p), err, L.ERRLEN), err)
+        self.ptr = int(p.value)
+
+    def close(self) -> None:
+        if getattr(self, "ptr", 0):
+            err = L.errbuf()
+            ptr, self.ptr = self.ptr, 0
+            L.check(L.lib().ff_ipc_close(ctypes.c_void_p(ptr), err, L.ERRLEN), err)
+
+
+def device_copy_async(dst_ptr: int, src_ptr: int, nbytes: int, stream: int = 0) -> None:
+    """ff_device_copy_async: device-to-device, local or into a mapped peer buffer, on `stream`."""
+    err = L.errbuf()
+    L.check(L.lib().ff_device_copy_async(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), int(nbytes),
+                                         ctypes.c_void_p(stream), err, L.ERRLEN), err)
+
+
 def format_float(f: float) -> str:
     """fmt.Fprintln's rendering of a float64, without the newline."""
     buf = ctypes.create_string_buffer(40)

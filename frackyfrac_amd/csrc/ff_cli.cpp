@@ -357,13 +357,21 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     phase[4] = t_dist;
     phase[5] = t_write;
     last = std::chrono::steady_clock::now();
+    // Unweighted in fixed point is the reference bit for bit only when every branch length is a
+    // multiple of 2^-scale; say so when it was not (the values are then within 1e-6, like weighted)
+    if (!f.weighted && info.precision == FF_PRECISION_FIXED32 && !info.lengths_exact)
+        fputs("Note: branch lengths are not multiples of a power of two that fits 31 bits: unweighted distances are "
+              "within 1e-6 (relative) of the reference's, not bit-identical; -precision exact64 gives the reference's bits\n",
+              stderr);
     if (f.stats)
         fprintf(stderr,
-                "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"tiles\": %lld, "
+                "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"bit_exact\": %s, \"tiles\": %lld, "
                 "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"seconds\": {\"tree\": %.3f, "
                 "\"load\": %.3f, \"validate\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f}}\n",
                 info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
-                info.lengths_exact, (long long)info.n_tiles, (long long)info.n_items,
+                info.lengths_exact,
+                info.precision == FF_PRECISION_EXACT64 || (!f.weighted && info.lengths_exact) ? "true" : "false",
+                (long long)info.n_tiles, (long long)info.n_items,
                 (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, phase[0], phase[1], phase[2], phase[3], phase[4],
                 phase[5]);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -371,3 +379,58 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     fputs("Done\n", stderr);
     return 0;
 }
+
+// ---- sprspr: dense table -> sparse table (sprspr/sprspr.go:19-44) ---------------------------
+
+namespace {
+const char *SPRSPR_USAGE =
+    "SparseySparse converts dense format abundance tables to sparse format.\n"
+    "\n"
+    "Usage:\n"
+    "sprspr < INPUT_FILE > OUTPUT_FILE\n"
+    "\n"
+    "Reading standard input...\n";
+}
+
+// One line per sample: its non-zero entries as name:value, tab-separated, the value as Go's %g
+// prints a float64 (= %v: shortest digits that round-trip).  The reference walks a Go map, so the
+// order of the entries within a line is random there; here it is the order of the table's header.
+extern "C" int ff_table_write_sparse(const ff_table *table, const char *path, char *err, size_t errlen)
+{
+    if (!table) return ff::fail(FF_ERR_ARG, err, errlen, "null table");
+    std::string out;
+    char buf[40];
+    const int64_t n = ff_table_num_samples(table);
+    for (int64_t s = 0; s < n; ++s) {
+        for (int64_t k = table->ptr[(size_t)s]; k < table->ptr[(size_t)s + 1]; ++k) {
+            if (k > table->ptr[(size_t)s]) out += '\t';
+            out += table->species[(size_t)table->key[(size_t)k]];
+            out += ':';
+            out.append(buf, (size_t)ff_format_float(table->val[(size_t)k], buf));
+        }
+        out += '\n';
+    }
+    FILE *fp = path ? fopen(path, "wb") : stdout;
+    if (!fp) return ff::fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+    const bool ok = fwrite(out.data(), 1, out.size(), fp) == out.size() && fflush(fp) == 0;
+    if (path) fclose(fp);
+    return ok ? FF_OK : ff::fail(FF_ERR_IO, err, errlen, "write %s: %s", path ? path : "stdout", strerror(errno));
+}
+
+// The whole `sprspr` command (sprspr/sprspr.go:14-17): usage to stderr, stdin -> stdout.
+extern "C" int ff_sprspr_main(int argc, char **argv)
+{
+    (void)argc;
+    (void)argv;
+    fputs(SPRSPR_USAGE, stderr);  // fmt.Fprintln(os.Stderr, usageMessage)
+    char err[1024];
+    ff_table *table = nullptr;
+    int rc = ff_table_read_file_mt(nullptr, 0, 2, &table, err, sizeof err);  // parser.ParseAbundance(r, 2, ...)
+    if (rc == FF_OK) rc = ff_table_write_sparse(table, nullptr, err, sizeof err);
+    const int64_t n = table ? ff_table_num_samples(table) : 0;
+    ff_table_free(table);
+    if (rc) return die(err);
+    fprintf(stderr, "%lld samples\n", (long long)n);  // (ptimer's closing line; its wording is unpinned)
+    return 0;
+}
+

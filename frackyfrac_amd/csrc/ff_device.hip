@@ -1362,6 +1362,81 @@ int ff_plan_audit(ff_plan *pl, int64_t *checked, int64_t *failed, double *max_re
     return FF_OK;
 }
 
+// ---- device buffers shared between processes (include/frackyfrac_amd.h, "Device buffers ...") ----
+
+static_assert(sizeof(hipIpcMemHandle_t) == sizeof(ff_ipc_handle), "ff_ipc_handle must hold a hipIpcMemHandle_t");
+
+int ff_device_alloc(int32_t device, size_t bytes, void **dptr, char *err, size_t errlen)
+{
+    if (!dptr) return ff::fail(FF_ERR_ARG, err, errlen, "null pointer argument");
+    *dptr = nullptr;
+    int cur = -1;
+    FF_HIP(hipGetDevice(&cur));
+    if (device >= 0 && device != cur) FF_HIP(hipSetDevice(device));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 1));
+    if (e == hipSuccess) e = hipMemset(p, 0, std::max<size_t>(bytes, 1));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (device >= 0 && device != cur) (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot allocate %.2f GB of device memory: %s", (double)bytes / 1e9,
+                        hipGetErrorString(e));
+    }
+    *dptr = p;
+    return FF_OK;
+}
+
+int ff_device_free(void *dptr, char *err, size_t errlen)
+{
+    if (dptr) FF_HIP(hipFree(dptr));
+    return FF_OK;
+}
+
+int ff_ipc_export(void *dptr, ff_ipc_handle *handle, char *err, size_t errlen)
+{
+    if (!dptr || !handle) return ff::fail(FF_ERR_ARG, err, errlen, "null pointer argument");
+    hipIpcMemHandle_t h;
+    FF_HIP(hipIpcGetMemHandle(&h, dptr));
+    memcpy(handle->bytes, &h, sizeof h);
+    return FF_OK;
+}
+
+int ff_ipc_open(const ff_ipc_handle *handle, int32_t device, void **dptr, char *err, size_t errlen)
+{
+    if (!dptr || !handle) return ff::fail(FF_ERR_ARG, err, errlen, "null pointer argument");
+    *dptr = nullptr;
+    int cur = -1;
+    FF_HIP(hipGetDevice(&cur));
+    if (device >= 0 && device != cur) FF_HIP(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle->bytes, sizeof h);
+    void *p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (device >= 0 && device != cur) (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    }
+    *dptr = p;
+    return FF_OK;
+}
+
+int ff_ipc_close(void *dptr, char *err, size_t errlen)
+{
+    if (dptr) FF_HIP(hipIpcCloseMemHandle(dptr));
+    return FF_OK;
+}
+
+int ff_device_copy_async(void *dst, const void *src, size_t bytes, void *stream, char *err, size_t errlen)
+{
+    if (bytes == 0) return FF_OK;
+    if (!dst || !src) return ff::fail(FF_ERR_ARG, err, errlen, "null pointer argument");
+    FF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FF_OK;
+}
+
 // Diagnostics, not part of the public header: copies the per-wave start/end stamps
 // of the last pair_sad_kernel launch (FF_STAMPS=1) into out[2 * n_wave_slots].
 int ff_debug_read_stamps(ff_plan *pl, unsigned long long *out)

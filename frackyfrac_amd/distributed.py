@@ -7,8 +7,9 @@ place.  There is no other collective on the data path: pairs are independent
 (frcfrc/unifrac.go:209-228 maps over pairs with no reduction across them).
 
 Two transports for that exchange (ShardedRun, FF_GATHER=auto|ipc|nccl):
-  * "ipc": the root's result array is mapped into every rank (HIP IPC memory handle,
-    exchanged once) and each rank copies its finished slice straight into it over its
+  * "ipc": the root's result array is mapped into every rank (HIP IPC memory handle through
+    the C ABI: ff_device_alloc / ff_ipc_export / ff_ipc_open, so a C or Go host has the same
+    transport; exchanged once) and each rank copies its finished slice straight into it over its
     xGMI link with a device-to-device hipMemcpyAsync on a side stream -- the copy
     engines move the slice while the rank's CUs already reduce the next batch (two
     local result buffers).  No RCCL kernel competes with the persistent pair kernel
@@ -59,6 +60,48 @@ def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, f
     return None
 
 
+def gather_slices_chunked(produce: Callable, n_samples: int, rank: int, world: int, chunks: int, root: int = 0,
+                          full=None, group=None, copy_root: Optional[Callable] = None):
+    """The gather with every rank's shard cut into `chunks` equal-pair sub-shards (sub-shard c of
+    rank r is shard r * chunks + c of world * chunks: still contiguous in IterPairs order) that are
+    produced back to back: `produce(c)` returns this rank's finished sub-shard c (a tensor, the work
+    enqueued on the current stream) and its transfer to the root is issued at once, so that only
+    the last sub-shard's transfer is exposed.  The root posts every receive up front, per peer
+    in chunk order.  Returns `full` on the root (allocated if not given), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    C, W = chunks, world
+    reqs = []
+    if rank == root:
+        ops = []
+        for c in range(C):
+            for r in range(W):
+                if r == root:
+                    continue
+                a, b = api.shard_slots(n_samples, r * C + c, W * C)
+                if b > a:
+                    if full is None:
+                        raise ValueError("the root needs its result array before the first receive is posted")
+                    ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
+        reqs += dist.batch_isend_irecv(ops) if ops else []
+    for c in range(C):
+        part = produce(c)
+        if rank == root:
+            a, b = api.shard_slots(n_samples, rank * C + c, W * C)
+            if copy_root is not None:
+                copy_root(full[a:b], part)
+            else:
+                full[a:b].copy_(part, non_blocking=True)
+        elif part.numel() > 0:
+            # enqueued behind sub-shard c's kernels on the communication stream; sub-shard c + 1 is
+            # launched right after and overlaps with the transfer
+            reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, part, root, group)])
+    for q in reqs:
+        q.wait()
+    return full if rank == root else None
+
+
 class ShardedRun:
     """One rank's share of the hot path: staged plan(s) for its row shard plus the output
     buffers, reusable across steps (bench.py) or used once.
@@ -92,12 +135,26 @@ class ShardedRun:
         self.plan = self.plans[0]
         self.locals = [torch.empty(p.n_slots, dtype=torch.float64, device=self.device) for p in self.plans]
         self.local = self.locals[0]
-        self.full = (torch.empty(api.num_pairs(self.n_samples), dtype=torch.float64, device=self.device)
-                     if (rank == root and world > 1) else None)
         if transport is None:
             transport = os.environ.get("FF_GATHER", "auto")
         if transport not in ("auto", "ipc", "nccl"):
             raise ValueError("transport must be auto, ipc or nccl")
+        # The root's result array.  For the "ipc" transport it is an allocation of the C ABI's own
+        # (ff_device_alloc: the start of a HIP allocation, which is what can be exported), viewed by
+        # torch without a copy; otherwise a plain torch tensor.
+        self.full, self._full_buf, self._full_note = None, None, ""
+        if rank == root and world > 1:
+            if self.chunks == 1 and transport in ("auto", "ipc"):
+                try:
+                    self._full_buf = api.DeviceBuffer(api.num_pairs(self.n_samples), device)
+                    self.full = self._full_buf.tensor()
+                except Exception as e:  # noqa: BLE001 -- the joint verdict of _setup_ipc turns this into "nccl"
+                    self._full_note = "alloc: %r" % (e,)
+                    if self._full_buf is not None:
+                        self._full_buf.free()
+                    self._full_buf = None
+            if self.full is None:
+                self.full = torch.empty(api.num_pairs(self.n_samples), dtype=torch.float64, device=self.device)
         self.transport = "none" if world == 1 else "nccl"
         self.transport_note = ""
         self.ipc_gbps = None
@@ -126,16 +183,17 @@ class ShardedRun:
         import os
 
         import torch.distributed as dist
-        from torch.multiprocessing.reductions import reduce_tensor
 
         torch = self.torch
         ok, note = True, ""
         box = [None]
         if self.rank == self.root:
             try:
+                if self._full_buf is None:
+                    raise RuntimeError(self._full_note or "no exportable buffer")
                 self.full.fill_(float("nan"))
                 torch.cuda.synchronize(self.device)
-                box[0] = reduce_tensor(self.full)[1]
+                box[0] = self._full_buf.export()  # 64 bytes: hipIpcGetMemHandle through the C ABI
             except Exception as e:  # noqa: BLE001 -- any failure means "use the other transport"
                 ok, note = False, "export: %r" % (e,)
         dist.broadcast_object_list(box, src=self.root, group=self.group)
@@ -147,12 +205,13 @@ class ShardedRun:
                     raise RuntimeError("root could not export its buffer")
                 if os.environ.get("FF_GATHER_FAULT") == str(self.rank):  # fault injection for the tests
                     raise RuntimeError("injected fault")
-                from torch.multiprocessing.reductions import rebuild_cuda_tensor
-                self.remote = rebuild_cuda_tensor(*box[0])
+                self.remote = api.MappedBuffer(box[0], self.device.index)  # ff_ipc_open
                 if b > a:
-                    mark = torch.full((min(16, b - a),), float(self.rank + 1), dtype=torch.float64, device=self.device)
-                    self.remote[a:a + mark.numel()].copy_(mark)
-                    self.remote[b - mark.numel():b].copy_(mark)
+                    k = min(16, b - a)
+                    mark = torch.full((k,), float(self.rank + 1), dtype=torch.float64, device=self.device)
+                    st = torch.cuda.current_stream(self.device).cuda_stream
+                    api.device_copy_async(self.remote.ptr + 8 * a, mark.data_ptr(), 8 * k, st)
+                    api.device_copy_async(self.remote.ptr + 8 * (b - k), mark.data_ptr(), 8 * k, st)
                 torch.cuda.synchronize(self.device)
             except Exception as e:  # noqa: BLE001
                 ok, note = False, "open/write: %r" % (e,)
@@ -171,21 +230,22 @@ class ShardedRun:
                         ok, note = False, "pattern of rank %d did not arrive" % r
         all_ok = self._flag_all(ok)
         if not all_ok:
-            self.remote = None
+            self._drop_mapping()
             self.transport_note = note or "another rank failed"
             return False
         # bandwidth probe: all peers copy their whole slice at once, as in a step.  A mapping
         # that works but crawls (staged through the host, say) must not beat RCCL to the job.
         gbps = float("inf")
         try:
+            st = torch.cuda.current_stream(self.device).cuda_stream
             if self.rank != self.root and b > a:
-                self.remote[a:b].copy_(self.local)           # first touch
+                api.device_copy_async(self.remote.ptr + 8 * a, self.local.data_ptr(), 8 * (b - a), st)  # first touch
                 torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
             if self.rank != self.root and b > a:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                self.remote[a:b].copy_(self.local, non_blocking=True)
+                api.device_copy_async(self.remote.ptr + 8 * a, self.local.data_ptr(), 8 * (b - a), st)
                 e1.record()
                 torch.cuda.synchronize(self.device)
                 gbps = 8.0 * (b - a) / (e0.elapsed_time(e1) * 1e-3) / 1e9
@@ -195,7 +255,7 @@ class ShardedRun:
         min_gbps = float(os.environ.get("FF_GATHER_MIN_GBPS", "15"))
         fast = gbps >= min_gbps or (b - a) * 8 < (4 << 20)    # (tiny slices only measure latency)
         if not self._flag_all(fast):
-            self.remote = None
+            self._drop_mapping()
             self.transport_note = note or ("ipc copies too slow (%.1f GB/s on this rank; FF_GATHER_MIN_GBPS=%g)"
                                            % (gbps, min_gbps))
             return False
@@ -221,11 +281,10 @@ class ShardedRun:
         self.plan.run(self.locals[q].data_ptr(), main.cuda_stream, timed=timed)
         ready = torch.cuda.Event()
         ready.record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            self.remote[a:b].copy_(self.locals[q], non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(self.side)
+        self.side.wait_event(ready)
+        api.device_copy_async(self.remote.ptr + 8 * a, self.locals[q].data_ptr(), 8 * (b - a), self.side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.side)
         self.copy_done[q] = done
         return None
 
@@ -277,32 +336,12 @@ class ShardedRun:
         if self.chunks == 1:
             self.plan.run(self.local.data_ptr(), stream.cuda_stream, timed=timed)
             return gather_slices(self.local, self.n_samples, self.rank, self.world, self.root, self.full, self.group)
-        import torch.distributed as dist
-
-        C, W = self.chunks, self.world
-        reqs = []
-        if self.rank == self.root:  # post every receive up front, per peer in chunk order
-            ops = []
-            for c in range(C):
-                for r in range(W):
-                    if r == self.root:
-                        continue
-                    a, b = api.shard_slots(self.n_samples, r * C + c, W * C)
-                    if b > a:
-                        ops.append(dist.P2POp(dist.irecv, self.full[a:b], r, self.group))
-            reqs += dist.batch_isend_irecv(ops) if ops else []
-        for c in range(C):
+        def produce(c):
             self.plans[c].run(self.locals[c].data_ptr(), stream.cuda_stream, timed=timed)
-            if self.rank == self.root:
-                a, b = api.shard_slots(self.n_samples, self.rank * C + c, W * C)
-                self.full[a:b].copy_(self.locals[c], non_blocking=True)
-            elif self.locals[c].numel() > 0:
-                # enqueued behind chunk c's kernels on the communication stream; chunk c+1
-                # is launched right after and overlaps with the transfer
-                reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, self.locals[c], self.root, self.group)])
-        for q in reqs:
-            q.wait()
-        return self.full if self.rank == self.root else None
+            return self.locals[c]
+
+        return gather_slices_chunked(produce, self.n_samples, self.rank, self.world, self.chunks, self.root, self.full,
+                                     self.group)
 
     def timing_collect(self):
         ms = n = 0
@@ -312,12 +351,30 @@ class ShardedRun:
             n += b
         return ms, n // max(1, len(self.plans))
 
-    def close(self):
+    def _drop_mapping(self):
         if getattr(self, "remote", None) is not None:
             self.torch.cuda.synchronize(self.device)
-            self.remote = None
+            self.remote.close()  # ff_ipc_close
+        self.remote = None
+
+    def close(self):
+        """Collective when the "ipc" transport is in use: every peer unmaps the root's array before
+        the root frees it."""
+        if getattr(self, "plans", None) is None:
+            return
+        if self.transport == "ipc":
+            import torch.distributed as dist
+
+            self._drop_mapping()
+            dist.barrier(group=self.group)
+        if self._full_buf is not None:
+            self.torch.cuda.synchronize(self.device)
+            self.full = None
+            self._full_buf.free()
+            self._full_buf = None
         for p in self.plans:
             p.close()
+        self.plans = None
 
 
 def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto", root: int = 0,

@@ -213,6 +213,34 @@ int ff_plan_refined_pairs(ff_plan *plan, int64_t *queued, int64_t *capacity);
  */
 int ff_plan_audit(ff_plan *plan, int64_t *checked, int64_t *failed, double *max_rel_err);
 
+/* -- Device buffers shared between the processes of one node (the multi-GPU gather) --
+ *
+ * With one process per GPU, every rank's distances end in ONE array on the root's device: the
+ * root allocates it (ff_device_alloc), exports it (ff_ipc_export), every other rank maps it
+ * (ff_ipc_open) and copies its finished slice of the IterPairs-ordered output straight into it
+ * over its own xGMI link (ff_device_copy_async on a side stream, i.e. by the copy engines, while
+ * its compute units already reduce the next batch).  Plain HIP IPC underneath
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle); the 64 handle bytes travel by whatever channel
+ * the host has (a Go host: a pipe or a socket; frackyfrac_amd/distributed.py: the process
+ * group's object broadcast).  A mapping stays valid until ff_ipc_close; the owner must outlive
+ * every mapping.  This pool's driver only supports dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0
+ * must be set in the environment of every process before its first HIP call. */
+typedef struct ff_ipc_handle {
+    unsigned char bytes[64];
+} ff_ipc_handle;
+/* `bytes` of device memory on HIP device `device` (-1: the current one), zero-filled. */
+int ff_device_alloc(int32_t device, size_t bytes, void **dptr, char *err, size_t errlen);
+int ff_device_free(void *dptr, char *err, size_t errlen);
+/* dptr must be the start of an allocation made by ff_device_alloc in THIS process. */
+int ff_ipc_export(void *dptr, ff_ipc_handle *handle, char *err, size_t errlen);
+/* Maps another process's allocation into this process; the pointer is usable on `device`
+ * (-1: the current one) -- peer access to the owner's device is enabled on first use. */
+int ff_ipc_open(const ff_ipc_handle *handle, int32_t device, void **dptr, char *err, size_t errlen);
+int ff_ipc_close(void *dptr, char *err, size_t errlen);
+/* Device-to-device copy (local or into a mapped peer buffer) on `stream` (hipStream_t; NULL =
+ * the null stream); returns without synchronising. */
+int ff_device_copy_async(void *dst, const void *src, size_t bytes, void *stream, char *err, size_t errlen);
+
 /* ------------------------------------------------------------------------- *
  * 2. Host surface either side of the hot path
  * ------------------------------------------------------------------------- */
@@ -256,6 +284,14 @@ int64_t ff_table_sample_size(const ff_table *table, int64_t sample);
  * position and its last value, as a Go map assignment would). */
 int ff_table_sample_entry(const ff_table *table, int64_t sample, int64_t k,
                           const char **name, double *value);
+
+/* The table in the reference's sparse format: one line per sample, its non-zero entries as
+ * name:value (Go's %g), tab-separated -- what the `sprspr` tool writes (sprspr/sprspr.go:19-44;
+ * entries in the order of the table's header: the reference's order is a Go map's, i.e. random).
+ * path NULL = stdout. */
+int ff_table_write_sparse(const ff_table *table, const char *path, char *err, size_t errlen);
+/* Whole `sprspr` command (sprspr/sprspr.go:14-17): dense table on stdin -> sparse table on stdout. */
+int ff_sprspr_main(int argc, char **argv);
 
 /* Replaces validateSpecies (frcfrc/unifrac.go:80-93). */
 int ff_validate_species(const ff_table *table, const ff_tree *tree, char *err, size_t errlen);

@@ -118,6 +118,15 @@ def parse_abundance(text: str) -> List[Dict[str, float]]:
     return out
 
 
+def to_sparse(text: str) -> str:
+    """sprspr/sprspr.go:19-37 toSparse: every sample of a dense table as name:%g tokens joined by
+    tabs, one line per sample.  (The reference ranges over a Go map, so the order of the tokens of a
+    line is random there; here it is the header's order -- compare lines as sets, as
+    sprspr_test.go:27-33 does.)"""
+    return "".join("\t".join("%s:%s" % (k, format_go_float(v)) for k, v in m.items()) + "\n"
+                   for m in parse_abundance(text))
+
+
 def split_sparse(s: str) -> Tuple[str, str]:
     """parser/parser.go:129-140 splitSparse: split at the LAST colon."""
     last = s.rfind(":")

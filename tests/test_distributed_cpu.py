@@ -68,3 +68,59 @@ def test_two_rank_gather_gloo(n_samples):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_chunked(rank, world, port, n_samples, chunks, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import frackyfrac_amd as ff
+    from frackyfrac_amd import synth
+    from frackyfrac_amd.distributed import gather_slices_chunked
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tree, ptr, idx, val = synth.make(n_samples, 60, 0.2, 99)
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    onodes = np.zeros(len(nodes.branch_id), dtype=O.FLATNODE)
+    onodes["id"], onodes["abnd"] = nodes.branch_id, nodes.abnd
+    produced = []
+
+    def produce(c):  # sub-shard c of this rank = shard rank * chunks + c of world * chunks
+        a, b = ff.shard_slots(n_samples, rank * chunks + c, world * chunks)
+        produced.append((a, b))
+        return torch.from_numpy(O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, True, 1, a, b).copy())
+
+    full = torch.full((ff.num_pairs(n_samples),), float("nan"), dtype=torch.float64) if rank == 0 else None
+    res = gather_slices_chunked(produce, n_samples, rank, world, chunks, 0, full)
+    # a rank's sub-shards tile its shard, in order
+    a0, b0 = ff.shard_slots(n_samples, rank, world)
+    assert produced[0][0] == a0 and produced[-1][1] == b0 and all(x[1] == y[0] for x, y in zip(produced, produced[1:]))
+    if rank == 0:
+        want = O.unifrac_dists(nodes.indptr, onodes, nodes.branch_len, True)
+        q.put(bool(np.array_equal(res.numpy(), want)))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_samples,chunks", [(2, 130, 3), (3, 70, 2), (2, 9, 4)])
+def test_chunked_gather_gloo(world, n_samples, chunks):
+    """FF_GATHER=nccl with FF_GATHER_CHUNKS > 1: the receives are posted up front, each rank's
+    sub-shards go out as they are produced; the root's array must be the single-process result."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunked, args=(r, world, port, n_samples, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

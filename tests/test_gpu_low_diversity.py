@@ -154,3 +154,22 @@ def test_identical_samples_are_at_distance_exactly_zero():
     got = ff.unifrac_dists(nodes, True, precision="fixed32")
     assert want[0] == 0.0 and got[0] == 0.0
     assert rel_err(got[1:], want[1:]).max() <= WEIGHTED_RTOL
+
+
+def test_cli_says_when_unweighted_is_tolerance_grade(tmp_path):
+    """Unweighted through the command in fixed point with lengths off the binary grid: a line on
+    stderr (and "bit_exact": false under -stats) tells the user the values are within 1e-6, not the
+    reference's bits; with dyadic lengths, or in exact64, nothing is said and bit_exact is true."""
+    tree, ptr, idx, val = synth.make(40, 300, 0.2, 7)
+    (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr, idx, val))
+    for lengths, precision, noted in ((0.1, "fixed32", True), (None, "fixed32", False), (0.1, "exact64", False)):
+        if lengths is not None:
+            tree.branch_len[:] = lengths
+            tree.branch_len[0] = 0.0
+        (tmp_path / "t.tree").write_text(tree.newick())
+        r = subprocess.run([L.FRCFRC_PATH, "-s", "-precision", precision, "-stats", "-i", str(tmp_path / "t.sparse"), "-t",
+                            str(tmp_path / "t.tree")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert ("Note: branch lengths are not multiples of a power of two" in r.stderr) == noted
+        assert ('"bit_exact": false' in r.stderr) == noted and ('"bit_exact": true' in r.stderr) == (not noted)
+        tree, _, _, _ = synth.make(40, 300, 0.2, 7)
