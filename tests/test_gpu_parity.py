@@ -333,6 +333,27 @@ def test_unweighted_mfma_five_digits_and_long_lengths():
     assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
 
 
+@pytest.mark.parametrize("ns,nl,dens", [(130, 20000, 0.02), (700, 17000, 0.01), (257, 33, 0.5), (1, 10, 0.5), (2, 40000, 0.001)])
+def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts(ns, nl, dens):
+    """The matrix-core kernel keeps 512 slabs of digits in LDS at a time (20000 leaves = 625 slabs:
+    two segments, the second of odd length), walks slabs in pairs with a tail, pads the sample
+    count to whole 256 x 128 tiles and cuts problems smaller than a round stream-K style: every
+    pair, bit-exact (dyadic lengths), against the oracle and against the vector-ALU kernel."""
+    nodes, ip, on, ft = synth_problem(ns, nl, dens, 4242 + ns)
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    if ns > 1:
+        assert plan.info.kernel == 2 and plan.info.lengths_exact == 1
+    got = plan.run_host() if ns > 1 else np.zeros(0)
+    plan.close()
+    assert np.array_equal(got, want, equal_nan=True)
+    for world in (3,):
+        parts = np.full_like(want, np.nan)
+        for r in range(world):
+            ff.unifrac_dists(nodes, False, precision="fixed32", rank=r, world=world, out=parts)
+        assert np.array_equal(parts, want, equal_nan=True)
+
+
 def test_cli_gpus_flag_matches_single_shard(tmp_path):
     tree, ptr, idx, val = synth.make(700, 3000, 0.1, 97)
     (tmp_path / "t.tree").write_text(tree.newick())
