@@ -44,6 +44,7 @@ using namespace ff::sched;
 // ----------------------------------------------------------------------------
 #include "ff_kernels_stage.hpp"
 #include "ff_kernels_pair_sad.hpp"
+#include "ff_kernels_finish_pair.hpp"
 #include "ff_kernels_mfma.hpp"
 #include "ff_kernels_stage_a.hpp"
 #include "ff_kernels_finish.hpp"
@@ -104,6 +105,7 @@ struct ff_plan {
     int32_t *d_ptiles = nullptr, *d_ptile_ptr = nullptr;
     int n_ptiles = 0;
     bool m_all_private = false;  // every item has a private partial tile
+    bool m_any_atomic = true;    // some item adds into num[] atomically: num[] has to be zero before a run
     int n_mitems = 0, n_mgroups = 0;
     // EXACT64
     double *d_DT = nullptr;
@@ -703,7 +705,11 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     FF_HIP(hipMemcpy(pl->d_mitem_ptr, mptr.data(), sizeof(int32_t) * mptr.size(), hipMemcpyHostToDevice));
     pl->lds_bytes = (size_t)M_LDS_BYTES;
     pl->m_all_private = !mi.empty();
-    for (const MItem &it : mi) pl->m_all_private = pl->m_all_private && it.pad > 0;
+    pl->m_any_atomic = false;
+    for (const MItem &it : mi) {
+        pl->m_all_private = pl->m_all_private && it.pad > 0;
+        pl->m_any_atomic = pl->m_any_atomic || it.pad == 0;
+    }
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<true>),
@@ -1141,34 +1147,53 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         ++pl->events_used;
     }
     if (inf.precision == FF_PRECISION_FIXED32) {
-        FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
+        FinishArgs fin;
+        fin.W = pl->d_W;
+        fin.wex = pl->d_wex;
+        fin.out = d_out;
+        fin.indptr = pl->refine ? pl->d_indptr : nullptr;
+        fin.refine_list = pl->d_refine_list;
+        fin.refine_count = pl->d_refine_count;
+        fin.refine_cap = pl->refine_cap;
+        fin.scale_log2 = inf.scale_log2;
+        fin.weighted = pl->weighted;
+        // The matrix-core path can finish in place when every slot has exactly one writer (its tile's
+        // only item, or reduce_partials_kernel): the integer sums then never go through num[], and
+        // there is neither a memset nor a finish launch.  Worth it where launches are what a step
+        // costs -- a problem smaller than one round, all of whose items are private partials (C2:
+        // 0.049 -> 0.038 ms per step); at C3 the divisions and 8-byte stores cost the persistent
+        // kernel's epilogue almost what the separate, chip-wide finish launch costs (0.290 -> 0.282 ms
+        // per step), so full rounds keep it.  FF_MFMA_FUSED_FINISH=1 / 0 forces either where possible.
+        const int fuse_env = env_int("FF_MFMA_FUSED_FINISH", -1);
+        const bool fused = pl->mfma && !pl->m_any_atomic && (fuse_env < 0 ? pl->m_all_private : fuse_env != 0);
+        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long) * 3, st));
+        if (!fused && (!pl->mfma || pl->m_any_atomic))
+            FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         if (pl->mfma) {
             auto kern = pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>;
 #ifdef FF_MFMA_DIAG  // ablations for timing only (wrong results): see the kernel's DIAG parameter
             switch (env_int("FF_MFMA_DIAG", 0)) {
-            case 1: kern = pair_common_mfma_kernel<false, 1>; break;
             case 2: kern = pair_common_mfma_kernel<false, 2>; break;
             case 4: kern = pair_common_mfma_kernel<false, 4>; break;
             case 8: kern = pair_common_mfma_kernel<false, 8>; break;
-            case 16: kern = pair_common_mfma_kernel<false, 16>; break;
             case 6: kern = pair_common_mfma_kernel<false, 6>; break;
             case 14: kern = pair_common_mfma_kernel<false, 14>; break;
-            case 15: kern = pair_common_mfma_kernel<false, 15>; break;
-            case 30: kern = pair_common_mfma_kernel<false, 30>; break;
-            case 31: kern = pair_common_mfma_kernel<false, 31>; break;
             default: break;
             }
             if (env_int("FF_MFMA_DIAG", 0))
                 FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
 #endif
+            FinishArgs none = fin;
+            none.out = nullptr;  // null: the kernels leave integer sums in num[]
             if (pl->n_mitems > 0)
                 kern<<<dim3((unsigned)pl->n_mgroups), dim3(M_THREADS), pl->lds_bytes, st>>>(
                     reinterpret_cast<const uint2 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
-                    pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin);
+                    pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, fused ? fin : none);
             if (pl->n_ptiles > 0)
                 reduce_partials_kernel<<<dim3(M_TILE_I * M_TILE_J / 256, (unsigned)pl->n_ptiles), dim3(256), 0, st>>>(
-                    pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin);
+                    pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin,
+                    fused ? fin : none);
         } else if (inf.n_items > 0 && pl->sparse)
             pair_sad_sparse_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
@@ -1179,11 +1204,10 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed) FF_HIP(hipEventRecord(ev1, st));
-        const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
-        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long) * 3, st));
-        finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(
-            pl->d_num, pl->n_planes, pl->plane_stride, pl->d_W, pl->d_wex, inf.scale_log2, pl->weighted, inf.slot_begin, n_slots, d_out,
-            pl->refine ? pl->d_indptr : nullptr, pl->d_refine_list, pl->d_refine_count, pl->refine_cap);
+        if (!fused) {
+            const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
+            finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->n_planes, pl->plane_stride, fin, inf.slot_begin, n_slots);
+        }
         if (pl->refine)
             refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * 8)), dim3(64), 0, st>>>(
                 pl->d_refine_list, pl->d_refine_count, pl->refine_cap, pl->d_indptr, pl->d_ids, pl->d_abnd,

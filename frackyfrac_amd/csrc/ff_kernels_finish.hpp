@@ -2,33 +2,10 @@
 // A fragment of ff_device.hip: included there, once, inside its anonymous namespace
 // (one translation unit, so the kernels stay internal and need no relocatable device code).
 
-// Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
-//
-// U(i,j) is a sum of k <= k_i + k_j terms (k_s = flat nodes of sample s), each an unbiased
-// estimate of l_b * |x_i(b) - x_j(b)| * 2^e with an error inside (-1, 1) that is independent
-// from branch to branch (the per-branch offset of the staging, ff_dither.hpp).  Hoeffding's
-// bound for such a sum: P(|error| >= t) <= 2 exp(-2 t^2 / k).  The denominator is binary64
-// (exact_weight_kernel), so the relative error of a distance is that of U alone.  A pair whose
-// U is so small that REFINE_C * sqrt(k) units could exceed 1e-6 of it -- nearly identical
-// samples -- is queued for refine_exact_kernel, which recomputes it with the reference's own
-// binary64 merge walk.  For every other pair the 1e-6 bar of BASELINE.json is missed with
-// probability <= 2 exp(-2 * 25) = 4e-22, and half of it (what the run-time audit checks) with
-// probability <= 2 exp(-12.5) per pair in the worst case of the bound, ~1e-9 for typical
-// variances -- and that only for the pairs right at the threshold.
-constexpr double REFINE_BAR = 1e-6;   // the relative bar of BASELINE.json ("within 1e-6 relative for weighted")
-constexpr double REFINE_C = 5.0;
-
+// Integer sums -> distances: finish_pair (ff_kernels_finish_pair.hpp) for every slot of the shard.
 __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
                                       int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
-                                      const unsigned long long *__restrict__ W,
-                                      const double *__restrict__ wex,  // binary64 weights (null: the integer sums are exact)
-                                      int scale_log2, int weighted,
-                                      int64_t slot_begin, int64_t n_slots,
-                                      double *__restrict__ out,
-                                      const int64_t *__restrict__ indptr,  // null: no refinement
-                                      unsigned long long *__restrict__ refine_list,
-                                      unsigned long long *__restrict__ refine_count,
-                                      unsigned long long refine_cap)
+                                      const FinishArgs f, int64_t slot_begin, int64_t n_slots)
 {
     // grid-stride: a launch carries at most 2^32 - 1 threads, a shard can have more slots
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots;
@@ -37,32 +14,7 @@ __global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         slot_to_pair(slot_begin + t, &i, &j);
         uint32_t u32 = num[t];
         for (int q = 1; q < n_planes; ++q) u32 += num[(int64_t)q * plane_stride + t];
-        const unsigned long long u = u32;
-        const unsigned long long w = W[i] + W[j];
-        double d;
-        if (u == w || !wex) {
-            // u == w: no branch carries both samples (integer identity): exactly 1, or 0/0 = NaN
-            // when both are empty (unifrac.go:169,204)
-            if (weighted) {
-                d = (double)u / (double)w;                 // numer / denom
-            } else {
-                const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
-                d = (double)u / (double)(u + common);      // result / (result + common)
-            }
-        } else {
-            const double s = ldexp(wex[i] + wex[j], scale_log2);
-            d = weighted ? (double)u / s                   // numer / denom
-                         : 2.0 * (double)u / (s + (double)u);  // result / (result + common), common = (s - result) / 2
-            d = fmin(d, 1.0);  // the integer numerator may pass the binary64 denominator by its rounding
-        }
-        out[t] = d;
-        if (indptr && w != 0) {
-            const double k = (double)((indptr[i + 1] - indptr[i]) + (indptr[j + 1] - indptr[j]));
-            if ((double)u * REFINE_BAR < REFINE_C * sqrt(k) + 2.0) {
-                const unsigned long long at = atomicAdd(refine_count, 1ull);
-                if (at < refine_cap) refine_list[at] = (unsigned long long)t;
-            }
-        }
+        finish_pair(f, t, i, j, u32);
     }
 }
 

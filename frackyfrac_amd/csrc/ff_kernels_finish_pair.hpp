@@ -1,0 +1,58 @@
+// ff_kernels_finish_pair.hpp -- integer sums of ONE pair -> its distance (shared by finish_fixed32_kernel and by the
+// epilogues that finish in place).  A fragment of ff_device.hip: included there, once, inside its anonymous namespace.
+
+// Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
+//
+// U(i,j) is a sum of k <= k_i + k_j terms (k_s = flat nodes of sample s), each an unbiased
+// estimate of l_b * |x_i(b) - x_j(b)| * 2^e with an error inside (-1, 1) that is independent
+// from branch to branch (the per-branch offset of the staging, ff_dither.hpp).  Hoeffding's
+// bound for such a sum: P(|error| >= t) <= 2 exp(-2 t^2 / k).  The denominator is binary64
+// (exact_weight_kernel), so the relative error of a distance is that of U alone.  A pair whose
+// U is so small that REFINE_C * sqrt(k) units could exceed 1e-6 of it -- nearly identical
+// samples -- is queued for refine_exact_kernel, which recomputes it with the reference's own
+// binary64 merge walk.  For every other pair the 1e-6 bar of BASELINE.json is missed with
+// probability <= 2 exp(-2 * 25) = 4e-22, and half of it (what the run-time audit checks) with
+// probability <= 2 exp(-12.5) per pair in the worst case of the bound, ~1e-9 for typical
+// variances -- and that only for the pairs right at the threshold.
+constexpr double REFINE_BAR = 1e-6;   // the relative bar of BASELINE.json ("within 1e-6 relative for weighted")
+constexpr double REFINE_C = 5.0;
+
+struct FinishArgs {
+    const unsigned long long *W;   // integer column sums
+    const double *wex;             // binary64 weights (null: the integer sums are exact)
+    double *out;                   // the shard's distances, out[t] for local slot t
+    const int64_t *indptr;         // null: no refinement
+    unsigned long long *refine_list, *refine_count;
+    unsigned long long refine_cap;
+    int scale_log2, weighted;
+};
+
+// Local slot t = pair (i, j), integer numerator u.
+__device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u)
+{
+    const unsigned long long w = f.W[i] + f.W[j];
+    double d;
+    if (u == w || !f.wex) {
+        // u == w: no branch carries both samples (integer identity): exactly 1, or 0/0 = NaN
+        // when both are empty (unifrac.go:169,204)
+        if (f.weighted) {
+            d = (double)u / (double)w;                 // numer / denom
+        } else {
+            const unsigned long long common = (w - u) >> 1;  // exact: w - u = 2 * common
+            d = (double)u / (double)(u + common);      // result / (result + common)
+        }
+    } else {
+        const double s = ldexp(f.wex[i] + f.wex[j], f.scale_log2);
+        d = f.weighted ? (double)u / s                   // numer / denom
+                       : 2.0 * (double)u / (s + (double)u);  // result / (result + common), common = (s - result) / 2
+        d = fmin(d, 1.0);  // the integer numerator may pass the binary64 denominator by its rounding
+    }
+    f.out[t] = d;
+    if (f.indptr && w != 0) {
+        const double k = (double)((f.indptr[i + 1] - f.indptr[i]) + (f.indptr[j + 1] - f.indptr[j]));
+        if ((double)u * REFINE_BAR < REFINE_C * sqrt(k) + 2.0) {
+            const unsigned long long at = atomicAdd(f.refine_count, 1ull);
+            if (at < f.refine_cap) f.refine_list[at] = (unsigned long long)t;
+        }
+    }
+}

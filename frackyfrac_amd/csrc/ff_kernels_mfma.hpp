@@ -109,7 +109,8 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                              const int8_t *__restrict__ Kd, int64_t ldb, const MItem *__restrict__ items,
                              const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
                              uint32_t *__restrict__ num, uint32_t *__restrict__ partial, int64_t row_begin,
-                             int64_t row_end, int64_t slot_begin)
+                             int64_t row_end, int64_t slot_begin,
+                             const FinishArgs fin)  // fin.out != null: a tile's only item writes distances, not sums
 {
     extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];  // [slab of the segment][plane][64 digits]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,21 +149,30 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
             const int8_t *tab = mfma_lds + half * 16;
             mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
             mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
-            uint2 wa0[2], wa1[2], wb[2];               // [slab parity]: i-words of rows lane / 64 + lane, j-words
+            uint2 wa0[4], wa1[4], wb[4];               // [slab & 3]: i-words of rows lane / 64 + lane, j-words
             uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
             uint32_t t[8];                             // its B masks in the making
             uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
             const uint2 *qa = pa + (int64_t)seg * n8, *qb = pb + (int64_t)seg * n8;
-            wa0[0] = qa[0];
-            wa1[0] = qa[64];
-            wb[0] = qb[0];
-            wa0[1] = qa[n8];
-            wa1[1] = qa[n8 + 64];
-            wb[1] = qb[n8];
-            qa += 2 * n8;
-            qb += 2 * n8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // slabs 0..3 of the segment
+                wa0[q] = qa[0];
+                wa1[q] = qa[64];
+                wb[q] = qb[0];
+                qa += n8;
+                qb += n8;
+            }
+            auto load_words = [&](int buf) {  // the next slab not yet requested, into buffer `buf` (reads past the
+                if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
+                    wa0[buf] = qa[0];
+                    wa1[buf] = qa[64];
+                    wb[buf] = qb[0];
+                }
+                qa += n8;
+                qb += n8;
+            };
             auto read_digits = [&](int set, int kstep) {  // kstep = 2 * slab + kt, within the segment
                 if constexpr (!(DIAG & 8)) {
                     dg0[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64);
@@ -171,7 +181,7 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                     dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
                 }
             };
-            // the words of slab parity `parity`, half `kt`, to where the fragments want them (3 swaps)
+            // the words in buffer `parity`, half `kt`, to where the fragments want them (3 swaps)
             auto take_words = [&](int parity, int kt) {
                 const uint32_t w0 = kt ? wa0[parity].y : wa0[parity].x, w1 = kt ? wa1[parity].y : wa1[parity].x;
                 const uint32_t wy = kt ? wb[parity].y : wb[parity].x;
@@ -198,7 +208,7 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
     __builtin_amdgcn_sched_barrier(0)
 #define FF_OP(stmt) if constexpr (!(DIAG & 4)) { stmt; }
 #define FF_END_PIECE() __builtin_amdgcn_sched_barrier(0)
-            // K-step `u` of the current slab pair (u = 0..3; slab sl + (u >> 1), kt = u & 1): the 16 MFMAs of
+            // K-step `u` of the current group of four slabs (u = 0..7; slab sl + (u >> 1), kt = u & 1): the 16 MFMAs of
             // set `cur`, and behind them the 72 vector operations that build set `nxt` for k-step u + 1
             // -- per B dword pair: shift, and, byte mask, two ands with the digits; per A dword: shift,
             // and -- dealt out LEVEL BY LEVEL (all shifts, then all ands, ...), so that no instruction
@@ -206,7 +216,7 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
             // dependent chain behind.  The last slot swaps in the words of k-step u + 2.
             auto kstep = [&](int u, int sl) {
                 const int cur = u & 1, nxt = cur ^ 1;
-                const int bp2 = ((u + 2) >> 1) & 1, bkt2 = u & 1;  // slab parity and half of k-step u + 2
+                const int bp2 = ((u + 2) >> 1) & 3, bkt2 = u & 1;  // buffer and half of k-step u + 2
                 read_digits(cur, 2 * sl + u + 2);  // set `cur` is rebuilt in the NEXT k-step, for u + 2
                 __builtin_amdgcn_sched_barrier(0);
                 FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_OP(t[0] = swy[0] >> shk[0]); FF_OP(t[1] = swy[0] >> shk[1]); FF_OP(t[2] = swy[0] >> shk[2]); FF_OP(t[3] = swy[0] >> shk[3]); FF_END_PIECE();
@@ -252,29 +262,34 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                 }
             }
             take_words(0, 1);
+            load_words(0);  // slab 4
             __builtin_amdgcn_sched_barrier(0);
+            // Buffer b holds the words of the slab whose number is b mod 4.  The k-steps of slab t consume
+            // the words of slab t + 1 (they build ITS fragments); that buffer then takes slab t + 5: four
+            // slabs, about 5,000 cycles, between a load and its first use -- with one wave per SIMD a late
+            // load stalls the matrix pipe outright (two slabs of distance left 14 % of the wave's life
+            // in s_waitcnt).
             int sl = 0;
-            for (; sl + 1 < nseg; sl += 2) {
+            for (; sl + 3 < nseg; sl += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    kstep(2 * q, sl);
+                    kstep(2 * q + 1, sl);
+                    load_words((q + 1) & 3);
+                }
+            }
+            // the last one to three slabs (what their k-steps build past the end is never used)
+            if (sl < nseg) {
                 kstep(0, sl);
                 kstep(1, sl);
-                if constexpr (!(DIAG & 2)) {  // slab sl's words are used up: fetch slab sl + 2 (reads past the
-                    wa0[0] = qa[0];           // item's end hit the arrays' padding and are never multiplied)
-                    wa1[0] = qa[64];
-                    wb[0] = qb[0];
-                }
+            }
+            if (sl + 1 < nseg) {
                 kstep(2, sl);
                 kstep(3, sl);
-                if constexpr (!(DIAG & 2)) {
-                    wa0[1] = qa[n8];
-                    wa1[1] = qa[n8 + 64];
-                    wb[1] = qb[n8];
-                }
-                qa += 2 * n8;
-                qb += 2 * n8;
             }
-            if (sl < nseg) {  // odd slab count: the last slab's two k-steps (what they build is never used)
-                kstep(0, sl);
-                kstep(1, sl);
+            if (sl + 2 < nseg) {
+                kstep(4, sl);
+                kstep(5, sl);
             }
 #undef FF_MM
 #undef FF_OP
@@ -334,7 +349,13 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                     *(uint2 *)(pt + row * M_TILE_J) = uint2{v0, v1};
                 } else if constexpr (!ALL_PRIVATE) {
                     if (i < row_begin || i >= row_end) continue;
-                    uint32_t *dst = num + (i * (i - 1) / 2 - slot_begin + j);
+                    const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
+                    if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
+                        if (j < i) finish_pair(fin, t0, i, j, v0);
+                        if (j + 1 < i) finish_pair(fin, t0 + 1, i, j + 1, v1);
+                        continue;
+                    }
+                    uint32_t *dst = num + t0;
                     if (item.pad < 0) {
                         if (j + 1 < i) {
                             // (a row's slots start at i (i - 1) / 2: 8-byte aligned only for some i)
@@ -356,7 +377,8 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
 // partials tile_ptr[t] .. tile_ptr[t+1]; one thread per pair of the tile.
 __global__ void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t *__restrict__ tiles,
                                        const int32_t *__restrict__ tile_ptr, uint32_t *__restrict__ num,
-                                       int64_t row_begin, int64_t row_end, int64_t slot_begin)
+                                       int64_t row_begin, int64_t row_end, int64_t slot_begin,
+                                       const FinishArgs fin)  // fin.out != null: distances, not sums
 {
     const int t = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // lr * M_TILE_J + lc
@@ -364,5 +386,7 @@ __global__ void reduce_partials_kernel(const uint32_t *__restrict__ partial, con
     if (i < row_begin || i >= row_end || j >= i) return;
     uint32_t s = 0;
     for (int p = tile_ptr[t]; p < tile_ptr[t + 1]; ++p) s += partial[(int64_t)p * (M_TILE_I * M_TILE_J) + idx];
-    num[i * (i - 1) / 2 - slot_begin + j] = s;
+    const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
+    if (fin.out) finish_pair(fin, slot, i, j, s);
+    else num[slot] = s;
 }

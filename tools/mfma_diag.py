@@ -24,10 +24,9 @@ else:
 nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
 plan = ff.Plan(nodes, False, precision="fixed32")
 out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
-names = {0: "full kernel", 1: "no barrier", 2: "no global loads in the loop", 4: "no expansion (VALU + LDS stores)",
-         8: "no fragment reads", 16: "no MFMA", 6: "no loads, no expansion", 14: "MFMA + barrier only",
-         15: "MFMA only", 30: "barrier only (loop + epilogues)", 31: "nothing (loop + epilogues)"}
-for diag in (0, 1, 2, 4, 8, 16, 6, 14, 15, 30, 31):
+names = {0: "full kernel", 2: "no global loads in the loop", 4: "no fragment building (vector work)",
+         8: "no digit reads", 6: "no loads, no fragment building", 14: "MFMAs only"}
+for diag in (0, 2, 4, 8, 6, 14):
     os.environ["FF_MFMA_DIAG"] = str(diag)
     for _ in range(3):
         plan.run(out.data_ptr())
