@@ -109,6 +109,9 @@ SIGNATURES = {
     "ff_format_float": (c_int, [c_double, c_char_p]),
     "ff_write_distances": (c_int, [c_char_p, c_void_p, c_int64, c_int, c_char_p, c_size_t]),
     "ff_frcfrc_main": (c_int, [c_int, POINTER(c_char_p)]),
+    "ff_tune": (c_int, [c_char_p, c_char_p]),
+    "ff_synth_counts": (c_int, [c_int64, c_double, ctypes.c_uint64, c_int64, c_int64, c_int, c_void_p]),
+    "ff_synth_fill": (c_int, [c_int64, c_double, ctypes.c_uint64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ff_version": (c_char_p, []),
 }
 

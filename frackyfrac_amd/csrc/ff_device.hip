@@ -161,7 +161,7 @@ template <typename T> struct Scratch {
 
 int env_int(const char *name, int dflt)
 {
-    const char *v = getenv(name);
+    const char *v = ff::tuning(name);
     if (!v || !*v) return dflt;
     return atoi(v);
 }
@@ -363,7 +363,7 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
     FF_HIP(hipGetDevice(&pl->device));
     (void)hipGetLastError();  // a stale error of the caller's (or of a failed plan) is not ours
     FF_HIP(hipGetDeviceProperties(prop, pl->device));
-    if (strncmp(prop->gcnArchName, "gfx950", 6) != 0 && !getenv("FF_ALLOW_ANY_ARCH"))
+    if (strncmp(prop->gcnArchName, "gfx950", 6) != 0 && !ff::tuning("FF_ALLOW_ANY_ARCH"))
         return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d is %s; this engine is built for gfx950 only",
                         pl->device, prop->gcnArchName);
     pl->weighted = o->weighted != 0;
@@ -620,7 +620,7 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     // matrix of 8192 x 50k leaves lose 1-2 % with it.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
     pl->reg12 = env_int("FF_REG12", 0) != 0;
-    if (!pl->sparse && !getenv("FF_WAVES_PER_WG") &&
+    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG") &&
         inf.n_tiles >= 2 * (int64_t)pl->n_workgroups * L_WAVES_PER_WG && inf.staged_bytes <= 2.0e9) {
         pl->waves_per_wg = L_WAVES_PER_WG;
         pl->reg12 = true;
@@ -977,7 +977,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
         const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
         const double inactive = 1.0 - (double)active / total;
-        const char *thr = getenv("FF_SPARSE_MIN");
+        const char *thr = ff::tuning("FF_SPARSE_MIN");
         // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
         // prefetch, per-row address arithmetic), so it pays from about a quarter upwards
         if (inactive >= (thr && *thr ? atof(thr) : 0.28)) {

@@ -34,6 +34,10 @@ int read_all(const char *path, std::string *out, char *err, size_t errlen);
 
 unsigned clamp_threads(int requested);
 
+// A tuning switch (the FF_* names of INTEGRATION.md): the value given through ff_tune, else the
+// environment variable of that name, else null.  The pointer stays valid until the next ff_tune.
+const char *tuning(const char *name);
+
 // Runs fn(t, begin, end) over [0, n) split into contiguous chunks on `threads` threads.
 void parallel_for(int64_t n, unsigned threads,
                   const std::function<void(unsigned, int64_t, int64_t)> &fn);

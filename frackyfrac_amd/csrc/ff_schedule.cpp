@@ -1,4 +1,5 @@
 // ff_schedule.cpp -- host-side work schedules of the pair kernels (see ff_schedule.hpp).
+#include "ff_host.hpp"
 #include "ff_schedule.hpp"
 
 #include <algorithm>
@@ -32,7 +33,7 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
 // cost 0.2 % and 1.5 %: more, shorter items).
 int xcd_slices()
 {
-    const char *e = getenv("FF_XCD_SLICES");
+    const char *e = ff::tuning("FF_XCD_SLICES");
     const int v = e && *e ? atoi(e) : 2;
     return v < 0 ? 0 : v;
 }
@@ -41,7 +42,7 @@ int xcd_slices()
 // fits three waves per SIMD; 8 = the register-buffered kernel with two.
 int waves_per_wg()
 {
-    const char *e = getenv("FF_WAVES_PER_WG");
+    const char *e = ff::tuning("FF_WAVES_PER_WG");
     const int v = e && *e ? atoi(e) : WAVES_PER_WG;
     return v == L_WAVES_PER_WG ? L_WAVES_PER_WG : WAVES_PER_WG;
 }
@@ -70,7 +71,7 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     // (8 x 128 B of scalar operands): 2 KiB per workgroup and branch instead of 8 KiB + 128 B with
     // row-block major order.  Measured: fabric traffic 280 -> 101 GB per launch at C4, 2.30 -> 2.09
     // at C3, kernel times unchanged (FF_TILE_ORDER=row restores the old order).
-    const char *order = getenv("FF_TILE_ORDER");
+    const char *order = ff::tuning("FF_TILE_ORDER");
     if (!(order && order[0] == 'r'))
         std::stable_sort(wide.begin(), wide.end(), [](const Tile &a, const Tile &b) { return a.j0 < b.j0; });
     const int64_t T = (int64_t)wide.size();

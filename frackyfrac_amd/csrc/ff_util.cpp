@@ -9,6 +9,9 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "ff_host.hpp"
 
 namespace ff {
@@ -475,3 +478,30 @@ int ff_write_distances(const char *path, const double *d, int64_t n, int threads
 }
 
 }  // extern "C"
+
+// ---- tuning switches: ff_tune overrides, then the environment -----------------------------
+
+namespace {
+std::mutex g_tune_mu;
+std::unordered_map<std::string, std::string> g_tune;
+}  // namespace
+
+const char *ff::tuning(const char *name)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(name);
+        if (it != g_tune.end()) return it->second.c_str();
+    }
+    return getenv(name);
+}
+
+extern "C" int ff_tune(const char *name, const char *value)
+{
+    if (!name || strncmp(name, "FF_", 3) != 0) return FF_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (value) g_tune[name] = value;
+    else g_tune.erase(name);
+    return FF_OK;
+}
+

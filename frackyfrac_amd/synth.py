@@ -12,17 +12,102 @@ Abundances: each (sample, leaf) is present independently with probability
 `density`; the value is the integer count 1 + floor(999 * u^2), u uniform in
 [0, 1).  Every sample is forced to hold at least one leaf.
 
-PRNG: numpy's PCG64 seeded with 0xF4AC0000 + config number (Generator streams
-are stable across numpy versions for the methods used here).
+PRNG: splitmix64 -> xoshiro256**, seed = 0xF4AC0000 + config number.  Any host
+can regenerate the inputs from this recipe, no numpy needed:
+  * stream(seed, k): a xoshiro256** generator whose four state words are four consecutive
+    outputs of splitmix64 started at  seed XOR (0xD1B54A32D192ED03 * k mod 2^64);
+    double() = (next() >> 11) * 2^-53.
+  * tree = stream(seed, 0): for t = 0 .. n_leaves-3 the leaf to split is
+    floor(double() * number_of_current_leaves) in the list of current leaves (the split leaf's
+    slot takes its first child, the second child is appended); then, for the nodes in
+    pre-order, the root included, length = (1 + floor(double() * 1024)) / 1024 (the root's is
+    then set to 0).
+  * sample s = stream(seed, s + 1): for the leaves in pre-order two draws each, u1 then u2:
+    present iff u1 < density, count = 1 + floor(999 * u2 * u2); after all leaves one more draw
+    u3: a sample with no leaf present holds leaf floor(u3 * n_leaves) with the count that leaf
+    drew.
+Samples have streams of their own, so a process can generate any range of samples
+(`abundances(..., begin, end)`): with one process per GPU each rank generates, flattens and
+uploads only its share, and the flat nodes are all-gathered (frackyfrac_amd/distributed.py).
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
 SEED_BASE = 0xF4AC0000
+_M64 = (1 << 64) - 1
+_STREAM_MUL = 0xD1B54A32D192ED03
+
+
+def _splitmix64(state: int) -> Tuple[int, int]:
+    """(next state, output) of splitmix64."""
+    state = (state + 0x9E3779B97F4A7C15) & _M64
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return state, z ^ (z >> 31)
+
+
+class Xoshiro:
+    """xoshiro256** on Python integers (the tree's stream; the reference for XoshiroVec)."""
+
+    def __init__(self, seed: int, stream: int = 0):
+        st = (seed ^ ((_STREAM_MUL * stream) & _M64)) & _M64
+        self.s = []
+        for _ in range(4):
+            st, out = _splitmix64(st)
+            self.s.append(out)
+
+    def next(self) -> int:
+        s = self.s
+        x = (s[1] * 5) & _M64
+        res = ((((x << 7) | (x >> 57)) & _M64) * 9) & _M64
+        t = (s[1] << 17) & _M64
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = ((s[3] << 45) | (s[3] >> 19)) & _M64
+        return res
+
+    def double(self) -> float:
+        return (self.next() >> 11) * (1.0 / 9007199254740992.0)
+
+
+class XoshiroVec:
+    """One xoshiro256** stream per entry of `streams` (uint64 stream numbers), stepped together."""
+
+    def __init__(self, seed: int, streams: np.ndarray):
+        with np.errstate(over="ignore"):
+            st = np.uint64(seed) ^ (np.uint64(_STREAM_MUL) * streams.astype(np.uint64))
+            self.s = []
+            for _ in range(4):
+                st = st + np.uint64(0x9E3779B97F4A7C15)
+                z = st.copy()
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                self.s.append(z ^ (z >> np.uint64(31)))
+
+    def next(self) -> np.ndarray:
+        s = self.s
+        with np.errstate(over="ignore"):
+            x = s[1] * np.uint64(5)
+            res = ((x << np.uint64(7)) | (x >> np.uint64(57))) * np.uint64(9)
+            t = s[1] << np.uint64(17)
+        s[2] = s[2] ^ s[0]
+        s[3] = s[3] ^ s[1]
+        s[1] = s[1] ^ s[2]
+        s[0] = s[0] ^ s[3]
+        s[2] = s[2] ^ t
+        s[3] = (s[3] << np.uint64(45)) | (s[3] >> np.uint64(19))
+        return res
+
+    def double(self) -> np.ndarray:
+        return (self.next() >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 @dataclass
@@ -81,18 +166,18 @@ def _fmt_len(x: float) -> str:
     return repr(float(x))
 
 
-def yule_tree(n_leaves: int, rng: np.random.Generator) -> SynthTree:
+def yule_tree(n_leaves: int, seed: int) -> SynthTree:
     if n_leaves < 2:
         raise ValueError("need at least 2 leaves")
+    rng = Xoshiro(seed, 0)
     # binary tree as child arrays; node 0 = root
     left = [1]
     right = [2]
     left += [-1, -1]
     right += [-1, -1]
     leaves = [1, 2]
-    picks = rng.random(n_leaves - 2)
-    for t in range(n_leaves - 2):
-        k = int(picks[t] * len(leaves))
+    for _ in range(n_leaves - 2):
+        k = int(rng.double() * len(leaves))
         nd = leaves[k]
         a = len(left)
         left.extend([-1, -1])
@@ -120,7 +205,7 @@ def yule_tree(n_leaves: int, rng: np.random.Generator) -> SynthTree:
     size = np.ones(total, dtype=np.int64)
     for i in range(total - 1, 0, -1):
         size[parent_new[i]] += size[i]
-    blen = rng.integers(1, 1025, size=total).astype(np.float64) / 1024.0
+    blen = np.array([(1 + int(rng.double() * 1024)) / 1024.0 for _ in range(total)], dtype=np.float64)
     blen[0] = 0.0
     names = [""] * total
     leaf_ids = np.flatnonzero(size == 1)
@@ -129,25 +214,66 @@ def yule_tree(n_leaves: int, rng: np.random.Generator) -> SynthTree:
     return SynthTree(parent_new, size, blen, names, leaf_ids.astype(np.int64))
 
 
-def abundances(tree: SynthTree, n_samples: int, density: float, rng: np.random.Generator,
-               chunk: int = 256) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Leaf-value CSR: (leaf_ptr int64[N+1], leaf_idx int64[nnz] node ids, leaf_val float64[nnz])."""
+def abundances(tree: SynthTree, n_samples: int, density: float, seed: int, begin: int = 0,
+               end: Optional[int] = None, threads: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Leaf-value CSR of samples [begin, end) (default: all): (leaf_ptr int64[m+1], leaf_idx int64[nnz]
+    node ids, leaf_val float64[nnz]).  Generated by the library's C twin of the recipe
+    (csrc/ff_synth.cpp: ff_synth_counts / ff_synth_fill), on `threads` host threads (0: all)."""
+    import os
+
+    from . import _lib as L
+
+    if end is None:
+        end = n_samples
+    m, nl = end - begin, len(tree.leaf_ids)
+    if threads <= 0:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    counts = np.zeros(max(m, 1), dtype=np.int64)
+    rc = L.lib().ff_synth_counts(nl, float(density), int(seed), begin, end, threads, counts.ctypes.data)
+    if rc:
+        raise ValueError("ff_synth_counts: bad argument")
+    ptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts[:m], out=ptr[1:])
+    ordinal = np.zeros(max(int(ptr[-1]), 1), dtype=np.int64)
+    val = np.zeros(max(int(ptr[-1]), 1), dtype=np.float64)
+    rc = L.lib().ff_synth_fill(nl, float(density), int(seed), begin, end, threads, ptr.ctypes.data, ordinal.ctypes.data,
+                               val.ctypes.data)
+    if rc:
+        raise ValueError("ff_synth_fill: bad argument")
+    nnz = int(ptr[-1])
+    return ptr, tree.leaf_ids[ordinal[:nnz]].astype(np.int64), val[:nnz]
+
+
+def abundances_numpy(tree: SynthTree, n_samples: int, density: float, seed: int, begin: int = 0,
+                     end: Optional[int] = None, chunk: int = 4096) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """The same table from the numpy statement of the recipe (XoshiroVec): what tests compare the C
+    generator with; ten times slower."""
+    if end is None:
+        end = n_samples
     L = len(tree.leaf_ids)
     ptr = [0]
     idx_parts, val_parts = [], []
-    for s0 in range(0, n_samples, chunk):
-        m = min(chunk, n_samples - s0)
-        present = rng.random((m, L)) < density
-        u = rng.random((m, L))
-        forced = rng.integers(0, L, size=m)
+    for s0 in range(begin, end, chunk):
+        m = min(chunk, end - s0)
+        gen = XoshiroVec(seed, np.arange(s0 + 1, s0 + m + 1, dtype=np.uint64))
+        present = np.empty((L, m), dtype=bool)
+        count = np.empty((L, m), dtype=np.uint16)
+        for k in range(L):  # the streams step together: two draws per leaf
+            present[k] = gen.double() < density
+            u = gen.double()
+            count[k] = (1.0 + np.floor(999.0 * u * u)).astype(np.uint16)
+        forced = np.minimum((gen.double() * L).astype(np.int64), L - 1)
+        present = np.ascontiguousarray(present.T)
+        count = np.ascontiguousarray(count.T)
         for r in range(m):
             cols = np.flatnonzero(present[r])
             if len(cols) == 0:
                 cols = np.array([forced[r]])
-            vals = 1.0 + np.floor(999.0 * u[r, cols] ** 2)
             idx_parts.append(tree.leaf_ids[cols])
-            val_parts.append(vals)
+            val_parts.append(count[r, cols].astype(np.float64))
             ptr.append(ptr[-1] + len(cols))
+    if not idx_parts:
+        return np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float64)
     return (np.asarray(ptr, dtype=np.int64), np.concatenate(idx_parts).astype(np.int64),
             np.concatenate(val_parts).astype(np.float64))
 
@@ -183,9 +309,8 @@ CONFIGS = {
 }
 
 
-def make(n_samples: int, n_leaves: int, density: float, seed: int):
-    """(tree, leaf_ptr, leaf_idx, leaf_val) for one configuration."""
-    rng = np.random.default_rng(seed)
-    tree = yule_tree(n_leaves, rng)
-    ptr, idx, val = abundances(tree, n_samples, density, rng)
+def make(n_samples: int, n_leaves: int, density: float, seed: int, begin: int = 0, end: Optional[int] = None):
+    """(tree, leaf_ptr, leaf_idx, leaf_val) for one configuration (samples [begin, end) of it)."""
+    tree = yule_tree(n_leaves, seed)
+    ptr, idx, val = abundances(tree, n_samples, density, seed, begin, end)
     return tree, ptr, idx, val

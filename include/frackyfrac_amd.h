@@ -339,6 +339,23 @@ int ff_write_distances(const char *path, const double *d, int64_t n, int threads
  * "ERROR: ..." to stderr). */
 int ff_frcfrc_main(int argc, char **argv);
 
+/* The synthetic abundance tables of the benchmark (recipe in frackyfrac_amd/synth.py
+ * and csrc/ff_synth.cpp: splitmix64 -> xoshiro256**, one stream per sample, so any range of samples
+ * can be generated on its own).  Samples [sample_begin, sample_end) of a table over n_leaves leaves:
+ * first the number of leaves each holds, then -- with ptr = their exclusive prefix sums -- the leaf
+ * ordinals (0 .. n_leaves-1, ascending within a sample) and integer counts.  Host code, no GPU. */
+int ff_synth_counts(int64_t n_leaves, double density, uint64_t seed, int64_t sample_begin, int64_t sample_end,
+                    int threads, int64_t *counts);
+int ff_synth_fill(int64_t n_leaves, double density, uint64_t seed, int64_t sample_begin, int64_t sample_end,
+                  int threads, const int64_t *ptr, int64_t *leaf_ordinal, double *value);
+
+/* The tuning switches INTEGRATION.md lists as FF_* environment variables (FF_WAVES_PER_WG,
+ * FF_XCD_SLICES, FF_SPARSE_MIN, FF_AUDIT, ...), for a host that cannot or should not change its
+ * environment: a value set here wins over the environment variable of the same name; value NULL
+ * removes the override.  Process-wide; switches are read when a plan is created or re-targeted
+ * (never per launch), so set them before ff_plan_create.  Defaults are the measured best. */
+int ff_tune(const char *name, const char *value);
+
 const char *ff_version(void);
 
 #ifdef __cplusplus

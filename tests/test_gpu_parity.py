@@ -354,6 +354,64 @@ def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts
         assert np.array_equal(parts, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("exact_lengths", [True, False])
+@pytest.mark.parametrize("ns", [300, 1200])
+def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch, exact_lengths, ns):
+    """FF_MFMA_FUSED_FINISH: distances written by the pair kernel's epilogue / the partial reduction
+    (no num[], no finish launch) or by finish_fixed32_kernel -- the same doubles either way, with the
+    refinement queue in play when the lengths are off the binary grid (replicated samples), and the
+    oracle's to 1e-6 (bit-exact for dyadic lengths)."""
+    tree, ptr, idx, val = synth.make(ns, 1500, 0.1, 31 + ns)
+    if not exact_lengths:
+        tree.branch_len[:] = np.random.default_rng(1).integers(1, 40, size=tree.n) / 10.0
+        tree.branch_len[0] = 0.0
+    k = int(ptr[1])  # samples 0..9 are one sample: distance 0, queued for the exact walk when lengths are inexact
+    ptr2 = np.concatenate([[0], np.cumsum([k] * 10 + list(np.diff(ptr)[10:]))]).astype(np.int64)
+    idx2 = np.concatenate([np.tile(idx[:k], 10), idx[ptr[10]:]])
+    val2 = np.concatenate([np.tile(val[:k], 10), val[ptr[10]:]])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr2, idx2, val2)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr2, idx2, val2, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("FF_MFMA_FUSED_FINISH", fused)
+        plan = ff.Plan(nodes, False, precision="fixed32")
+        assert plan.info.kernel == 2 and plan.info.lengths_exact == (1 if exact_lengths else 0)
+        got[fused] = plan.run_host()
+        if not exact_lengths:
+            queued, cap = plan.refined_pairs()
+            assert 45 <= queued <= cap
+        plan.close()
+    assert np.array_equal(got["0"], got["1"])
+    if exact_lengths:
+        assert np.array_equal(got["1"], want)
+    else:
+        assert np.all(got["1"][want == 0] == 0)
+        assert rel_err(got["1"], want) <= WEIGHTED_RTOL
+
+
+def test_tuning_switches_through_the_c_abi():
+    """ff_tune sets what the FF_* environment variables set, for hosts that cannot touch their
+    environment (a Go program after start-up): the override wins, NULL removes it."""
+    nodes, ip, on, ft = synth_problem(700, 900, 0.1, 52)
+    lib = L.lib()
+    try:
+        assert lib.ff_tune(b"FF_WAVES_PER_WG", b"12") == 0 and lib.ff_tune(b"FF_REG12", b"1") == 0
+        plan = ff.Plan(nodes, True, precision="fixed32")
+        assert plan.info.n_wave_slots == 12 * plan.info.n_compute_units
+        got12 = plan.run_host()
+        plan.close()
+    finally:
+        assert lib.ff_tune(b"FF_WAVES_PER_WG", None) == 0 and lib.ff_tune(b"FF_REG12", None) == 0
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.n_wave_slots == 8 * plan.info.n_compute_units
+    assert np.array_equal(plan.run_host(), got12)
+    plan.close()
+    assert lib.ff_tune(b"PATH", b"x") != 0 and lib.ff_tune(None, b"x") != 0
+
+
 def test_cli_gpus_flag_matches_single_shard(tmp_path):
     tree, ptr, idx, val = synth.make(700, 3000, 0.1, 97)
     (tmp_path / "t.tree").write_text(tree.newick())

@@ -201,7 +201,7 @@ def test_prefix_and_threads():
 
 def test_selfgenerated_fixture_is_stable():
     """tests/golden/selfgen: written by make_selfgen.py from the oracle itself; pins the
-    synthetic generator (numpy PCG64 stream) and the oracle against silent drift."""
+    synthetic generator (splitmix64 -> xoshiro256**) and the oracle against silent drift."""
     import os
     from conftest import GOLDEN
     from frackyfrac_amd import synth

@@ -89,3 +89,32 @@ def test_stage_a_host_matches_oracle(ns, nl, dens, seed):
     ip, nodes = O.flatten_samples(ft, ptr, idx, val, 0)
     assert np.array_equal(got.indptr, ip) and np.array_equal(got.branch_id, nodes["id"])
     assert np.array_equal(got.abnd, nodes["abnd"])
+
+
+def test_synthetic_generator_follows_its_recipe():
+    """splitmix64 -> xoshiro256**.  The published reference vectors of both generators,
+    the numpy statement of the recipe against the library's C twin (every sample, any range of
+    samples on its own), and the properties the recipe promises."""
+    from frackyfrac_amd import synth
+
+    assert synth._splitmix64(0)[1] == 0xE220A8397B1DCDAF
+    g = synth.Xoshiro(0)
+    g.s = [1, 2, 3, 4]
+    assert [g.next() for _ in range(4)] == [11520, 0, 1509978240, 1215971899390074240]
+    vec = synth.XoshiroVec(99, np.arange(1, 8, dtype=np.uint64))
+    draws = [vec.next() for _ in range(12)]
+    for s in range(7):
+        ref = synth.Xoshiro(99, s + 1)
+        assert [int(d[s]) for d in draws] == [ref.next() for _ in range(12)]
+    for ns, nl, dens, seed in ((41, 70, 0.2, 5), (6, 3, 0.01, 9), (300, 150, 0.1, synth.SEED_BASE + 2)):
+        tree = synth.yule_tree(nl, seed)
+        assert tree.n == 2 * nl - 1 and tree.branch_len[0] == 0 and np.all(tree.branch_len[1:] * 1024 % 1 == 0)
+        a = synth.abundances(tree, ns, dens, seed)
+        b = synth.abundances_numpy(tree, ns, dens, seed)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        ptr, idx, val = a
+        assert np.all(np.diff(ptr) >= 1) and np.all((val >= 1) & (val <= 1000) & (val % 1 == 0))
+        lo, hi = 2, min(ns, 11)
+        p2, i2, v2 = synth.abundances(tree, ns, dens, seed, lo, hi)
+        assert np.array_equal(p2, ptr[lo:hi + 1] - ptr[lo]) and np.array_equal(i2, idx[ptr[lo]:ptr[hi]])
+        assert np.array_equal(v2, val[ptr[lo]:ptr[hi]])
