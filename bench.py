@@ -157,9 +157,15 @@ def make_problem(ctx, workload, n_samples=None):
     if n_samples is not None:
         cfg["n_samples"] = n_samples
     t0 = time.perf_counter()
-    tree, ptr, idx, val = synth.make(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+    # N > 1: every rank generates and flattens only its own block of samples (the generator has a
+    # stream per sample); one all-gather replicates the flat nodes
+    from frackyfrac_amd.distributed import allgather_flat_nodes, sample_block
+    b, e = sample_block(cfg["n_samples"], ctx.rank, ctx.world)
+    tree, ptr, idx, val = synth.make(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"], b, e)
     T = ff.parse_newick(tree.newick())
     nodes = ff.flatten_leaf_csr(T, ptr, idx, val)        # stage A on the host
+    if ctx.world > 1:
+        nodes = allgather_flat_nodes(nodes)
     cfg["prep_s"] = time.perf_counter() - t0
     cfg["name"] = name
     return cfg, nodes

@@ -60,6 +60,46 @@ def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, f
     return None
 
 
+def allgather_flat_nodes(local: "api.FlatNodes", group=None) -> "api.FlatNodes":
+    """Input replication: every rank has flattened ONLY its own contiguous block of
+    samples (rank order = sample order) -- a G-th of stage A and of the upload each -- and one
+    all-gather over RCCL/xGMI (padded to the largest block) gives every rank the flat nodes of all
+    samples, from which it stages the matrix its pair tiles read.  Works on CPU groups (gloo) too."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    n, nnz = local.n_samples, int(local.indptr[-1])
+    sizes = torch.zeros(world, 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([[n, nnz]], dtype=torch.int64, device=dev), group=group)
+    sizes = sizes.cpu().numpy()
+    max_n, max_nnz = int(sizes[:, 0].max()), max(1, int(sizes[:, 1].max()))
+
+    def gather(arr, dtype, width):
+        buf = torch.zeros(width, dtype=dtype, device=dev)
+        buf[:len(arr)] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        out = torch.empty(world * width, dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        return out.cpu().numpy().reshape(world, width)
+
+    counts = gather(np.diff(local.indptr), torch.int64, max(1, max_n))
+    ids = gather(local.branch_id, torch.int32, max_nnz)
+    abnd = gather(local.abnd, torch.float64, max_nnz)
+    all_counts = np.concatenate([counts[r, :sizes[r, 0]] for r in range(world)])
+    indptr = np.zeros(len(all_counts) + 1, dtype=np.int64)
+    np.cumsum(all_counts, out=indptr[1:])
+    return api.FlatNodes(indptr, np.concatenate([ids[r, :sizes[r, 1]] for r in range(world)]),
+                         np.concatenate([abnd[r, :sizes[r, 1]] for r in range(world)]), local.branch_len)
+
+
+def sample_block(n_samples: int, rank: int, world: int):
+    """The contiguous block of samples rank `rank` generates / parses / flattens: [begin, end)."""
+    return n_samples * rank // world, n_samples * (rank + 1) // world
+
+
 def gather_slices_chunked(produce: Callable, n_samples: int, rank: int, world: int, chunks: int, root: int = 0,
                           full=None, group=None, copy_root: Optional[Callable] = None):
     """The gather with every rank's shard cut into `chunks` equal-pair sub-shards (sub-shard c of

@@ -124,3 +124,47 @@ def test_chunked_gather_gloo(world, n_samples, chunks):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_allgather(rank, world, port, n_samples, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import frackyfrac_amd as ff
+    from frackyfrac_amd import synth
+    from frackyfrac_amd.distributed import allgather_flat_nodes, sample_block
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = sample_block(n_samples, rank, world)
+    tree, ptr, idx, val = synth.make(n_samples, 80, 0.15, 424, b, e)   # this rank's samples only
+    T = ff.parse_newick(tree.newick())
+    mine = ff.flatten_leaf_csr(T, ptr, idx, val)
+    assert mine.n_samples == e - b
+    got = allgather_flat_nodes(mine)
+    tree, ptr, idx, val = synth.make(n_samples, 80, 0.15, 424)
+    want = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ok = (np.array_equal(got.indptr, want.indptr) and np.array_equal(got.branch_id, want.branch_id)
+          and np.array_equal(got.abnd, want.abnd) and np.array_equal(got.branch_len, want.branch_len))
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_samples", [(2, 37), (3, 100), (3, 2)])
+def test_flat_nodes_of_sample_blocks_allgather_to_the_whole_table(world, n_samples):
+    """Input replication: every rank generates and flattens only its block of samples; after one
+    all-gather every rank holds exactly the flat nodes a single process computes for all of them."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_allgather, args=(r, world, port, n_samples, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(q.get(timeout=5) for _ in range(world))
