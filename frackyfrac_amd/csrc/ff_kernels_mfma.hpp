@@ -38,7 +38,12 @@ typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 typedef unsigned short mfma_u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int M_PAD_SLABS = 4;      // slabs of zero padding behind the staged arrays: the loop's prefetch runs past an item's end
+constexpr int M_WORDS_AHEAD = 4;    // slabs of presence words in flight (buffers of the kernel's loop)
+// Slabs of zero padding behind the staged arrays: the loop requests the words of slab t + 1 + M_WORDS_AHEAD
+// while it multiplies slab t, so an item that ends at the last slab reads M_WORDS_AHEAD + 1 slabs past it.
+// (With 4 -- one short -- a 32-slab problem faulted: the read past the allocation is 8 * n8 bytes.)
+constexpr int M_PAD_SLABS = 8;
+static_assert(M_PAD_SLABS > M_WORDS_AHEAD + 1, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
 constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time (128 bytes each: 64 KiB)
 
 // Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,

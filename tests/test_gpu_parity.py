@@ -333,7 +333,8 @@ def test_unweighted_mfma_five_digits_and_long_lengths():
     assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
 
 
-@pytest.mark.parametrize("ns,nl,dens", [(130, 20000, 0.02), (700, 17000, 0.01), (257, 33, 0.5), (1, 10, 0.5), (2, 40000, 0.001)])
+@pytest.mark.parametrize("ns,nl,dens", [(130, 20000, 0.02), (700, 17000, 0.01), (257, 33, 0.5), (1, 10, 0.5), (2, 40000, 0.001),
+                                        (300, 1000, 0.1)])  # 1000 leaves = 32 slabs: the deepest read past an item's end
 def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts(ns, nl, dens):
     """The matrix-core kernel keeps 512 slabs of digits in LDS at a time (20000 leaves = 625 slabs:
     two segments, the second of odd length), walks slabs in pairs with a tail, pads the sample
