@@ -684,8 +684,14 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     std::vector<int32_t> mptr;
     std::vector<int32_t> ptiles, pptr;
     const bool want_partials = env_int("FF_MFMA_PARTIALS", 1) != 0;
+    // Up to FF_MFMA_PRIVATE_MB of partial tiles (128 KiB each), every item gets its own: the kernel's
+    // copy-out is then aligned 512-byte rows into a contiguous tile (2.8 us a tile at C3) instead of 4-byte
+    // stores into rows of the triangle that start anywhere (12.8 us), and reduce_partials_kernel writes the
+    // distances straight from the sums -- no num[] round trip, no finish launch.
+    const int64_t private_tiles = (int64_t)env_int("FF_MFMA_PRIVATE_MB", 2048) * (1 << 20) / (M_TILE_I * M_TILE_J * 4);
     const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr,
-                                                 want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr);
+                                                 want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr,
+                                                 private_tiles);
     if (!pptr.empty()) {
         pl->n_ptiles = (int)pptr.size() - 1;
         FF_HIP(hipMalloc(&pl->d_partial, sizeof(uint32_t) * (size_t)pptr.back() * M_TILE_I * M_TILE_J));
@@ -857,7 +863,7 @@ int compact_branches(StageCtx &x, char *err, size_t errlen)
 int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
-    // presence bits (slab-major 64-bit words) and per-branch digits, zero padded to whole tiles and slabs
+    // presence bits (64-bit words, pairs of slabs major) and per-branch digits, zero padded to whole tiles and quads of slabs
     pl->mfma = true;
     inf.kernel = FF_KERNEL_MFMA_I8;
     inf.lengths_exact = q.lengths_exact;
@@ -869,7 +875,7 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
     pl->m_digits = digits;
     inf.n_digits = digits;
     const int64_t n8 = round_up(N, M_TILE_I);
-    const int64_t ldb = round_up(R, M_KSLAB);  // whole slabs
+    const int64_t ldb = round_up(std::max<int64_t>(R, 1), M_KSLAB * M_QUAD_SLABS);  // whole quads of slabs
     const int64_t n_slabs = ldb / M_KSLAB;
     pl->m_ldb = ldb;
     pl->m_n8 = n8;
@@ -1188,10 +1194,11 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             none.out = nullptr;  // null: the kernels leave integer sums in num[]
             if (pl->n_mitems > 0)
                 kern<<<dim3((unsigned)pl->n_mgroups), dim3(M_THREADS), pl->lds_bytes, st>>>(
-                    reinterpret_cast<const uint2 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
+                    reinterpret_cast<const uint4 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, fused ? fin : none);
+            if (timed) FF_HIP(hipEventRecord(ev1, st));  // the timed region is the pair kernel alone
             if (pl->n_ptiles > 0)
-                reduce_partials_kernel<<<dim3(M_TILE_I * M_TILE_J / 256, (unsigned)pl->n_ptiles), dim3(256), 0, st>>>(
+                reduce_partials_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
                     pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin,
                     fused ? fin : none);
         } else if (inf.n_items > 0 && pl->sparse)
@@ -1203,7 +1210,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
-        if (timed) FF_HIP(hipEventRecord(ev1, st));
+        if (timed && !pl->mfma) FF_HIP(hipEventRecord(ev1, st));
         if (!fused) {
             const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
             finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->n_planes, pl->plane_stride, fin, inf.slot_begin, n_slots);
@@ -1370,6 +1377,22 @@ int ff_plan_refined_pairs(ff_plan *pl, int64_t *queued, int64_t *capacity)
     *queued = (int64_t)n;
     return FF_OK;
 }
+
+#ifdef FF_MFMA_DIAG
+// Diagnostic build only.  First call (host_out == null): allocates the stamp array for n_workgroups
+// and arms the kernel.  Later calls copy the stamps out ([workgroup][4 items][8] 100 MHz ticks).
+int ff_debug_mfma_stamps(unsigned long long *host_out, int64_t n_workgroups)
+{
+    static unsigned long long *d = nullptr;
+    const size_t bytes = (size_t)n_workgroups * 4 * 8 * sizeof(unsigned long long);
+    if (!host_out) {
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) return FF_ERR_DEVICE;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_stamps), &d, sizeof(d)) == hipSuccess ? FF_OK : FF_ERR_DEVICE;
+    }
+    if (!d) return FF_ERR_ARG;
+    return hipMemcpy(host_out, d, bytes, hipMemcpyDeviceToHost) == hipSuccess ? FF_OK : FF_ERR_DEVICE;
+}
+#endif
 
 int ff_plan_audit(ff_plan *pl, int64_t *checked, int64_t *failed, double *max_rel_err)
 {

@@ -34,16 +34,19 @@
 // dword kk, byte q = branch 32*kt + 8*q + 4*h + kk of the slab, and the digit arrays are stored in
 // that order (chunk 2*kt + h, ff_device.hip stage_for_mfma).
 
+typedef unsigned short mfma_u16x2 __attribute__((ext_vector_type(2)));
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
-typedef unsigned short mfma_u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int M_WORDS_AHEAD = 4;    // slabs of presence words in flight (buffers of the kernel's loop)
-// Slabs of zero padding behind the staged arrays: the loop requests the words of slab t + 1 + M_WORDS_AHEAD
-// while it multiplies slab t, so an item that ends at the last slab reads M_WORDS_AHEAD + 1 slabs past it.
-// (With 4 -- one short -- a 32-slab problem faulted: the read past the allocation is 8 * n8 bytes.)
-constexpr int M_PAD_SLABS = 8;
-static_assert(M_PAD_SLABS > M_WORDS_AHEAD + 1, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
+// The presence words are staged in PAIRS of slabs -- Pbits[slab / 2][sample] = the sample's 64-bit words of
+// slabs 2p and 2p + 1 -- so that one 16-byte load per lane fetches two slabs; the kernel's loop keeps four
+// pairs in flight.  An item is a whole number of M_QUAD_SLABS slabs (the branch rows are zero padded to that)
+// and starts at a multiple of it.
+constexpr int M_QUAD_SLABS = 4;
+// Slabs of zero padding behind the staged arrays: the loop requests pair p + 4 when it is done with pair p,
+// and its prologue four pairs whatever the item's length: up to 8 slabs past an item's end are read.
+constexpr int M_PAD_SLABS = 12;
+static_assert(M_PAD_SLABS >= 8 && M_PAD_SLABS % 2 == 0, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
 constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time (128 bytes each: 64 KiB)
 
 // Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,
@@ -72,7 +75,8 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
         }
         __syncthreads();
         for (int64_t q = threadIdx.x; q < 1024 && win * 1024 + q < n_slabs; q += 256)
-            Pbits[(win * 1024 + q) * n8 + s] = (unsigned long long)bm[2 * q] | ((unsigned long long)bm[2 * q + 1] << 32);
+            Pbits[(((win * 1024 + q) >> 1) * n8 + s) * 2 + (q & 1)] =
+                (unsigned long long)bm[2 * q] | ((unsigned long long)bm[2 * q + 1] << 32);
         __syncthreads();
     }
     for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
@@ -108,9 +112,23 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
 // DIAG (builds with -DFF_MFMA_DIAG only; results are then WRONG, the time is what is asked for):
 // bit 1 drops the global loads inside the loop, bit 2 the expansion (vector work), bit 3 the
 // digit reads, bit 4 the MFMAs.
+#ifdef FF_MFMA_DIAG
+// Diagnostic build: the first thread of every workgroup stamps the phases of its first four items
+// with the 100 MHz real-time clock (tools/mfma_stamps.py): [workgroup][item][8].
+__device__ unsigned long long *g_mfma_stamps = nullptr;
+#define FF_STAMP(slot)                                                                                         \
+    if (g_mfma_stamps && tid == 0 && it - it_begin < 4)                                                        \
+    g_mfma_stamps[((int64_t)blockIdx.x * 4 + (it - it_begin)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+#define FF_STAMP_CLOCK(slot)                                                                                   \
+    if (g_mfma_stamps && tid == 0 && it - it_begin < 4)                                                        \
+    g_mfma_stamps[((int64_t)blockIdx.x * 4 + (it - it_begin)) * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define FF_STAMP(slot)
+#define FF_STAMP_CLOCK(slot)
+#endif
 template <bool ALL_PRIVATE, int DIAG = 0>
 __global__ __launch_bounds__(M_THREADS, 1)
-void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
+void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                              const int8_t *__restrict__ Kd, int64_t ldb, const MItem *__restrict__ items,
                              const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
                              uint32_t *__restrict__ num, uint32_t *__restrict__ partial, int64_t row_begin,
@@ -125,11 +143,13 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
     const int half = lane >> 5, sh = 4 * half;
     for (int it = it_begin; it < it_end; ++it) {
         const MItem item = items[it];
+        FF_STAMP(0);
         const int nd = item.nd;
         const int nslab = (item.k1 - item.k0) / M_KSLAB;
+        __builtin_assume(nslab >= M_QUAD_SLABS);  // (ff_schedule.cpp: whole quads of slabs, at least one)
         // this lane's samples: rows `lane` and 64 + `lane` of the wave's 128 i-samples, row `lane` of its 64 j-samples
-        const uint2 *pa = Pbits + (int64_t)(item.k0 / M_KSLAB) * n8 + item.i0 + wi * 128 + lane;
-        const uint2 *pb = Pbits + (int64_t)(item.k0 / M_KSLAB) * n8 + item.j0 + wj * 64 + lane;
+        const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + lane;
+        const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + lane;
         const int8_t *dig_src[2] = {Kd + (int64_t)item.d0 * ldb + item.k0,
                                     Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0};
         mfma_v16i acc[M_ND][4][2];
@@ -145,31 +165,46 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
             const int nseg = nslab - seg < M_TABLE_SLABS ? nslab - seg : M_TABLE_SLABS;
             // the segment's digits -> LDS: table[(slab * 2 + plane) * 64 + position]
             __syncthreads();  // (every wave is done with the previous table)
-            for (int c = tid; c < nseg * 8; c += M_THREADS) {  // 16-byte pieces: 4 per (slab, plane)
-                const int sp = c >> 2, piece = c & 3;
-                *(mfma_v4i *)(mfma_lds + sp * 64 + piece * 16) =
-                    *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
+            for (int c0 = tid; c0 < nseg * 8; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
+                mfma_v4i piece16[4];                                  // four loads in flight per thread
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u * M_THREADS, sp = c >> 2, piece = c & 3;
+                    if (c < nseg * 8)
+                        piece16[u] = *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u * M_THREADS;
+                    if (c < nseg * 8) *(mfma_v4i *)(mfma_lds + (c >> 2) * 64 + (c & 3) * 16) = piece16[u];
+                }
             }
             __syncthreads();
             const int8_t *tab = mfma_lds + half * 16;
             mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
             mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
-            uint2 wa0[4], wa1[4], wb[4];               // [slab & 3]: i-words of rows lane / 64 + lane, j-words
+            uint4 wa0[4], wa1[4], wb[4];               // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component
+                                                       // c = the 32 branches of k-step c of the pair
             uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
             uint32_t t[8];                             // its B masks in the making
             uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
+            // The loop's constant lives in a vector register the compiler cannot see through: beside an
+            // MFMA a vector instruction with a literal or scalar operand costs its SIMD about two cycles
+            // more than the all-register form (tools/microbench/mfma_i8_rate.hip).
+            uint32_t c01;
+            asm volatile("v_mov_b32 %0, 0x01010101" : "=v"(c01));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
-            const uint2 *qa = pa + (int64_t)seg * n8, *qb = pb + (int64_t)seg * n8;
+            const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {  // slabs 0..3 of the segment
+            for (int q = 0; q < 4; ++q) {  // pairs 0..3 of the segment
                 wa0[q] = qa[0];
                 wa1[q] = qa[64];
                 wb[q] = qb[0];
                 qa += n8;
                 qb += n8;
             }
-            auto load_words = [&](int buf) {  // the next slab not yet requested, into buffer `buf` (reads past the
+            auto load_words = [&](int buf) {  // the next pair not yet requested, into buffer `buf` (reads past the
                 if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
                     wa0[buf] = qa[0];
                     wa1[buf] = qa[64];
@@ -186,10 +221,10 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                     dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
                 }
             };
-            // the words in buffer `parity`, half `kt`, to where the fragments want them (3 swaps)
-            auto take_words = [&](int parity, int kt) {
-                const uint32_t w0 = kt ? wa0[parity].y : wa0[parity].x, w1 = kt ? wa1[parity].y : wa1[parity].x;
-                const uint32_t wy = kt ? wb[parity].y : wb[parity].x;
+            // component `c` of the words in buffer `buf` to where the fragments want them (3 swaps)
+            auto take_words = [&](int buf, int c) {
+                auto comp = [c](const uint4 &w) { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
+                const uint32_t w0 = comp(wa0[buf]), w1 = comp(wa1[buf]), wy = comp(wb[buf]);
                 if constexpr (!(DIAG & 4)) {
                     const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
@@ -213,7 +248,7 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
     __builtin_amdgcn_sched_barrier(0)
 #define FF_OP(stmt) if constexpr (!(DIAG & 4)) { stmt; }
 #define FF_END_PIECE() __builtin_amdgcn_sched_barrier(0)
-            // K-step `u` of the current group of four slabs (u = 0..7; slab sl + (u >> 1), kt = u & 1): the 16 MFMAs of
+            // K-step `u` of the current group of eight slabs (u = 0..15; slab sl + (u >> 1), pair u >> 2, component u & 3): the 16 MFMAs of
             // set `cur`, and behind them the 72 vector operations that build set `nxt` for k-step u + 1
             // -- per B dword pair: shift, and, byte mask, two ands with the digits; per A dword: shift,
             // and -- dealt out LEVEL BY LEVEL (all shifts, then all ands, ...), so that no instruction
@@ -221,7 +256,7 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
             // dependent chain behind.  The last slot swaps in the words of k-step u + 2.
             auto kstep = [&](int u, int sl) {
                 const int cur = u & 1, nxt = cur ^ 1;
-                const int bp2 = ((u + 2) >> 1) & 3, bkt2 = u & 1;  // buffer and half of k-step u + 2
+                const int bp2 = ((u + 2) >> 2) & 3, bkt2 = (u + 2) & 3;  // buffer and component of k-step u + 2
                 read_digits(cur, 2 * sl + u + 2);  // set `cur` is rebuilt in the NEXT k-step, for u + 2
                 __builtin_amdgcn_sched_barrier(0);
                 FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_OP(t[0] = swy[0] >> shk[0]); FF_OP(t[1] = swy[0] >> shk[1]); FF_OP(t[2] = swy[0] >> shk[2]); FF_OP(t[3] = swy[0] >> shk[3]); FF_END_PIECE();
@@ -267,34 +302,29 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                 }
             }
             take_words(0, 1);
-            load_words(0);  // slab 4
             __builtin_amdgcn_sched_barrier(0);
-            // Buffer b holds the words of the slab whose number is b mod 4.  The k-steps of slab t consume
-            // the words of slab t + 1 (they build ITS fragments); that buffer then takes slab t + 5: four
-            // slabs, about 5,000 cycles, between a load and its first use -- with one wave per SIMD a late
-            // load stalls the matrix pipe outright (two slabs of distance left 14 % of the wave's life
-            // in s_waitcnt).
+            if (seg == 0) { FF_STAMP(1); FF_STAMP_CLOCK(5); }
+            // Buffer b holds the words of the pair whose number is b mod 4.  K-step u takes the words of k-step
+            // u + 2, so pair p's last component is gone after its second k-step; when its fourth is done the
+            // buffer takes pair p + 4, whose first component is wanted eleven k-steps -- five and a half slabs,
+            // about 7,000 cycles -- later.  With one wave per SIMD a late load stalls the matrix pipe outright
+            // (single slabs requested two ahead left 14 % of the wave's life in s_waitcnt, four ahead 9 %),
+            // and a 16-byte load costs the wave's instruction stream what an 8-byte one does.
             int sl = 0;
-            for (; sl + 3 < nseg; sl += 4) {
+            for (; sl + 7 < nseg; sl += 8) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    kstep(2 * q, sl);
-                    kstep(2 * q + 1, sl);
-                    load_words((q + 1) & 3);
+                for (int p = 0; p < 4; ++p) {
+                    kstep(4 * p, sl);
+                    kstep(4 * p + 1, sl);
+                    kstep(4 * p + 2, sl);
+                    kstep(4 * p + 3, sl);
+                    load_words(p);
                 }
             }
-            // the last one to three slabs (what their k-steps build past the end is never used)
+            // a last quad of slabs (what its k-steps build past the end is never used)
             if (sl < nseg) {
-                kstep(0, sl);
-                kstep(1, sl);
-            }
-            if (sl + 1 < nseg) {
-                kstep(2, sl);
-                kstep(3, sl);
-            }
-            if (sl + 2 < nseg) {
-                kstep(4, sl);
-                kstep(5, sl);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kstep(u, sl);
             }
 #undef FF_MM
 #undef FF_OP
@@ -302,6 +332,8 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
         }
         // the last MFMAs (inline asm: the compiler inserts no wait) must have written the accumulators
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        FF_STAMP(2);
+        FF_STAMP_CLOCK(6);
         // Epilogue.  The 256 accumulator tiles of a lane sit in registers that only static code can name;
         // written out element by element with the shard / diagonal tests around each store that was
         // 9,000 instructions per item (instruction-cache misses made it cost more than the whole
@@ -319,79 +351,119 @@ void pair_common_mfma_kernel(const uint2 *__restrict__ Pbits, int64_t n8,
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        uint32_t common = (uint32_t)acc[0][m][n][r] << s0;
-                        if (nd > 1) common += (uint32_t)acc[1][m][n][r] << s1;
+                        // (explicit reads, next to their stores: left to the compiler, all 256 accumulators
+                        // are copied out of the AGPRs at the loop's exit, which spills -- and a kernel with
+                        // private memory pays for it at dispatch, see tools/microbench/launch_cost.hip)
+                        uint32_t lo, hi;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][r]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][r]));
+                        uint32_t common = lo << s0;
+                        if (nd > 1) common += hi << s1;
                         tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
                     }
         }
         __syncthreads();
+        FF_STAMP(3);
         {
             // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
             //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
             //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
             //        item);   = 0  into num[] by atomic add.
-            const uint2 *tile = (const uint2 *)mfma_lds;  // a lane takes columns 2 * lane, 2 * lane + 1
-            const int64_t j = item.j0 + 2 * lane;
-            uint32_t wj0 = 0u, wj1 = 0u;
-            if (item.first) {
-                wj0 = (uint32_t)W[j];
-                wj1 = (uint32_t)W[j + 1];
-            }
+            constexpr int NW = M_THREADS / 64;
             const bool priv = ALL_PRIVATE || item.pad > 0;
-            uint32_t *pt = partial + (int64_t)(priv ? item.pad - 1 : 0) * (M_TILE_I * M_TILE_J) + 2 * lane;
             // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
             // no trip waits for a load of its own
-            constexpr int NW = M_THREADS / 64;
             const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
+            if (priv) {  // a lane takes columns 2 * lane, 2 * lane + 1: aligned 8-byte stores
+                const uint2 *tile = (const uint2 *)mfma_lds;
+                const int64_t j = item.j0 + 2 * lane;
+                uint32_t wj0 = 0u, wj1 = 0u;
+                if (item.first) {
+                    wj0 = (uint32_t)W[j];
+                    wj1 = (uint32_t)W[j + 1];
+                }
+                uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + 2 * lane;
 #pragma unroll 4
-            for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
-                const int row = wave + NW * trip;
-                const int64_t i = item.i0 + row;
-                const uint2 c = tile[row * (M_TILE_J / 2) + lane];
-                const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
-                const uint32_t v0 = wi_ + wj0 - 2u * c.x, v1 = wi_ + wj1 - 2u * c.y;
-                if (priv) {
-                    *(uint2 *)(pt + row * M_TILE_J) = uint2{v0, v1};
-                } else if constexpr (!ALL_PRIVATE) {
+                for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                    const int row = wave + NW * trip;
+                    const uint2 c = tile[row * (M_TILE_J / 2) + lane];
+                    const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                    *(uint2 *)(pt + row * M_TILE_J) = uint2{wi_ + wj0 - 2u * c.x, wi_ + wj1 - 2u * c.y};
+                }
+            } else if constexpr (!ALL_PRIVATE) {
+                // a lane takes columns lane and 64 + lane: a row of num[] starts at slot i (i - 1) / 2, aligned
+                // to nothing, so the stores are 4 bytes each -- and a wave's 64 of them are contiguous
+                const uint32_t *tile = (const uint32_t *)mfma_lds;
+                const int64_t j = item.j0 + lane;
+                uint32_t wj0 = 0u, wj1 = 0u;
+                if (item.first) {
+                    wj0 = (uint32_t)W[j];
+                    wj1 = (uint32_t)W[j + 64];
+                }
+#pragma unroll 4
+                for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                    const int row = wave + NW * trip;
+                    const int64_t i = item.i0 + row;  // (wave-uniform, like everything derived from it)
+                    const uint32_t c0 = tile[row * M_TILE_J + lane], c1 = tile[row * M_TILE_J + 64 + lane];
+                    const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                    const uint32_t v0 = wi_ + wj0 - 2u * c0, v1 = wi_ + wj1 - 2u * c1;
                     if (i < row_begin || i >= row_end) continue;
                     const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
                     if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
                         if (j < i) finish_pair(fin, t0, i, j, v0);
-                        if (j + 1 < i) finish_pair(fin, t0 + 1, i, j + 1, v1);
+                        if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
                         continue;
                     }
                     uint32_t *dst = num + t0;
                     if (item.pad < 0) {
-                        if (j + 1 < i) {
-                            // (a row's slots start at i (i - 1) / 2: 8-byte aligned only for some i)
-                            dst[0] = v0;
-                            dst[1] = v1;
-                        } else if (j < i) dst[0] = v0;
+                        if (j < i) dst[0] = v0;
+                        if (j + 64 < i) dst[64] = v1;
                     } else {
                         if (j < i && v0) atomicAdd(dst, v0);
-                        if (j + 1 < i && v1) atomicAdd(dst + 1, v1);
+                        if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
                     }
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores and atomics of this item
+        FF_STAMP(4);
     }
 }
 
+#undef FF_STAMP
+#undef FF_STAMP_CLOCK
+
 // Sums the private partial tiles of a small problem: tile t = (tiles[2t], tiles[2t+1]) owns the
-// partials tile_ptr[t] .. tile_ptr[t+1]; one thread per pair of the tile.
-__global__ void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t *__restrict__ tiles,
-                                       const int32_t *__restrict__ tile_ptr, uint32_t *__restrict__ num,
-                                       int64_t row_begin, int64_t row_end, int64_t slot_begin,
-                                       const FinishArgs fin)  // fin.out != null: distances, not sums
+// partials tile_ptr[t] .. tile_ptr[t+1]; one thread per four consecutive pairs of a row (16-byte
+// loads, several partials in flight per thread).
+constexpr int M_REDUCE_THREADS = 256;
+constexpr int M_REDUCE_BLOCKS = M_TILE_I * M_TILE_J / 4 / M_REDUCE_THREADS;
+__global__ __launch_bounds__(M_REDUCE_THREADS)
+void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t *__restrict__ tiles,
+                            const int32_t *__restrict__ tile_ptr, uint32_t *__restrict__ num,
+                            int64_t row_begin, int64_t row_end, int64_t slot_begin,
+                            const FinishArgs fin)  // fin.out != null: distances, not sums
 {
     const int t = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // lr * M_TILE_J + lc
+    const int idx = (blockIdx.x * M_REDUCE_THREADS + threadIdx.x) * 4;  // lr * M_TILE_J + lc, lc a multiple of 4
     const int64_t i = tiles[2 * t] + idx / M_TILE_J, j = tiles[2 * t + 1] + idx % M_TILE_J;
     if (i < row_begin || i >= row_end || j >= i) return;
-    uint32_t s = 0;
-    for (int p = tile_ptr[t]; p < tile_ptr[t + 1]; ++p) s += partial[(int64_t)p * (M_TILE_I * M_TILE_J) + idx];
+    uint4 s = {0u, 0u, 0u, 0u};
+    const int p0 = tile_ptr[t], p1 = tile_ptr[t + 1];
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) {
+        const uint4 v = *(const uint4 *)(partial + (int64_t)p * (M_TILE_I * M_TILE_J) + idx);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
     const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
-    if (fin.out) finish_pair(fin, slot, i, j, s);
-    else num[slot] = s;
+    const uint32_t sums[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (j + e < i) {
+            if (fin.out) finish_pair(fin, slot + e, i, j + e, sums[e]);
+            else num[slot + e] = sums[e];
+        }
 }

@@ -200,7 +200,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
 
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
-                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr)
+                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr,
+                            int64_t max_private_tiles)
 {
     // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
     // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
@@ -226,13 +227,18 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     // slab ranges so that every workgroup ends at the same time.
     const int groups = (digits + M_ND - 1) / M_ND;
     const int64_t units = (int64_t)groups * (int64_t)tiles.size();
+    // The branch sweep is cut at multiples of M_QUAD_SLABS slabs (the kernel's loop works in quads; the
+    // engine pads the staged rows to whole quads): from here on `slabs` counts quads, and make_item
+    // turns quads back into branches.
+    const int64_t true_slabs = slabs;
+    slabs = (slabs + M_QUAD_SLABS - 1) / M_QUAD_SLABS;
     auto make_item = [&](int64_t unit, int64_t s0, int64_t s1) {
         const int64_t grp = unit / (int64_t)tiles.size(), t = unit % (int64_t)tiles.size();
         MItem itm{};
         itm.i0 = tiles[(size_t)t].i0;
         itm.j0 = tiles[(size_t)t].j0;
-        itm.k0 = (int32_t)(s0 * M_KSLAB);
-        itm.k1 = (int32_t)(s1 * M_KSLAB);
+        itm.k0 = (int32_t)(s0 * M_QUAD_SLABS * M_KSLAB);
+        itm.k1 = (int32_t)(std::min(true_slabs, s1 * M_QUAD_SLABS) * M_KSLAB);
         itm.d0 = (int32_t)(M_ND * grp);
         itm.nd = std::min(M_ND, digits - M_ND * (int)grp);
         itm.first = (grp == 0 && s0 == 0) ? 1 : 0;
@@ -240,15 +246,19 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     };
     std::vector<std::vector<MItem>> per((size_t)G);
     const int64_t rounds = units / G;
+    const int64_t rem_units = units - rounds * G;
     const int per_xcd = std::max(1, G / 8);
+    // (with one digit group a unit is a tile; the remainder makes at most G + rem_units ranges)
+    const bool all_private = partial_tiles && partial_ptr && groups == 1 && rounds > 0 &&
+                             rounds * G + (rem_units ? G + rem_units : 0) <= max_private_tiles;
     for (int64_t r = 0; r < rounds; ++r)
         for (int g = 0; g < G; ++g) {
             const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
             MItem itm = make_item(r * G + local, 0, slabs);
-            if (partial_tiles && partial_ptr && groups == 1) itm.pad = -1;
+            if (all_private) itm.pad = (int32_t)(r * G + local) + 1;  // unit u of a main round: ordinal u
+            else if (partial_tiles && partial_ptr && groups == 1) itm.pad = -1;
             per[(size_t)g].push_back(itm);
         }
-    const int64_t rem_units = units - rounds * G;
     // Device-scope atomics across XCDs are performed at the memory side and are slow (a problem
     // too small for even one round, all remainder, spent two thirds of its kernel in them).  With
     // one digit group a tile of a main round has a single item, which stores plainly
@@ -258,28 +268,66 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     int32_t ordinal = 0;
     if (partial_tiles) partial_tiles->clear();
     if (partial_ptr) partial_ptr->clear();
+    // partial_ptr / partial_tiles list the tiles that own partials: with all_private every tile, the
+    // main rounds' first; else the remainder's alone.  first_listed = the unit of entry 0.
+    const int64_t first_listed = all_private ? 0 : rounds * G;
+    if (all_private)
+        for (int64_t u = 0; u < rounds * G; ++u) {
+            partial_ptr->push_back(ordinal++);
+            partial_tiles->push_back(tiles[(size_t)u].i0);
+            partial_tiles->push_back(tiles[(size_t)u].j0);
+        }
+    auto add_range = [&](int g, int64_t unit, int64_t s0, int64_t s1) {
+        MItem itm = make_item(rounds * G + unit, s0, s1);
+        if (private_partials) {
+            // ranges are created in ascending (unit, slab) order: a unit's ordinals are contiguous
+            while ((int64_t)partial_ptr->size() <= rounds * G - first_listed + unit) {
+                const size_t t = (size_t)((first_listed + (int64_t)partial_ptr->size()) % (int64_t)tiles.size());
+                partial_ptr->push_back(ordinal);
+                partial_tiles->push_back(tiles[t].i0);
+                partial_tiles->push_back(tiles[t].j0);
+            }
+            itm.pad = ++ordinal;
+        }
+        per[(size_t)g].push_back(itm);
+    };
     if (rem_units > 0) {
+        // Two ways to cut rem_units x slabs over G workgroups.  Stream-K: equal shares; a share that
+        // straddles a unit boundary becomes two items, and an item costs its workgroup a prologue and
+        // an epilogue -- about M_ITEM_OVERHEAD_SLABS slabs' worth -- on top of its slabs.  Aligned:
+        // unit u gets G / rem_units workgroups (the first G % rem_units units one more), which cut it
+        // evenly; nothing straddles, but the ranges of a unit with fewer workgroups are longer.  The
+        // cut whose slowest workgroup finishes first is taken.
         const int64_t total = rem_units * slabs;
         const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
+        int64_t cost_stream = 0;
         for (int g = 0; g < G; ++g) {
-            int64_t a2 = (int64_t)g * share;
-            const int64_t b2 = std::min(total, a2 + share);
-            while (a2 < b2) {
-                const int64_t unit = a2 / slabs, s0 = a2 % slabs;
-                const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
-                MItem itm = make_item(rounds * G + unit, s0, s1);
-                if (private_partials) {
-                    // ranges are created in ascending (unit, slab) order: a unit's ordinals are contiguous
-                    while ((int64_t)partial_ptr->size() <= unit) {
-                        const size_t t = (size_t)((rounds * G + (int64_t)partial_ptr->size()) % (int64_t)tiles.size());
-                        partial_ptr->push_back(ordinal);
-                        partial_tiles->push_back(tiles[t].i0);
-                        partial_tiles->push_back(tiles[t].j0);
-                    }
-                    itm.pad = ++ordinal;
+            const int64_t a2 = (int64_t)g * share, b2 = std::min(total, a2 + share);
+            if (a2 >= b2) break;
+            const int64_t n_items = (b2 - 1) / slabs - a2 / slabs + 1;
+            cost_stream = std::max(cost_stream, (b2 - a2) + (n_items - 1) * (M_ITEM_OVERHEAD_SLABS / M_QUAD_SLABS));
+        }
+        const int64_t w_min = G / rem_units;  // >= 1: the remainder has fewer units than workgroups
+        const int64_t cost_aligned = (slabs + w_min - 1) / w_min;
+        if (cost_aligned <= cost_stream) {
+            int g = 0;
+            for (int64_t unit = 0; unit < rem_units; ++unit) {
+                const int64_t w = w_min + (unit < G % rem_units ? 1 : 0);
+                for (int64_t q = 0; q < w; ++q, ++g) {
+                    const int64_t s0 = slabs * q / w, s1 = slabs * (q + 1) / w;
+                    if (s0 < s1) add_range(g, unit, s0, s1);
                 }
-                per[(size_t)g].push_back(itm);
-                a2 += s1 - s0;
+            }
+        } else {
+            for (int g = 0; g < G; ++g) {
+                int64_t a2 = (int64_t)g * share;
+                const int64_t b2 = std::min(total, a2 + share);
+                while (a2 < b2) {
+                    const int64_t unit = a2 / slabs, s0 = a2 % slabs;
+                    const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
+                    add_range(g, unit, s0, s1);
+                    a2 += s1 - s0;
+                }
             }
         }
     }

@@ -43,9 +43,13 @@ constexpr int M_TILE_J = 128;  //   4 waves (2 x 2) of 128 x 64, i.e. 4 x 2 MFMA
 constexpr int M_THREADS = 256; // one wave per SIMD (256 accumulator registers per lane)
 constexpr int M_WGS_PER_CU = 1;
 constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps) = bits of a presence word
+constexpr int M_QUAD_SLABS = 4; // an item of pair_common_mfma_kernel is a whole number of these, and starts at one
 constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
 constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB, ff_kernels_mfma.hpp
                                                       // M_TABLE_SLABS), then the epilogue's 256 x 128 tile of 32-bit sums
+// what one more item costs a workgroup of pair_common_mfma_kernel, in slabs of its loop (measured:
+// about 10 us of prologue, accumulator write-out and copy-out against 0.63 us per two-digit slab)
+constexpr int64_t M_ITEM_OVERHEAD_SLABS = 16;  // (a multiple of M_QUAD_SLABS)
 
 // One unit of work: a 256 x 128 tile over the branch slabs [k0, k1) for the digit planes
 // d0 .. d0+nd-1.  Every item adds its share of U = W_i + W_j - 2*common to num[]
@@ -75,9 +79,13 @@ int waves_per_wg();
 // Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
 // partial_tiles / partial_ptr (may be null): filled when the ranges get private partial tiles
 // (MItem.pad = ordinal + 1): (i0, j0) per tile and, per tile, its first ordinal (+ the total).
+// max_private_tiles: when the whole schedule needs no more partial tiles than this, the items of the
+// main rounds get one each as well (every item then stores aligned 512-byte rows and the reduce
+// kernel writes the results); otherwise only the remainder's ranges do.
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
-                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr);
+                            std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr,
+                            int64_t max_private_tiles = 0);
 
 }  // namespace sched
 }  // namespace ff

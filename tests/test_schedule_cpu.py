@@ -135,3 +135,23 @@ def test_mfma_schedule_covers_pairs_slabs_and_digits_once(n, slabs, n_cu, digits
         if len(items):
             per = np.array([sum(int(it[3] - it[2]) for it in items[ptr[g]:ptr[g + 1]]) for g in range(len(ptr) - 1)])
             assert per.max() - per[per > 0].min() <= 64 * max(1, slabs) if world == 1 else True
+
+
+def test_mfma_remainder_is_cut_along_unit_boundaries_when_that_is_faster():
+    """C3's shape: 272 tiles on 256 workgroups = one round and 16 remainder tiles of 316 slabs (79 quads;
+    items are whole quads of slabs).  Equal stream-K shares of 5 quads would straddle tile boundaries in
+    15 workgroups (three items = one more prologue and epilogue, about 16 slabs' worth); 16 workgroups
+    per tile do not."""
+    items, ptr, n_tiles = schedule(2, 4096, 316, 0, 4096, 256, digits=2)
+    assert n_tiles == 272
+    per = [items[ptr[g]:ptr[g + 1]] for g in range(256)]
+    assert max(len(x) for x in per) == 2
+    rem = [int(x[1][3] - x[1][2]) // 64 for x in per if len(x) == 2]
+    assert len(rem) == 256 and set(rem) <= {16, 20}
+    assert all(int(it[2]) % 256 == 0 for it in items)            # every item starts at a quad
+    # few units on many workgroups, uneven division: stream-K shares stay (an aligned cut would leave
+    # some units with half the workgroups of others)
+    items, ptr, n_tiles = schedule(2, 4096, 316, 0, 4096, 200, digits=2)
+    per = np.array([sum(int(it[3] - it[2]) for it in items[ptr[g]:ptr[g + 1]]) for g in range(200)])
+    assert np.median(per) == per.max() and (per < per.max()).sum() <= 4   # equal shares, the last few shorter
+    assert all(int(it[2]) % 256 == 0 for it in items)

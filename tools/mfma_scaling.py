@@ -1,7 +1,7 @@
-"""Fixed cost vs per-slab cost of the unweighted MFMA path: times one pass (pair kernel + partial
-reduction, HIP events of ff_plan_run_timed) at a fixed sample count for several tree sizes; the
+"""Fixed cost vs per-slab cost of the unweighted MFMA path: times the pair kernel (HIP events
+of ff_plan_run_timed) at a fixed sample count for several tree sizes; the
 slope over the slab count is the loop, the intercept everything else (launch, digit table,
-epilogues, reduce_partials_kernel).    python tools/mfma_scaling.py [n_samples]"""
+epilogues).    python tools/mfma_scaling.py [n_samples]"""
 import os
 import sys
 
