@@ -1197,7 +1197,11 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                     reinterpret_cast<const uint4 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, fused ? fin : none);
             if (timed) FF_HIP(hipEventRecord(ev1, st));  // the timed region is the pair kernel alone
-            if (pl->n_ptiles > 0)
+            if (pl->n_ptiles > 0 && pl->m_all_private)
+                reduce_private_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
+                    pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_W, pl->d_num, inf.row_begin, inf.row_end,
+                    inf.slot_begin, fused ? fin : none);
+            else if (pl->n_ptiles > 0)
                 reduce_partials_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
                     pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin,
                     fused ? fin : none);

@@ -163,6 +163,19 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                     for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
         for (int seg = 0; seg < nslab; seg += M_TABLE_SLABS) {
             const int nseg = nslab - seg < M_TABLE_SLABS ? nslab - seg : M_TABLE_SLABS;
+            // the words of the segment's first four pairs are requested before anything else: their latency
+            // passes while the digit table is copied
+            uint4 wa0[4], wa1[4], wb[4];  // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component c =
+                                          // the 32 branches of k-step c of the pair
+            const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wa0[q] = qa[0];
+                wa1[q] = qa[64];
+                wb[q] = qb[0];
+                qa += n8;
+                qb += n8;
+            }
             // the segment's digits -> LDS: table[(slab * 2 + plane) * 64 + position]
             __syncthreads();  // (every wave is done with the previous table)
             for (int c0 = tid; c0 < nseg * 8; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
@@ -183,8 +196,6 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
             const int8_t *tab = mfma_lds + half * 16;
             mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
             mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
-            uint4 wa0[4], wa1[4], wb[4];               // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component
-                                                       // c = the 32 branches of k-step c of the pair
             uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
             uint32_t t[8];                             // its B masks in the making
             uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
@@ -195,15 +206,6 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
             asm volatile("v_mov_b32 %0, 0x01010101" : "=v"(c01));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
-            const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {  // pairs 0..3 of the segment
-                wa0[q] = qa[0];
-                wa1[q] = qa[64];
-                wb[q] = qb[0];
-                qa += n8;
-                qb += n8;
-            }
             auto load_words = [&](int buf) {  // the next pair not yet requested, into buffer `buf` (reads past the
                 if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
                     wa0[buf] = qa[0];
@@ -341,86 +343,113 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         // table is dead by now), and a short rolled loop, one row per wave and trip, applies the
         // tests and writes whole 512-byte rows.
         // D[row][col] of an MFMA tile: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31.
-        __syncthreads();  // every wave is done with the digit table
-        {
-            uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
+        if constexpr (ALL_PRIVATE) {
+            // Every item owns a partial tile, and nobody but reduce_private_kernel reads it: it is written in
+            // the order the accumulators have in the registers -- [wave][m][n][r >> 2][lane][r & 3], 16-byte
+            // stores, a contiguous KiB per instruction -- without a detour through LDS, and W_i + W_j is the
+            // reduce kernel's business.
+            uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + wave * (M_TILE_I * M_TILE_J / 4) + lane * 4;
             const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // (explicit reads, next to their stores: left to the compiler, all 256 accumulators
-                        // are copied out of the AGPRs at the loop's exit, which spills -- and a kernel with
-                        // private memory pays for it at dispatch, see tools/microbench/launch_cost.hip)
-                        uint32_t lo, hi;
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][r]));
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][r]));
-                        uint32_t common = lo << s0;
-                        if (nd > 1) common += hi << s1;
-                        tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
+                    for (int g = 0; g < 4; ++g) {
+                        uint32_t v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t lo, hi;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][4 * g + e]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][4 * g + e]));
+                            v[e] = lo << s0;
+                            if (nd > 1) v[e] += hi << s1;
+                        }
+                        *(uint4 *)(pt + ((m * 2 + n) * 4 + g) * 256) = uint4{v[0], v[1], v[2], v[3]};
                     }
-        }
-        __syncthreads();
-        FF_STAMP(3);
-        {
-            // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
-            //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
-            //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
-            //        item);   = 0  into num[] by atomic add.
-            constexpr int NW = M_THREADS / 64;
-            const bool priv = ALL_PRIVATE || item.pad > 0;
-            // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
-            // no trip waits for a load of its own
-            const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
-            if (priv) {  // a lane takes columns 2 * lane, 2 * lane + 1: aligned 8-byte stores
-                const uint2 *tile = (const uint2 *)mfma_lds;
-                const int64_t j = item.j0 + 2 * lane;
-                uint32_t wj0 = 0u, wj1 = 0u;
-                if (item.first) {
-                    wj0 = (uint32_t)W[j];
-                    wj1 = (uint32_t)W[j + 1];
-                }
-                uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + 2 * lane;
-#pragma unroll 4
-                for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
-                    const int row = wave + NW * trip;
-                    const uint2 c = tile[row * (M_TILE_J / 2) + lane];
-                    const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
-                    *(uint2 *)(pt + row * M_TILE_J) = uint2{wi_ + wj0 - 2u * c.x, wi_ + wj1 - 2u * c.y};
-                }
-            } else if constexpr (!ALL_PRIVATE) {
-                // a lane takes columns lane and 64 + lane: a row of num[] starts at slot i (i - 1) / 2, aligned
-                // to nothing, so the stores are 4 bytes each -- and a wave's 64 of them are contiguous
-                const uint32_t *tile = (const uint32_t *)mfma_lds;
-                const int64_t j = item.j0 + lane;
-                uint32_t wj0 = 0u, wj1 = 0u;
-                if (item.first) {
-                    wj0 = (uint32_t)W[j];
-                    wj1 = (uint32_t)W[j + 64];
-                }
-#pragma unroll 4
-                for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
-                    const int row = wave + NW * trip;
-                    const int64_t i = item.i0 + row;  // (wave-uniform, like everything derived from it)
-                    const uint32_t c0 = tile[row * M_TILE_J + lane], c1 = tile[row * M_TILE_J + 64 + lane];
-                    const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
-                    const uint32_t v0 = wi_ + wj0 - 2u * c0, v1 = wi_ + wj1 - 2u * c1;
-                    if (i < row_begin || i >= row_end) continue;
-                    const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
-                    if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
-                        if (j < i) finish_pair(fin, t0, i, j, v0);
-                        if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
-                        continue;
+            FF_STAMP(3);
+        } else {
+            __syncthreads();  // every wave is done with the digit table
+            {
+                uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
+                const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+    #pragma unroll
+                for (int m = 0; m < 4; ++m)
+    #pragma unroll
+                    for (int n = 0; n < 2; ++n)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            // (explicit reads, next to their stores: left to the compiler, all 256 accumulators
+                            // are copied out of the AGPRs at the loop's exit, which spills -- and a kernel with
+                            // private memory pays for it at dispatch, see tools/microbench/launch_cost.hip)
+                            uint32_t lo, hi;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][r]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][r]));
+                            uint32_t common = lo << s0;
+                            if (nd > 1) common += hi << s1;
+                            tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
+                        }
+            }
+            __syncthreads();
+            FF_STAMP(3);
+            {
+                // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
+                //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
+                //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
+                //        item);   = 0  into num[] by atomic add.
+                constexpr int NW = M_THREADS / 64;
+                const bool priv = item.pad > 0;
+                // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
+                // no trip waits for a load of its own
+                const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
+                if (priv) {  // a lane takes columns 2 * lane, 2 * lane + 1: aligned 8-byte stores
+                    const uint2 *tile = (const uint2 *)mfma_lds;
+                    const int64_t j = item.j0 + 2 * lane;
+                    uint32_t wj0 = 0u, wj1 = 0u;
+                    if (item.first) {
+                        wj0 = (uint32_t)W[j];
+                        wj1 = (uint32_t)W[j + 1];
                     }
-                    uint32_t *dst = num + t0;
-                    if (item.pad < 0) {
-                        if (j < i) dst[0] = v0;
-                        if (j + 64 < i) dst[64] = v1;
-                    } else {
-                        if (j < i && v0) atomicAdd(dst, v0);
-                        if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
+                    uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + 2 * lane;
+    #pragma unroll 4
+                    for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                        const int row = wave + NW * trip;
+                        const uint2 c = tile[row * (M_TILE_J / 2) + lane];
+                        const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                        *(uint2 *)(pt + row * M_TILE_J) = uint2{wi_ + wj0 - 2u * c.x, wi_ + wj1 - 2u * c.y};
+                    }
+                } else {
+                    // a lane takes columns lane and 64 + lane: a row of num[] starts at slot i (i - 1) / 2, aligned
+                    // to nothing, so the stores are 4 bytes each -- and a wave's 64 of them are contiguous
+                    const uint32_t *tile = (const uint32_t *)mfma_lds;
+                    const int64_t j = item.j0 + lane;
+                    uint32_t wj0 = 0u, wj1 = 0u;
+                    if (item.first) {
+                        wj0 = (uint32_t)W[j];
+                        wj1 = (uint32_t)W[j + 64];
+                    }
+    #pragma unroll 4
+                    for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                        const int row = wave + NW * trip;
+                        const int64_t i = item.i0 + row;  // (wave-uniform, like everything derived from it)
+                        const uint32_t c0 = tile[row * M_TILE_J + lane], c1 = tile[row * M_TILE_J + 64 + lane];
+                        const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                        const uint32_t v0 = wi_ + wj0 - 2u * c0, v1 = wi_ + wj1 - 2u * c1;
+                        if (i < row_begin || i >= row_end) continue;
+                        const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
+                        if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
+                            if (j < i) finish_pair(fin, t0, i, j, v0);
+                            if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
+                            continue;
+                        }
+                        uint32_t *dst = num + t0;
+                        if (item.pad < 0) {
+                            if (j < i) dst[0] = v0;
+                            if (j + 64 < i) dst[64] = v1;
+                        } else {
+                            if (j < i && v0) atomicAdd(dst, v0);
+                            if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
+                        }
                     }
                 }
             }
@@ -467,3 +496,42 @@ void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t 
             else num[slot + e] = sums[e];
         }
 }
+
+// The same for a schedule whose every item has a private tile in the accumulators' own order
+// (pair_common_mfma_kernel<true>): thread q of a tile takes the 16 bytes at 4 q of each of its partials
+// -- rows row0 .. row0 + 3 of one column -- and adds W_i + W_j, which those items leave out.
+__global__ __launch_bounds__(M_REDUCE_THREADS)
+void reduce_private_kernel(const uint32_t *__restrict__ partial, const int32_t *__restrict__ tiles,
+                           const int32_t *__restrict__ tile_ptr, const unsigned long long *__restrict__ W,
+                           uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end, int64_t slot_begin,
+                           const FinishArgs fin)  // fin.out != null: distances, not sums
+{
+    const int t = blockIdx.y;
+    const int q = blockIdx.x * M_REDUCE_THREADS + threadIdx.x;
+    const int lane = q & 63, g = (q >> 6) & 3, n = (q >> 8) & 1, m = (q >> 9) & 3, wave = q >> 11;
+    const int row0 = (wave >> 1) * 128 + m * 32 + 8 * g + 4 * (lane >> 5), col = (wave & 1) * 64 + n * 32 + (lane & 31);
+    const int64_t i0 = tiles[2 * t] + row0, j = tiles[2 * t + 1] + col;
+    if (i0 + 3 < row_begin || i0 >= row_end || j >= i0 + 3) return;
+    uint4 s = {0u, 0u, 0u, 0u};
+    const int p0 = tile_ptr[t], p1 = tile_ptr[t + 1];
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) {
+        const uint4 v = *(const uint4 *)(partial + (int64_t)p * (M_TILE_I * M_TILE_J) + 4 * q);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
+    const uint32_t sums[4] = {s.x, s.y, s.z, s.w};
+    const uint32_t wj = (uint32_t)W[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = i0 + e;
+        if (i < row_begin || i >= row_end || j >= i) continue;
+        const uint32_t u = (uint32_t)W[i] + wj - 2u * sums[e];
+        const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
+        if (fin.out) finish_pair(fin, slot, i, j, u);
+        else num[slot] = u;
+    }
+}
+

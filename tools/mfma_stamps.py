@@ -1,5 +1,5 @@
 """Phase timeline of pair_common_mfma_kernel: every workgroup stamps item start / loop start /
-loop end / LDS tile written / item end with the 100 MHz real-time clock.  Diagnostic build only:
+loop end / accumulators written / item end with the 100 MHz real-time clock.  Diagnostic build only:
 
     make -C frackyfrac_amd/csrc diag
     FF_LIB_PATH=frackyfrac_amd/lib/libfrackyfrac_amd_diag.so python tools/mfma_stamps.py [C3|C2|NxL] [DIAG]
@@ -50,7 +50,7 @@ first = st[:, 0, 0]
 print("first item start: min %.1f  median %.1f  max %.1f us after the earliest" % (us(first.min()), us(np.median(first)), us(first.max())))
 ends = st[:, :, 4].max(axis=1)
 print("workgroup end:    min %.1f  median %.1f  max %.1f us" % (us(ends.min()), us(np.median(ends)), us(ends.max())))
-names = ["prologue (table, first words, set 0)", "loop", "accumulators -> LDS tile", "copy-out"]
+names = ["prologue (table, first words, set 0)", "loop", "accumulators -> partial tile (or LDS tile)", "drain (or copy-out from LDS)"]
 for k in range(4):
     have = st[:, k, 0] > 0
     if not have.any():
