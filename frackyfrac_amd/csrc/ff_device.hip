@@ -230,7 +230,9 @@ struct Quant {
     std::string why_not;
 };
 
-Quant choose_quant(const DeviceCsr &c, bool weighted)
+// (d_indptr, d_ids, d_len: the flat nodes and treeDists on the device -- the plan owns them by now)
+Quant choose_quant(const DeviceCsr &c, bool weighted, const int64_t *d_indptr, const int32_t *d_ids, const double *d_abnd,
+                   const double *d_len)
 {
     Quant q;
     const int64_t B = c.B, N = c.N;
@@ -269,12 +271,12 @@ Quant choose_quant(const DeviceCsr &c, bool weighted)
         q.fixed_ok = true;
         return q;
     }
-    // unweighted: smallest e making every length an integer, if the total still fits
-    double total = 0;
+    // unweighted: smallest e making every length an integer, if every sample's sum still fits
+    double lmax = 0;
     int e_exact = -2000;
     for (int64_t b = 0; b < B; ++b) {
         const double l = c.h_len[(size_t)b];
-        total += l;
+        lmax = std::max(lmax, l);
         if (l == 0) continue;
         int ex;
         const double m = std::frexp(l, &ex);  // l = m * 2^ex, 0.5 <= m < 1
@@ -284,19 +286,47 @@ Quant choose_quant(const DeviceCsr &c, bool weighted)
         e_exact = std::max(e_exact, -lowbit);
     }
     q.klen.assign((size_t)B, 0);
-    if (total == 0) {
+    // What has to stay below 2^31 is a SAMPLE's sum of integer lengths (U = W_i + W_j - 2 common), not the
+    // tree's: a sample reaches a fraction of the tree, and the bits this leaves go to the resolution.
+    // (Scaled by the tree's total, C3's shape with inexact lengths kept so few bits per pair that most
+    // pairs failed the refinement rule and went to the binary64 walk: 55 ms a pass instead of 0.5.)
+    double wl = 0;  // max over samples of sum_b l_b over the sample's flat nodes
+    int64_t nnz_max = 0;
+    if (N > 0 && c.nnz > 0) {
+        double *d_w = nullptr;
+        std::vector<double> hw((size_t)N);
+        bool ok = hipMalloc(&d_w, sizeof(double) * (size_t)N) == hipSuccess;
+        if (ok) {
+            exact_weight_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, 0, d_w);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpy(hw.data(), d_w, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        (void)hipFree(d_w);
+        if (!ok) {
+            q.why_not = "device error while summing the samples' branch lengths";
+            return q;
+        }
+        for (int64_t s = 0; s < N; ++s) {
+            wl = std::max(wl, hw[(size_t)s]);
+            nnz_max = std::max(nnz_max, c.h_indptr[(size_t)s + 1] - c.h_indptr[(size_t)s]);
+        }
+    }
+    if (wl == 0) {  // no sample has a branch of positive length: every distance is 0/0
         q.fixed_ok = true;
         q.e = 0;
         q.lengths_exact = 1;
         return q;
     }
-    if (e_exact > -2000 && e_exact < 1000 && std::ldexp(total, e_exact) <= LIMIT - 2.0) {
+    if (e_exact > -2000 && e_exact < 1000 && std::ldexp(std::max(wl, lmax), e_exact) <= LIMIT - 2.0) {
         q.e = e_exact;
         q.lengths_exact = 1;
     } else {
-        int ex;
-        std::frexp((LIMIT - (double)B - 2.0) / total, &ex);
-        q.e = ex - 1;
+        // every sample's sum (each length rounded up by less than 1) below 2^31, every length below 2^28:
+        // four base-128 digits = two sweeps of the matrix-core kernel, which three digits cost as well
+        int ex, ex2;
+        std::frexp((LIMIT - (double)nnz_max - 2.0) / wl, &ex);
+        std::frexp((268435456.0 - 2.0) / lmax, &ex2);
+        q.e = std::min(ex, ex2) - 1;
         q.lengths_exact = 0;
     }
     // the branch's shared rounding offset (ff_dither.hpp); an exact length is its own integer
@@ -1075,7 +1105,7 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)R <= 4294967296.0)
         prec = FF_PRECISION_EXACT64;
     if (prec != FF_PRECISION_EXACT64) {
-        q = choose_quant(*c, weighted);
+        q = choose_quant(*c, weighted, pl->d_indptr, pl->d_ids, pl->d_abnd, pl->d_len);
         if (!q.fixed_ok) {
             if (prec == FF_PRECISION_FIXED32)
                 return ff::fail(FF_ERR_ARG, err, errlen, "FIXED32 not applicable: %s", q.why_not.c_str());

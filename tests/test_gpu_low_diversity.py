@@ -120,6 +120,32 @@ def test_fixed32_unweighted_few_distinct_lengths(mfma, monkeypatch):
     plan.close()
 
 
+def test_fixed32_unweighted_inexact_lengths_keep_their_bits():
+    """Branch lengths of a real phylogeny (not short binary fractions): the integer lengths are scaled by
+    the largest SAMPLE's sum, not the tree's.  Scaled by the tree's total, a sample that reaches a tenth of
+    the tree kept 28 of the 31 bits, most pairs failed the refinement rule and the pass was the binary64
+    walk (55 ms at C3's shape instead of 0.5).  Here: within 1e-6 of unifracDistUnweighted
+    (unifrac.go:144-171), and only a handful of pairs go to the walk."""
+    tree, ptr, idx, val = synth.make(300, 4000, 0.1, 11)
+    rng = np.random.default_rng(3)
+    tree.branch_len[:] = tree.branch_len * (1.0 + 1e-3 * rng.random(tree.branch_len.shape[0]))
+    tree.branch_len[0] = 0.0
+    nodes, ip, on, ft = both_sides(tree, ptr, idx, val, False)
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=4)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.lengths_exact == 0 and plan.info.kernel == 2 and plan.info.n_digits >= 3
+    got = plan.run_host()
+    assert rel_err(got, want).max() <= WEIGHTED_RTOL
+    queued, cap = plan.refined_pairs()
+    assert queued <= len(want) // 50
+    # the largest sample's integer sum uses the top bit of the 31 it may
+    sums = np.array([np.asarray(ft.dist)[on["id"][ip[s]:ip[s + 1]]].sum() for s in range(300)])
+    assert 2.0 ** 30 <= sums.max() * 2.0 ** plan.info.scale_log2 < 2.0 ** 31
+    n, bad, worst = plan.audit()
+    assert bad == 0
+    plan.close()
+
+
 def test_disjoint_samples_are_at_distance_exactly_one():
     """Samples that share no branch but the root (length 0): numer == denom term by term, so the
     reference returns exactly 1 (unifrac.go:204); FIXED32 must too, although its denominator

@@ -1,0 +1,36 @@
+"""Unweighted FIXED32 with branch lengths that are NOT short dyadic fractions (any real phylogeny):
+the integer lengths then take the whole 31-bit budget, three to five base-128 digits instead of
+C3's two.  Times the pass for C3's shape with the generator's lengths and with perturbed ones.
+    python tools/mfma_digits.py [n_samples] [n_leaves]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import frackyfrac_amd as ff  # noqa: E402
+from frackyfrac_amd import synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+tree, ptr, idx, val = synth.make(n, leaves, 0.1, synth.CONFIGS["C3"]["seed"])
+rng = np.random.default_rng(5)
+for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e-3 u), u uniform"):
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        plan.run(out.data_ptr())
+    torch.cuda.synchronize()
+    plan.timing_collect()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        plan.run(out.data_ptr(), timed=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms, k = plan.timing_collect()
+    print("%-44s digits %d  items %d  pair kernel %.4f ms  pass %.4f ms" % (
+        label, plan.info.n_digits, plan.info.n_items, ms / k, e0.elapsed_time(e1) / 20), flush=True)
+    tree.branch_len = tree.branch_len * (1.0 + 1e-3 * rng.random(tree.branch_len.shape[0]))
