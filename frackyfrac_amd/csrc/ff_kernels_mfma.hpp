@@ -152,308 +152,320 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + lane;
         const int8_t *dig_src[2] = {Kd + (int64_t)item.d0 * ldb + item.k0,
                                     Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0};
-        mfma_v16i acc[M_ND][4][2];
+        // An item with a single digit plane (the last group of an odd number of digits) runs without the
+        // second plane's MFMAs, digit reads and masks.  The whole item -- accumulators, loop, way out -- is
+        // instantiated once per case: a branch inside the loop nest would join the two cases' accumulators,
+        // and the compiler resolves such a join of 256 AGPR-pinned values through private memory.
+        auto run_item = [&](auto two_planes) {
+            mfma_v16i acc[M_ND][4][2];
 #pragma unroll
-        for (int d = 0; d < M_ND; ++d)
+            for (int d = 0; d < M_ND; ++d)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
-        for (int seg = 0; seg < nslab; seg += M_TABLE_SLABS) {
-            const int nseg = nslab - seg < M_TABLE_SLABS ? nslab - seg : M_TABLE_SLABS;
-            // the words of the segment's first four pairs are requested before anything else: their latency
-            // passes while the digit table is copied
-            uint4 wa0[4], wa1[4], wb[4];  // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component c =
-                                          // the 32 branches of k-step c of the pair
-            const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
+                        for (int r = 0; r < 16; ++r) acc[d][m][n][r] = 0;
+            for (int seg = 0; seg < nslab; seg += M_TABLE_SLABS) {
+                const int nseg = nslab - seg < M_TABLE_SLABS ? nslab - seg : M_TABLE_SLABS;
+                // the words of the segment's first four pairs are requested before anything else: their latency
+                // passes while the digit table is copied
+                uint4 wa0[4], wa1[4], wb[4];  // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component c =
+                                              // the 32 branches of k-step c of the pair
+                const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wa0[q] = qa[0];
-                wa1[q] = qa[64];
-                wb[q] = qb[0];
-                qa += n8;
-                qb += n8;
-            }
-            // the segment's digits -> LDS: table[(slab * 2 + plane) * 64 + position]
-            __syncthreads();  // (every wave is done with the previous table)
-            for (int c0 = tid; c0 < nseg * 8; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
-                mfma_v4i piece16[4];                                  // four loads in flight per thread
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = c0 + u * M_THREADS, sp = c >> 2, piece = c & 3;
-                    if (c < nseg * 8)
-                        piece16[u] = *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
+                for (int q = 0; q < 4; ++q) {
+                    wa0[q] = qa[0];
+                    wa1[q] = qa[64];
+                    wb[q] = qb[0];
+                    qa += n8;
+                    qb += n8;
                 }
+                // the segment's digits -> LDS: table[(slab * 2 + plane) * 64 + position]
+                __syncthreads();  // (every wave is done with the previous table)
+                for (int c0 = tid; c0 < nseg * 8; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
+                    mfma_v4i piece16[4];                                  // four loads in flight per thread
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = c0 + u * M_THREADS;
-                    if (c < nseg * 8) *(mfma_v4i *)(mfma_lds + (c >> 2) * 64 + (c & 3) * 16) = piece16[u];
-                }
-            }
-            __syncthreads();
-            const int8_t *tab = mfma_lds + half * 16;
-            mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
-            mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
-            uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
-            uint32_t t[8];                             // its B masks in the making
-            uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
-            // The loop's constant lives in a vector register the compiler cannot see through: beside an
-            // MFMA a vector instruction with a literal or scalar operand costs its SIMD about two cycles
-            // more than the all-register form (tools/microbench/mfma_i8_rate.hip).
-            uint32_t c01;
-            asm volatile("v_mov_b32 %0, 0x01010101" : "=v"(c01));
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
-            auto load_words = [&](int buf) {  // the next pair not yet requested, into buffer `buf` (reads past the
-                if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
-                    wa0[buf] = qa[0];
-                    wa1[buf] = qa[64];
-                    wb[buf] = qb[0];
-                }
-                qa += n8;
-                qb += n8;
-            };
-            auto read_digits = [&](int set, int kstep) {  // kstep = 2 * slab + kt, within the segment
-                if constexpr (!(DIAG & 8)) {
-                    dg0[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64);
-                    dg1[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64 + 64);
-                } else {
-                    dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
-                }
-            };
-            // component `c` of the words in buffer `buf` to where the fragments want them (3 swaps)
-            auto take_words = [&](int buf, int c) {
-                auto comp = [c](const uint4 &w) { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
-                const uint32_t w0 = comp(wa0[buf]), w1 = comp(wa1[buf]), wy = comp(wb[buf]);
-                if constexpr (!(DIAG & 4)) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
-                    const auto sy = __builtin_amdgcn_permlane32_swap(wy, wy, false, false);
-                    swx[0] = s0[0]; swx[1] = s0[1]; swx[2] = s1[0]; swx[3] = s1[1];
-                    swy[0] = sy[0]; swy[1] = sy[1];
-                } else {
-                    swx[0] = w0; swx[1] = w1; swx[2] = w0 ^ 1; swx[3] = w1 ^ 1;
-                    swy[0] = wy; swy[1] = wy ^ 1;
-                }
-            };
-            // bytes 0/1 -> 0x00/0xFF: each 16-bit half (b0 + 256 b1) * 255 = 0x00FF b0 + 0xFF00 b1
-            auto ff_bytemask = [](uint32_t one) {
-                const mfma_u16x2 m16 = __builtin_bit_cast(mfma_u16x2, one) * (unsigned short)0x00FF;
-                return __builtin_bit_cast(uint32_t, m16);
-            };
-#define FF_MM(d, m, n, A, B)                                                                       \
-    if constexpr (!(DIAG & 16))                                                                    \
-        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[d][m][n]) : "v"(A), "v"(B)); \
-    else acc[d][m][n][0] += A[0] ^ B[0];                                                           \
-    __builtin_amdgcn_sched_barrier(0)
-#define FF_OP(stmt) if constexpr (!(DIAG & 4)) { stmt; }
-#define FF_END_PIECE() __builtin_amdgcn_sched_barrier(0)
-            // K-step `u` of the current group of eight slabs (u = 0..15; slab sl + (u >> 1), pair u >> 2, component u & 3): the 16 MFMAs of
-            // set `cur`, and behind them the 72 vector operations that build set `nxt` for k-step u + 1
-            // -- per B dword pair: shift, and, byte mask, two ands with the digits; per A dword: shift,
-            // and -- dealt out LEVEL BY LEVEL (all shifts, then all ands, ...), so that no instruction
-            // waits for the one in front of it: a wave alone on its SIMD has nobody to hide a
-            // dependent chain behind.  The last slot swaps in the words of k-step u + 2.
-            auto kstep = [&](int u, int sl) {
-                const int cur = u & 1, nxt = cur ^ 1;
-                const int bp2 = ((u + 2) >> 2) & 3, bkt2 = (u + 2) & 3;  // buffer and component of k-step u + 2
-                read_digits(cur, 2 * sl + u + 2);  // set `cur` is rebuilt in the NEXT k-step, for u + 2
-                __builtin_amdgcn_sched_barrier(0);
-                FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_OP(t[0] = swy[0] >> shk[0]); FF_OP(t[1] = swy[0] >> shk[1]); FF_OP(t[2] = swy[0] >> shk[2]); FF_OP(t[3] = swy[0] >> shk[3]); FF_END_PIECE();
-                FF_MM(1, 0, 0, fa[cur][0], fb1[cur][0]); FF_OP(t[4] = swy[1] >> shk[0]); FF_OP(t[5] = swy[1] >> shk[1]); FF_OP(t[6] = swy[1] >> shk[2]); FF_OP(t[7] = swy[1] >> shk[3]); FF_OP(t[0] &= 0x01010101u); FF_END_PIECE();
-                FF_MM(0, 0, 1, fa[cur][0], fb0[cur][1]); FF_OP(t[1] &= 0x01010101u); FF_OP(t[2] &= 0x01010101u); FF_OP(t[3] &= 0x01010101u); FF_OP(t[4] &= 0x01010101u); FF_OP(t[5] &= 0x01010101u); FF_END_PIECE();
-                FF_MM(1, 0, 1, fa[cur][0], fb1[cur][1]); FF_OP(t[6] &= 0x01010101u); FF_OP(t[7] &= 0x01010101u); FF_OP(t[0] = ff_bytemask(t[0])); FF_OP(t[1] = ff_bytemask(t[1])); FF_OP(t[2] = ff_bytemask(t[2])); FF_END_PIECE();
-                FF_MM(0, 1, 0, fa[cur][1], fb0[cur][0]); FF_OP(t[3] = ff_bytemask(t[3])); FF_OP(t[4] = ff_bytemask(t[4])); FF_OP(t[5] = ff_bytemask(t[5])); FF_OP(t[6] = ff_bytemask(t[6])); FF_OP(t[7] = ff_bytemask(t[7])); FF_END_PIECE();
-                FF_MM(1, 1, 0, fa[cur][1], fb1[cur][0]); FF_OP(fb0[nxt][0][0] = (int)((uint32_t)dg0[nxt][0] & t[0])); FF_OP(fb1[nxt][0][0] = (int)((uint32_t)dg1[nxt][0] & t[0])); FF_OP(fb0[nxt][0][1] = (int)((uint32_t)dg0[nxt][1] & t[1])); FF_OP(fb1[nxt][0][1] = (int)((uint32_t)dg1[nxt][1] & t[1])); FF_END_PIECE();
-                FF_MM(0, 1, 1, fa[cur][1], fb0[cur][1]); FF_OP(fb0[nxt][0][2] = (int)((uint32_t)dg0[nxt][2] & t[2])); FF_OP(fb1[nxt][0][2] = (int)((uint32_t)dg1[nxt][2] & t[2])); FF_OP(fb0[nxt][0][3] = (int)((uint32_t)dg0[nxt][3] & t[3])); FF_OP(fb1[nxt][0][3] = (int)((uint32_t)dg1[nxt][3] & t[3])); FF_OP(fb0[nxt][1][0] = (int)((uint32_t)dg0[nxt][0] & t[4])); FF_END_PIECE();
-                FF_MM(1, 1, 1, fa[cur][1], fb1[cur][1]); FF_OP(fb1[nxt][1][0] = (int)((uint32_t)dg1[nxt][0] & t[4])); FF_OP(fb0[nxt][1][1] = (int)((uint32_t)dg0[nxt][1] & t[5])); FF_OP(fb1[nxt][1][1] = (int)((uint32_t)dg1[nxt][1] & t[5])); FF_OP(fb0[nxt][1][2] = (int)((uint32_t)dg0[nxt][2] & t[6])); FF_OP(fb1[nxt][1][2] = (int)((uint32_t)dg1[nxt][2] & t[6])); FF_END_PIECE();
-                FF_MM(0, 2, 0, fa[cur][2], fb0[cur][0]); FF_OP(fb0[nxt][1][3] = (int)((uint32_t)dg0[nxt][3] & t[7])); FF_OP(fb1[nxt][1][3] = (int)((uint32_t)dg1[nxt][3] & t[7])); FF_OP(fa[nxt][0][0] = (int)(swx[0] >> shk[0])); FF_OP(fa[nxt][0][1] = (int)(swx[0] >> shk[1])); FF_OP(fa[nxt][0][2] = (int)(swx[0] >> shk[2])); FF_END_PIECE();
-                FF_MM(1, 2, 0, fa[cur][2], fb1[cur][0]); FF_OP(fa[nxt][0][3] = (int)(swx[0] >> shk[3])); FF_OP(fa[nxt][1][0] = (int)(swx[1] >> shk[0])); FF_OP(fa[nxt][1][1] = (int)(swx[1] >> shk[1])); FF_OP(fa[nxt][1][2] = (int)(swx[1] >> shk[2])); FF_OP(fa[nxt][1][3] = (int)(swx[1] >> shk[3])); FF_END_PIECE();
-                FF_MM(0, 2, 1, fa[cur][2], fb0[cur][1]); FF_OP(fa[nxt][2][0] = (int)(swx[2] >> shk[0])); FF_OP(fa[nxt][2][1] = (int)(swx[2] >> shk[1])); FF_OP(fa[nxt][2][2] = (int)(swx[2] >> shk[2])); FF_OP(fa[nxt][2][3] = (int)(swx[2] >> shk[3])); FF_END_PIECE();
-                FF_MM(1, 2, 1, fa[cur][2], fb1[cur][1]); FF_OP(fa[nxt][3][0] = (int)(swx[3] >> shk[0])); FF_OP(fa[nxt][3][1] = (int)(swx[3] >> shk[1])); FF_OP(fa[nxt][3][2] = (int)(swx[3] >> shk[2])); FF_OP(fa[nxt][3][3] = (int)(swx[3] >> shk[3])); FF_OP(fa[nxt][0][0] &= 0x01010101); FF_END_PIECE();
-                FF_MM(0, 3, 0, fa[cur][3], fb0[cur][0]); FF_OP(fa[nxt][0][1] &= 0x01010101); FF_OP(fa[nxt][0][2] &= 0x01010101); FF_OP(fa[nxt][0][3] &= 0x01010101); FF_OP(fa[nxt][1][0] &= 0x01010101); FF_OP(fa[nxt][1][1] &= 0x01010101); FF_END_PIECE();
-                FF_MM(1, 3, 0, fa[cur][3], fb1[cur][0]); FF_OP(fa[nxt][1][2] &= 0x01010101); FF_OP(fa[nxt][1][3] &= 0x01010101); FF_OP(fa[nxt][2][0] &= 0x01010101); FF_OP(fa[nxt][2][1] &= 0x01010101); FF_OP(fa[nxt][2][2] &= 0x01010101); FF_END_PIECE();
-                FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_OP(fa[nxt][2][3] &= 0x01010101); FF_OP(fa[nxt][3][0] &= 0x01010101); FF_OP(fa[nxt][3][1] &= 0x01010101); FF_OP(fa[nxt][3][2] &= 0x01010101); FF_OP(fa[nxt][3][3] &= 0x01010101); FF_END_PIECE();
-                FF_MM(1, 3, 1, fa[cur][3], fb1[cur][1]); take_words(bp2, bkt2); FF_END_PIECE();
-            };
-            // prologue: digits of k-steps 0 and 1, fragment set 0 for k-step 0, the words of k-step 1
-            read_digits(0, 0);
-            read_digits(1, 1);
-            take_words(0, 0);
-            if constexpr (!(DIAG & 4)) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const uint32_t mask = ff_bytemask((swy[n] >> shk[kk]) & 0x01010101u);
-                        fb0[0][n][kk] = (int)((uint32_t)dg0[0][kk] & mask);
-                        fb1[0][n][kk] = (int)((uint32_t)dg1[0][kk] & mask);
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u * M_THREADS, sp = c >> 2, piece = c & 3;
+                        if (c < nseg * 8)
+                            piece16[u] = *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
                     }
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)((swx[m] >> shk[kk]) & 0x01010101u);
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u * M_THREADS;
+                        if (c < nseg * 8) *(mfma_v4i *)(mfma_lds + (c >> 2) * 64 + (c & 3) * 16) = piece16[u];
+                    }
                 }
-            } else {
+                __syncthreads();
+                const int8_t *tab = mfma_lds + half * 16;
+                mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
+                mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
+                uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
+                uint32_t t[8];                             // its B masks in the making
+                uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
+                auto load_words = [&](int buf) {  // the next pair not yet requested, into buffer `buf` (reads past the
+                    if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
+                        wa0[buf] = qa[0];
+                        wa1[buf] = qa[64];
+                        wb[buf] = qb[0];
+                    }
+                    qa += n8;
+                    qb += n8;
+                };
+                auto read_digits = [&](auto two_planes, int set, int kstep) {  // kstep = 2 * slab + kt, within the segment
+                    if constexpr (!(DIAG & 8)) {
+                        dg0[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64);
+                        if constexpr (decltype(two_planes)::value)
+                            dg1[set] = *(const mfma_v4i *)(tab + kstep * 32 + (kstep >> 1) * 64 + 64);
+                    } else {
+                        dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
+                    }
+                };
+                // component `c` of the words in buffer `buf` to where the fragments want them (3 swaps)
+                auto take_words = [&](int buf, int c) {
+                    auto comp = [c](const uint4 &w) { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
+                    const uint32_t w0 = comp(wa0[buf]), w1 = comp(wa1[buf]), wy = comp(wb[buf]);
+                    if constexpr (!(DIAG & 4)) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(wy, wy, false, false);
+                        swx[0] = s0[0]; swx[1] = s0[1]; swx[2] = s1[0]; swx[3] = s1[1];
+                        swy[0] = sy[0]; swy[1] = sy[1];
+                    } else {
+                        swx[0] = w0; swx[1] = w1; swx[2] = w0 ^ 1; swx[3] = w1 ^ 1;
+                        swy[0] = wy; swy[1] = wy ^ 1;
+                    }
+                };
+                // bytes 0/1 -> 0x00/0xFF: each 16-bit half (b0 + 256 b1) * 255 = 0x00FF b0 + 0xFF00 b1
+                auto ff_bytemask = [](uint32_t one) {
+                    const mfma_u16x2 m16 = __builtin_bit_cast(mfma_u16x2, one) * (unsigned short)0x00FF;
+                    return __builtin_bit_cast(uint32_t, m16);
+                };
+#define FF_MM(d, m, n, A, B)                                                                           \
+        if constexpr ((d) == 0 || TWO) {                                                                   \
+            if constexpr (!(DIAG & 16))                                                                    \
+                asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[d][m][n]) : "v"(A), "v"(B)); \
+            else acc[d][m][n][0] += A[0] ^ B[0];                                                           \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0)
+#define FF_OP(stmt) if constexpr (!(DIAG & 4)) { stmt; }
+#define FF_OP1(stmt) if constexpr (TWO && !(DIAG & 4)) { stmt; }  // (the second digit plane's)
+#define FF_END_PIECE() __builtin_amdgcn_sched_barrier(0)
+                // K-step `u` of the current group of eight slabs (u = 0..15; slab sl + (u >> 1), pair u >> 2, component u & 3): the 16 MFMAs of
+                // set `cur`, and behind them the 72 vector operations that build set `nxt` for k-step u + 1
+                // -- per B dword pair: shift, and, byte mask, two ands with the digits; per A dword: shift,
+                // and -- dealt out LEVEL BY LEVEL (all shifts, then all ands, ...), so that no instruction
+                // waits for the one in front of it: a wave alone on its SIMD has nobody to hide a
+                // dependent chain behind.  The last slot swaps in the words of k-step u + 2.
+                auto kstep = [&](auto two_planes, int u, int sl) {
+                    constexpr bool TWO = decltype(two_planes)::value;
+                    const int cur = u & 1, nxt = cur ^ 1;
+                    const int bp2 = ((u + 2) >> 2) & 3, bkt2 = (u + 2) & 3;  // buffer and component of k-step u + 2
+                    read_digits(two_planes, cur, 2 * sl + u + 2);  // set `cur` is rebuilt in the NEXT k-step, for u + 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_OP(t[0] = swy[0] >> shk[0]); FF_OP(t[1] = swy[0] >> shk[1]); FF_OP(t[2] = swy[0] >> shk[2]); FF_OP(t[3] = swy[0] >> shk[3]); FF_END_PIECE();
+                    FF_MM(1, 0, 0, fa[cur][0], fb1[cur][0]); FF_OP(t[4] = swy[1] >> shk[0]); FF_OP(t[5] = swy[1] >> shk[1]); FF_OP(t[6] = swy[1] >> shk[2]); FF_OP(t[7] = swy[1] >> shk[3]); FF_OP(t[0] &= 0x01010101u); FF_END_PIECE();
+                    FF_MM(0, 0, 1, fa[cur][0], fb0[cur][1]); FF_OP(t[1] &= 0x01010101u); FF_OP(t[2] &= 0x01010101u); FF_OP(t[3] &= 0x01010101u); FF_OP(t[4] &= 0x01010101u); FF_OP(t[5] &= 0x01010101u); FF_END_PIECE();
+                    FF_MM(1, 0, 1, fa[cur][0], fb1[cur][1]); FF_OP(t[6] &= 0x01010101u); FF_OP(t[7] &= 0x01010101u); FF_OP(t[0] = ff_bytemask(t[0])); FF_OP(t[1] = ff_bytemask(t[1])); FF_OP(t[2] = ff_bytemask(t[2])); FF_END_PIECE();
+                    FF_MM(0, 1, 0, fa[cur][1], fb0[cur][0]); FF_OP(t[3] = ff_bytemask(t[3])); FF_OP(t[4] = ff_bytemask(t[4])); FF_OP(t[5] = ff_bytemask(t[5])); FF_OP(t[6] = ff_bytemask(t[6])); FF_OP(t[7] = ff_bytemask(t[7])); FF_END_PIECE();
+                    FF_MM(1, 1, 0, fa[cur][1], fb1[cur][0]); FF_OP(fb0[nxt][0][0] = (int)((uint32_t)dg0[nxt][0] & t[0])); FF_OP1(fb1[nxt][0][0] = (int)((uint32_t)dg1[nxt][0] & t[0])); FF_OP(fb0[nxt][0][1] = (int)((uint32_t)dg0[nxt][1] & t[1])); FF_OP1(fb1[nxt][0][1] = (int)((uint32_t)dg1[nxt][1] & t[1])); FF_END_PIECE();
+                    FF_MM(0, 1, 1, fa[cur][1], fb0[cur][1]); FF_OP(fb0[nxt][0][2] = (int)((uint32_t)dg0[nxt][2] & t[2])); FF_OP1(fb1[nxt][0][2] = (int)((uint32_t)dg1[nxt][2] & t[2])); FF_OP(fb0[nxt][0][3] = (int)((uint32_t)dg0[nxt][3] & t[3])); FF_OP1(fb1[nxt][0][3] = (int)((uint32_t)dg1[nxt][3] & t[3])); FF_OP(fb0[nxt][1][0] = (int)((uint32_t)dg0[nxt][0] & t[4])); FF_END_PIECE();
+                    FF_MM(1, 1, 1, fa[cur][1], fb1[cur][1]); FF_OP1(fb1[nxt][1][0] = (int)((uint32_t)dg1[nxt][0] & t[4])); FF_OP(fb0[nxt][1][1] = (int)((uint32_t)dg0[nxt][1] & t[5])); FF_OP1(fb1[nxt][1][1] = (int)((uint32_t)dg1[nxt][1] & t[5])); FF_OP(fb0[nxt][1][2] = (int)((uint32_t)dg0[nxt][2] & t[6])); FF_OP1(fb1[nxt][1][2] = (int)((uint32_t)dg1[nxt][2] & t[6])); FF_END_PIECE();
+                    FF_MM(0, 2, 0, fa[cur][2], fb0[cur][0]); FF_OP(fb0[nxt][1][3] = (int)((uint32_t)dg0[nxt][3] & t[7])); FF_OP1(fb1[nxt][1][3] = (int)((uint32_t)dg1[nxt][3] & t[7])); FF_OP(fa[nxt][0][0] = (int)(swx[0] >> shk[0])); FF_OP(fa[nxt][0][1] = (int)(swx[0] >> shk[1])); FF_OP(fa[nxt][0][2] = (int)(swx[0] >> shk[2])); FF_END_PIECE();
+                    FF_MM(1, 2, 0, fa[cur][2], fb1[cur][0]); FF_OP(fa[nxt][0][3] = (int)(swx[0] >> shk[3])); FF_OP(fa[nxt][1][0] = (int)(swx[1] >> shk[0])); FF_OP(fa[nxt][1][1] = (int)(swx[1] >> shk[1])); FF_OP(fa[nxt][1][2] = (int)(swx[1] >> shk[2])); FF_OP(fa[nxt][1][3] = (int)(swx[1] >> shk[3])); FF_END_PIECE();
+                    FF_MM(0, 2, 1, fa[cur][2], fb0[cur][1]); FF_OP(fa[nxt][2][0] = (int)(swx[2] >> shk[0])); FF_OP(fa[nxt][2][1] = (int)(swx[2] >> shk[1])); FF_OP(fa[nxt][2][2] = (int)(swx[2] >> shk[2])); FF_OP(fa[nxt][2][3] = (int)(swx[2] >> shk[3])); FF_END_PIECE();
+                    FF_MM(1, 2, 1, fa[cur][2], fb1[cur][1]); FF_OP(fa[nxt][3][0] = (int)(swx[3] >> shk[0])); FF_OP(fa[nxt][3][1] = (int)(swx[3] >> shk[1])); FF_OP(fa[nxt][3][2] = (int)(swx[3] >> shk[2])); FF_OP(fa[nxt][3][3] = (int)(swx[3] >> shk[3])); FF_OP(fa[nxt][0][0] &= 0x01010101); FF_END_PIECE();
+                    FF_MM(0, 3, 0, fa[cur][3], fb0[cur][0]); FF_OP(fa[nxt][0][1] &= 0x01010101); FF_OP(fa[nxt][0][2] &= 0x01010101); FF_OP(fa[nxt][0][3] &= 0x01010101); FF_OP(fa[nxt][1][0] &= 0x01010101); FF_OP(fa[nxt][1][1] &= 0x01010101); FF_END_PIECE();
+                    FF_MM(1, 3, 0, fa[cur][3], fb1[cur][0]); FF_OP(fa[nxt][1][2] &= 0x01010101); FF_OP(fa[nxt][1][3] &= 0x01010101); FF_OP(fa[nxt][2][0] &= 0x01010101); FF_OP(fa[nxt][2][1] &= 0x01010101); FF_OP(fa[nxt][2][2] &= 0x01010101); FF_END_PIECE();
+                    FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_OP(fa[nxt][2][3] &= 0x01010101); FF_OP(fa[nxt][3][0] &= 0x01010101); FF_OP(fa[nxt][3][1] &= 0x01010101); FF_OP(fa[nxt][3][2] &= 0x01010101); FF_OP(fa[nxt][3][3] &= 0x01010101); FF_END_PIECE();
+                    FF_MM(1, 3, 1, fa[cur][3], fb1[cur][1]); take_words(bp2, bkt2); FF_END_PIECE();
+                };
+                // prologue: digits of k-steps 0 and 1, fragment set 0 for k-step 0, the words of k-step 1
+                read_digits(std::true_type{}, 0, 0);
+                read_digits(std::true_type{}, 1, 1);
+                take_words(0, 0);
+                if constexpr (!(DIAG & 4)) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) { fb0[0][n][kk] = dg0[0][kk]; fb1[0][n][kk] = dg1[0][kk]; }
+                    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)swx[m];
+                        for (int n = 0; n < 2; ++n) {
+                            const uint32_t mask = ff_bytemask((swy[n] >> shk[kk]) & 0x01010101u);
+                            fb0[0][n][kk] = (int)((uint32_t)dg0[0][kk] & mask);
+                            fb1[0][n][kk] = (int)((uint32_t)dg1[0][kk] & mask);
+                        }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)((swx[m] >> shk[kk]) & 0x01010101u);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) { fb0[0][n][kk] = dg0[0][kk]; fb1[0][n][kk] = dg1[0][kk]; }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)swx[m];
+                    }
                 }
-            }
-            take_words(0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (seg == 0) { FF_STAMP(1); FF_STAMP_CLOCK(5); }
-            // Buffer b holds the words of the pair whose number is b mod 4.  K-step u takes the words of k-step
-            // u + 2, so pair p's last component is gone after its second k-step; when its fourth is done the
-            // buffer takes pair p + 4, whose first component is wanted eleven k-steps -- five and a half slabs,
-            // about 7,000 cycles -- later.  With one wave per SIMD a late load stalls the matrix pipe outright
-            // (single slabs requested two ahead left 14 % of the wave's life in s_waitcnt, four ahead 9 %),
-            // and a 16-byte load costs the wave's instruction stream what an 8-byte one does.
-            int sl = 0;
-            for (; sl + 7 < nseg; sl += 8) {
+                take_words(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (seg == 0) { FF_STAMP(1); FF_STAMP_CLOCK(5); }
+                // Buffer b holds the words of the pair whose number is b mod 4.  K-step u takes the words of k-step
+                // u + 2, so pair p's last component is gone after its second k-step; when its fourth is done the
+                // buffer takes pair p + 4, whose first component is wanted eleven k-steps -- five and a half slabs,
+                // about 7,000 cycles -- later.  With one wave per SIMD a late load stalls the matrix pipe outright
+                // (single slabs requested two ahead left 14 % of the wave's life in s_waitcnt, four ahead 9 %),
+                // and a 16-byte load costs the wave's instruction stream what an 8-byte one does.
+                auto sweep = [&](auto two_planes) {
+                    int sl = 0;
+                    for (; sl + 7 < nseg; sl += 8) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    kstep(4 * p, sl);
-                    kstep(4 * p + 1, sl);
-                    kstep(4 * p + 2, sl);
-                    kstep(4 * p + 3, sl);
-                    load_words(p);
-                }
-            }
-            // a last quad of slabs (what its k-steps build past the end is never used)
-            if (sl < nseg) {
+                        for (int p = 0; p < 4; ++p) {
+                            kstep(two_planes, 4 * p, sl);
+                            kstep(two_planes, 4 * p + 1, sl);
+                            kstep(two_planes, 4 * p + 2, sl);
+                            kstep(two_planes, 4 * p + 3, sl);
+                            load_words(p);
+                        }
+                    }
+                    // a last quad of slabs (what its k-steps build past the end is never used)
+                    if (sl < nseg) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kstep(u, sl);
-            }
+                        for (int u = 0; u < 8; ++u) kstep(two_planes, u, sl);
+                    }
+                };
+                sweep(two_planes);
 #undef FF_MM
 #undef FF_OP
+#undef FF_OP1
 #undef FF_END_PIECE
-        }
-        // the last MFMAs (inline asm: the compiler inserts no wait) must have written the accumulators
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        FF_STAMP(2);
-        FF_STAMP_CLOCK(6);
-        // Epilogue.  The 256 accumulator tiles of a lane sit in registers that only static code can name;
-        // written out element by element with the shard / diagonal tests around each store that was
-        // 9,000 instructions per item (instruction-cache misses made it cost more than the whole
-        // loop).  Instead: common = sum of the planes goes to LDS as a plain 256 x 128 tile (the digit
-        // table is dead by now), and a short rolled loop, one row per wave and trip, applies the
-        // tests and writes whole 512-byte rows.
-        // D[row][col] of an MFMA tile: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31.
-        if constexpr (ALL_PRIVATE) {
-            // Every item owns a partial tile, and nobody but reduce_private_kernel reads it: it is written in
-            // the order the accumulators have in the registers -- [wave][m][n][r >> 2][lane][r & 3], 16-byte
-            // stores, a contiguous KiB per instruction -- without a detour through LDS, and W_i + W_j is the
-            // reduce kernel's business.
-            uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + wave * (M_TILE_I * M_TILE_J / 4) + lane * 4;
-            const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint32_t v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            uint32_t lo, hi;
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][4 * g + e]));
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][4 * g + e]));
-                            v[e] = lo << s0;
-                            if (nd > 1) v[e] += hi << s1;
-                        }
-                        *(uint4 *)(pt + ((m * 2 + n) * 4 + g) * 256) = uint4{v[0], v[1], v[2], v[3]};
-                    }
-            FF_STAMP(3);
-        } else {
-            __syncthreads();  // every wave is done with the digit table
-            {
-                uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
-                const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
-    #pragma unroll
-                for (int m = 0; m < 4; ++m)
-    #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-    #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            // (explicit reads, next to their stores: left to the compiler, all 256 accumulators
-                            // are copied out of the AGPRs at the loop's exit, which spills -- and a kernel with
-                            // private memory pays for it at dispatch, see tools/microbench/launch_cost.hip)
-                            uint32_t lo, hi;
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][r]));
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][r]));
-                            uint32_t common = lo << s0;
-                            if (nd > 1) common += hi << s1;
-                            tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
-                        }
             }
-            __syncthreads();
-            FF_STAMP(3);
-            {
-                // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
-                //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
-                //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
-                //        item);   = 0  into num[] by atomic add.
-                constexpr int NW = M_THREADS / 64;
-                const bool priv = item.pad > 0;
-                // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
-                // no trip waits for a load of its own
-                const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
-                if (priv) {  // a lane takes columns 2 * lane, 2 * lane + 1: aligned 8-byte stores
-                    const uint2 *tile = (const uint2 *)mfma_lds;
-                    const int64_t j = item.j0 + 2 * lane;
-                    uint32_t wj0 = 0u, wj1 = 0u;
-                    if (item.first) {
-                        wj0 = (uint32_t)W[j];
-                        wj1 = (uint32_t)W[j + 1];
-                    }
-                    uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + 2 * lane;
-    #pragma unroll 4
-                    for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
-                        const int row = wave + NW * trip;
-                        const uint2 c = tile[row * (M_TILE_J / 2) + lane];
-                        const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
-                        *(uint2 *)(pt + row * M_TILE_J) = uint2{wi_ + wj0 - 2u * c.x, wi_ + wj1 - 2u * c.y};
-                    }
-                } else {
-                    // a lane takes columns lane and 64 + lane: a row of num[] starts at slot i (i - 1) / 2, aligned
-                    // to nothing, so the stores are 4 bytes each -- and a wave's 64 of them are contiguous
-                    const uint32_t *tile = (const uint32_t *)mfma_lds;
-                    const int64_t j = item.j0 + lane;
-                    uint32_t wj0 = 0u, wj1 = 0u;
-                    if (item.first) {
-                        wj0 = (uint32_t)W[j];
-                        wj1 = (uint32_t)W[j + 64];
-                    }
-    #pragma unroll 4
-                    for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
-                        const int row = wave + NW * trip;
-                        const int64_t i = item.i0 + row;  // (wave-uniform, like everything derived from it)
-                        const uint32_t c0 = tile[row * M_TILE_J + lane], c1 = tile[row * M_TILE_J + 64 + lane];
-                        const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
-                        const uint32_t v0 = wi_ + wj0 - 2u * c0, v1 = wi_ + wj1 - 2u * c1;
-                        if (i < row_begin || i >= row_end) continue;
-                        const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
-                        if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
-                            if (j < i) finish_pair(fin, t0, i, j, v0);
-                            if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
-                            continue;
+            // the last MFMAs (inline asm: the compiler inserts no wait) must have written the accumulators
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            FF_STAMP(2);
+            FF_STAMP_CLOCK(6);
+            // Epilogue.  The 256 accumulator tiles of a lane sit in registers that only static code can name;
+            // written out element by element with the shard / diagonal tests around each store that was
+            // 9,000 instructions per item (instruction-cache misses made it cost more than the whole
+            // loop).  Instead: common = sum of the planes goes to LDS as a plain 256 x 128 tile (the digit
+            // table is dead by now), and a short rolled loop, one row per wave and trip, applies the
+            // tests and writes whole 512-byte rows.
+            // D[row][col] of an MFMA tile: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31.
+            if constexpr (ALL_PRIVATE) {
+                // Every item owns a partial tile, and nobody but reduce_private_kernel reads it: it is written in
+                // the order the accumulators have in the registers -- [wave][m][n][r >> 2][lane][r & 3], 16-byte
+                // stores, a contiguous KiB per instruction -- without a detour through LDS, and W_i + W_j is the
+                // reduce kernel's business.
+                uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + wave * (M_TILE_I * M_TILE_J / 4) + lane * 4;
+                const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            uint32_t v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                uint32_t lo, hi;
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][4 * g + e]));
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][4 * g + e]));
+                                v[e] = lo << s0;
+                                if (nd > 1) v[e] += hi << s1;
+                            }
+                            *(uint4 *)(pt + ((m * 2 + n) * 4 + g) * 256) = uint4{v[0], v[1], v[2], v[3]};
                         }
-                        uint32_t *dst = num + t0;
-                        if (item.pad < 0) {
-                            if (j < i) dst[0] = v0;
-                            if (j + 64 < i) dst[64] = v1;
-                        } else {
-                            if (j < i && v0) atomicAdd(dst, v0);
-                            if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
+                FF_STAMP(3);
+            } else {
+                __syncthreads();  // every wave is done with the digit table
+                {
+                    uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
+                    const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+        #pragma unroll
+                    for (int m = 0; m < 4; ++m)
+        #pragma unroll
+                        for (int n = 0; n < 2; ++n)
+        #pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                // (explicit reads, next to their stores: left to the compiler, all 256 accumulators
+                                // are copied out of the AGPRs at the loop's exit, which spills -- and a kernel with
+                                // private memory pays for it at dispatch, see tools/microbench/launch_cost.hip)
+                                uint32_t lo, hi;
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(acc[0][m][n][r]));
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(acc[1][m][n][r]));
+                                uint32_t common = lo << s0;
+                                if (nd > 1) common += hi << s1;
+                                tile[(m * 32 + (r & 3) + 8 * (r >> 2)) * M_TILE_J + 32 * n] = common;
+                            }
+                }
+                __syncthreads();
+                FF_STAMP(3);
+                {
+                    // This item's share of result = W_i + W_j - 2 * common (modulo 2^32) goes, by item.pad:
+                    //   > 0  to its private partial tile, every element, plain stores (reduce_partials_kernel
+                    //        applies the shard and diagonal masks);   < 0  plainly into num[] (the tile's only
+                    //        item);   = 0  into num[] by atomic add.
+                    constexpr int NW = M_THREADS / 64;
+                    const bool priv = item.pad > 0;
+                    // W_i of the 64 rows this wave writes (rows wave, wave + 4, ...): lane t holds trip t's, so that
+                    // no trip waits for a load of its own
+                    const uint32_t wrows = item.first ? (uint32_t)W[item.i0 + wave + NW * lane] : 0u;
+                    if (priv) {  // a lane takes columns 2 * lane, 2 * lane + 1: aligned 8-byte stores
+                        const uint2 *tile = (const uint2 *)mfma_lds;
+                        const int64_t j = item.j0 + 2 * lane;
+                        uint32_t wj0 = 0u, wj1 = 0u;
+                        if (item.first) {
+                            wj0 = (uint32_t)W[j];
+                            wj1 = (uint32_t)W[j + 1];
+                        }
+                        uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + 2 * lane;
+        #pragma unroll 4
+                        for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                            const int row = wave + NW * trip;
+                            const uint2 c = tile[row * (M_TILE_J / 2) + lane];
+                            const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                            *(uint2 *)(pt + row * M_TILE_J) = uint2{wi_ + wj0 - 2u * c.x, wi_ + wj1 - 2u * c.y};
+                        }
+                    } else {
+                        // a lane takes columns lane and 64 + lane: a row of num[] starts at slot i (i - 1) / 2, aligned
+                        // to nothing, so the stores are 4 bytes each -- and a wave's 64 of them are contiguous
+                        const uint32_t *tile = (const uint32_t *)mfma_lds;
+                        const int64_t j = item.j0 + lane;
+                        uint32_t wj0 = 0u, wj1 = 0u;
+                        if (item.first) {
+                            wj0 = (uint32_t)W[j];
+                            wj1 = (uint32_t)W[j + 64];
+                        }
+        #pragma unroll 4
+                        for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
+                            const int row = wave + NW * trip;
+                            const int64_t i = item.i0 + row;  // (wave-uniform, like everything derived from it)
+                            const uint32_t c0 = tile[row * M_TILE_J + lane], c1 = tile[row * M_TILE_J + 64 + lane];
+                            const uint32_t wi_ = (uint32_t)__builtin_amdgcn_readlane((int)wrows, trip);
+                            const uint32_t v0 = wi_ + wj0 - 2u * c0, v1 = wi_ + wj1 - 2u * c1;
+                            if (i < row_begin || i >= row_end) continue;
+                            const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
+                            if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
+                                if (j < i) finish_pair(fin, t0, i, j, v0);
+                                if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
+                                continue;
+                            }
+                            uint32_t *dst = num + t0;
+                            if (item.pad < 0) {
+                                if (j < i) dst[0] = v0;
+                                if (j + 64 < i) dst[64] = v1;
+                            } else {
+                                if (j < i && v0) atomicAdd(dst, v0);
+                                if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (nd > 1) run_item(std::true_type{});
+        else run_item(std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores and atomics of this item
         FF_STAMP(4);
     }

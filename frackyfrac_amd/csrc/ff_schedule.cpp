@@ -245,51 +245,38 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
         return itm;
     };
     std::vector<std::vector<MItem>> per((size_t)G);
+    std::vector<std::vector<int32_t>> per_tile((size_t)G);  // tile index of every item (for the ordinals below)
     const int64_t rounds = units / G;
     const int64_t rem_units = units - rounds * G;
     const int per_xcd = std::max(1, G / 8);
-    // (with one digit group a unit is a tile; the remainder makes at most G + rem_units ranges)
-    const bool all_private = partial_tiles && partial_ptr && groups == 1 && rounds > 0 &&
-                             rounds * G + (rem_units ? G + rem_units : 0) <= max_private_tiles;
+    // Device-scope atomics across XCDs are performed at the memory side and are slow (a problem
+    // too small for even one round, all remainder, spent two thirds of its kernel in them).  Ways
+    // out of the kernel, by MItem.pad:  p > 0 -- the item owns private partial tile p - 1, which a
+    // reduce kernel sums with the tile's others;  -1 -- the tile's only item stores plainly into
+    // num[];  0 -- adds into num[] atomically.
+    //   all_private: every item owns a tile (any number of digit groups; the whole schedule needs
+    //     no more than max_private_tiles of them -- at most G + rem_units ranges in the remainder);
+    //   else, one digit group: a main-round item is its tile's only one (-1), the remainder's
+    //     ranges own tiles;  else (several groups, over the budget): atomics throughout.
+    const bool can_list = partial_tiles && partial_ptr;
+    const bool all_private = can_list && rounds * G + (rem_units ? G + rem_units : 0) <= max_private_tiles;
+    const bool private_remainder = can_list && (all_private || groups == 1);
     for (int64_t r = 0; r < rounds; ++r)
         for (int g = 0; g < G; ++g) {
             const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
             MItem itm = make_item(r * G + local, 0, slabs);
-            if (all_private) itm.pad = (int32_t)(r * G + local) + 1;  // unit u of a main round: ordinal u
-            else if (partial_tiles && partial_ptr && groups == 1) itm.pad = -1;
+            if (all_private) itm.pad = 1;  // (a private tile: the ordinal comes below)
+            else if (can_list && groups == 1) itm.pad = -1;
             per[(size_t)g].push_back(itm);
+            per_tile[(size_t)g].push_back((int32_t)((r * G + local) % (int64_t)tiles.size()));
         }
-    // Device-scope atomics across XCDs are performed at the memory side and are slow (a problem
-    // too small for even one round, all remainder, spent two thirds of its kernel in them).  With
-    // one digit group a tile of a main round has a single item, which stores plainly
-    // (MItem.pad = -1); the ranges of the remainder get private partial tiles instead
-    // (MItem.pad = ordinal + 1), summed by a reduce kernel.
-    const bool private_partials = partial_tiles && partial_ptr && groups == 1;
-    int32_t ordinal = 0;
     if (partial_tiles) partial_tiles->clear();
     if (partial_ptr) partial_ptr->clear();
-    // partial_ptr / partial_tiles list the tiles that own partials: with all_private every tile, the
-    // main rounds' first; else the remainder's alone.  first_listed = the unit of entry 0.
-    const int64_t first_listed = all_private ? 0 : rounds * G;
-    if (all_private)
-        for (int64_t u = 0; u < rounds * G; ++u) {
-            partial_ptr->push_back(ordinal++);
-            partial_tiles->push_back(tiles[(size_t)u].i0);
-            partial_tiles->push_back(tiles[(size_t)u].j0);
-        }
     auto add_range = [&](int g, int64_t unit, int64_t s0, int64_t s1) {
         MItem itm = make_item(rounds * G + unit, s0, s1);
-        if (private_partials) {
-            // ranges are created in ascending (unit, slab) order: a unit's ordinals are contiguous
-            while ((int64_t)partial_ptr->size() <= rounds * G - first_listed + unit) {
-                const size_t t = (size_t)((first_listed + (int64_t)partial_ptr->size()) % (int64_t)tiles.size());
-                partial_ptr->push_back(ordinal);
-                partial_tiles->push_back(tiles[t].i0);
-                partial_tiles->push_back(tiles[t].j0);
-            }
-            itm.pad = ++ordinal;
-        }
+        if (private_remainder) itm.pad = 1;
         per[(size_t)g].push_back(itm);
+        per_tile[(size_t)g].push_back((int32_t)((rounds * G + unit) % (int64_t)tiles.size()));
     };
     if (rem_units > 0) {
         // Two ways to cut rem_units x slabs over G workgroups.  Stream-K: equal shares; a share that
@@ -331,7 +318,28 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
             }
         }
     }
-    if (private_partials && !partial_ptr->empty()) partial_ptr->push_back(ordinal);
+    // Ordinals of the private tiles, tile by tile: partial_tiles lists the tiles that own any,
+    // partial_ptr their first ordinal (+ the total); a tile's partials are contiguous.
+    if (can_list) {
+        std::vector<int32_t> count(tiles.size() + 1, 0);
+        for (int g = 0; g < G; ++g)
+            for (size_t k = 0; k < per[(size_t)g].size(); ++k)
+                if (per[(size_t)g][k].pad > 0) ++count[(size_t)per_tile[(size_t)g][k] + 1];
+        std::vector<int32_t> next(tiles.size(), 0);
+        int32_t total_partials = 0;
+        for (size_t t = 0; t < tiles.size(); ++t) {
+            if (count[t + 1] == 0) continue;
+            partial_ptr->push_back(total_partials);
+            partial_tiles->push_back(tiles[t].i0);
+            partial_tiles->push_back(tiles[t].j0);
+            next[t] = total_partials;
+            total_partials += count[t + 1];
+        }
+        if (!partial_ptr->empty()) partial_ptr->push_back(total_partials);
+        for (int g = 0; g < G; ++g)
+            for (size_t k = 0; k < per[(size_t)g].size(); ++k)
+                if (per[(size_t)g][k].pad > 0) per[(size_t)g][k].pad = ++next[(size_t)per_tile[(size_t)g][k]];
+    }
     std::vector<MItem> &mi = *items;
     std::vector<int32_t> &mptr = *item_ptr;
     mi.clear();
