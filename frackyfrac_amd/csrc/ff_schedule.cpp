@@ -3,6 +3,7 @@
 #include "ff_schedule.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 
@@ -226,7 +227,6 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     // sweep the branches in step.  Remainder (< G units): cut stream-K style into G equal
     // slab ranges so that every workgroup ends at the same time.
     const int groups = (digits + M_ND - 1) / M_ND;
-    const int64_t units = (int64_t)groups * (int64_t)tiles.size();
     // The branch sweep is cut at multiples of M_QUAD_SLABS slabs (the kernel's loop works in quads; the
     // engine pads the staged rows to whole quads): from here on `slabs` counts quads, and make_item
     // turns quads back into branches.
@@ -246,8 +246,17 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     };
     std::vector<std::vector<MItem>> per((size_t)G);
     std::vector<std::vector<int32_t>> per_tile((size_t)G);  // tile index of every item (for the ordinals below)
-    const int64_t rounds = units / G;
-    const int64_t rem_units = units - rounds * G;
+    const int64_t T = (int64_t)tiles.size();
+    // Whole rounds are dealt out digit group by digit group: a sweep of a group with a single digit
+    // plane costs about three quarters of a two-plane one (its loop is bound by the vector work,
+    // not the MFMAs), and a round that mixed both kinds would leave some workgroups a quarter of a
+    // unit behind.  What does not fill a round of its group goes to the remainder, which is cut by cost.
+    const int64_t rounds_per_group = T / G;
+    const int64_t rounds = rounds_per_group * groups;
+    std::vector<int64_t> rem;  // units of the remainder, in (group, tile) order
+    for (int grp = 0; grp < groups; ++grp)
+        for (int64_t t = rounds_per_group * G; t < T; ++t) rem.push_back((int64_t)grp * T + t);
+    const int64_t rem_units = (int64_t)rem.size();
     const int per_xcd = std::max(1, G / 8);
     // Device-scope atomics across XCDs are performed at the memory side and are slow (a problem
     // too small for even one round, all remainder, spent two thirds of its kernel in them).  Ways
@@ -261,61 +270,99 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     const bool can_list = partial_tiles && partial_ptr;
     const bool all_private = can_list && rounds * G + (rem_units ? G + rem_units : 0) <= max_private_tiles;
     const bool private_remainder = can_list && (all_private || groups == 1);
-    for (int64_t r = 0; r < rounds; ++r)
-        for (int g = 0; g < G; ++g) {
-            const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
-            MItem itm = make_item(r * G + local, 0, slabs);
-            if (all_private) itm.pad = 1;  // (a private tile: the ordinal comes below)
-            else if (can_list && groups == 1) itm.pad = -1;
-            per[(size_t)g].push_back(itm);
-            per_tile[(size_t)g].push_back((int32_t)((r * G + local) % (int64_t)tiles.size()));
-        }
+    for (int grp = 0; grp < groups; ++grp)
+        for (int64_t r = 0; r < rounds_per_group; ++r)
+            for (int g = 0; g < G; ++g) {
+                const int64_t local = (G % 8 == 0) ? (int64_t)(g % 8) * per_xcd + g / 8 : g;
+                const int64_t t = r * G + local;
+                MItem itm = make_item((int64_t)grp * T + t, 0, slabs);
+                if (all_private) itm.pad = 1;  // (a private tile: the ordinal comes below)
+                else if (can_list && groups == 1) itm.pad = -1;
+                per[(size_t)g].push_back(itm);
+                per_tile[(size_t)g].push_back((int32_t)t);
+            }
     if (partial_tiles) partial_tiles->clear();
     if (partial_ptr) partial_ptr->clear();
     auto add_range = [&](int g, int64_t unit, int64_t s0, int64_t s1) {
-        MItem itm = make_item(rounds * G + unit, s0, s1);
+        MItem itm = make_item(unit, s0, s1);
         if (private_remainder) itm.pad = 1;
         per[(size_t)g].push_back(itm);
-        per_tile[(size_t)g].push_back((int32_t)((rounds * G + unit) % (int64_t)tiles.size()));
+        per_tile[(size_t)g].push_back((int32_t)(unit % T));
     };
     if (rem_units > 0) {
-        // Two ways to cut rem_units x slabs over G workgroups.  Stream-K: equal shares; a share that
-        // straddles a unit boundary becomes two items, and an item costs its workgroup a prologue and
-        // an epilogue -- about M_ITEM_OVERHEAD_SLABS slabs' worth -- on top of its slabs.  Aligned:
-        // unit u gets G / rem_units workgroups (the first G % rem_units units one more), which cut it
-        // evenly; nothing straddles, but the ranges of a unit with fewer workgroups are longer.  The
-        // cut whose slowest workgroup finishes first is taken.
-        const int64_t total = rem_units * slabs;
+        // Cost of a quad of slabs of unit u: 4 with two digit planes, 3 with one.  Two ways to cut the
+        // remainder over G workgroups.  Stream-K: equal shares of cost; a share that straddles a unit
+        // boundary becomes two items, and an item costs its workgroup a prologue and an epilogue --
+        // about M_ITEM_OVERHEAD_SLABS slabs' worth -- on top of its slabs.  Aligned: every unit gets
+        // workgroups in proportion to its cost, which cut it evenly; nothing straddles, but ranges
+        // come out unequal where the proportions do not divide.  The cut whose slowest workgroup
+        // finishes first is taken.
+        auto quad_cost = [&](int64_t unit) { return (int64_t)(std::min(M_ND, digits - M_ND * (int)(unit / T)) > 1 ? 4 : 3); };
+        std::vector<int64_t> start((size_t)rem_units + 1, 0);  // cost position at which unit k begins
+        for (int64_t k = 0; k < rem_units; ++k) start[(size_t)k + 1] = start[(size_t)k] + slabs * quad_cost(rem[(size_t)k]);
+        const int64_t total = start[(size_t)rem_units];
         const int64_t share = std::max<int64_t>(1, (total + G - 1) / G);
+        // the quad of unit k at which cost position x falls (both neighbours of a boundary use this)
+        auto quad_at = [&](int64_t k, int64_t x) {
+            const int64_t c = quad_cost(rem[(size_t)k]);
+            return std::min(slabs, std::max<int64_t>(0, (x - start[(size_t)k] + c - 1) / c));
+        };
+        auto stream_ranges = [&](int g, const std::function<void(int64_t, int64_t, int64_t)> &emit) {
+            const int64_t a2 = (int64_t)g * share, b2 = std::min(total, a2 + share);
+            for (int64_t k = 0; k < rem_units && a2 < b2; ++k) {
+                if (start[(size_t)k + 1] <= a2 || start[(size_t)k] >= b2) continue;
+                const int64_t s0 = quad_at(k, a2), s1 = quad_at(k, b2);
+                if (s0 < s1) emit(k, s0, s1);
+            }
+        };
+        const int64_t overhead = M_ITEM_OVERHEAD_SLABS / M_QUAD_SLABS * 4;
         int64_t cost_stream = 0;
         for (int g = 0; g < G; ++g) {
-            const int64_t a2 = (int64_t)g * share, b2 = std::min(total, a2 + share);
-            if (a2 >= b2) break;
-            const int64_t n_items = (b2 - 1) / slabs - a2 / slabs + 1;
-            cost_stream = std::max(cost_stream, (b2 - a2) + (n_items - 1) * (M_ITEM_OVERHEAD_SLABS / M_QUAD_SLABS));
+            int64_t c = 0, n_items = 0;
+            stream_ranges(g, [&](int64_t k, int64_t s0, int64_t s1) {
+                c += (s1 - s0) * quad_cost(rem[(size_t)k]);
+                ++n_items;
+            });
+            cost_stream = std::max(cost_stream, c + std::max<int64_t>(0, n_items - 1) * overhead);
         }
-        const int64_t w_min = G / rem_units;  // >= 1: the remainder has fewer units than workgroups
-        const int64_t cost_aligned = (slabs + w_min - 1) / w_min;
+        // aligned: w[k] workgroups for unit k, at least one, the spare ones to whoever carries most
+        std::vector<int64_t> w((size_t)rem_units, 1);
+        int64_t cost_aligned = INT64_MAX;
+        if (rem_units <= G) {
+            int64_t used = 0;
+            for (int64_t k = 0; k < rem_units; ++k) {
+                w[(size_t)k] = std::max<int64_t>(1, (int64_t)G * (start[(size_t)k + 1] - start[(size_t)k]) / total);
+                used += w[(size_t)k];
+            }
+            auto load = [&](int64_t k) { return (slabs + w[(size_t)k] - 1) / w[(size_t)k] * quad_cost(rem[(size_t)k]); };
+            for (; used > G; --used) {  // (the "at least one" may have overdrawn: take from the lightest)
+                int64_t best = -1;
+                for (int64_t k = 0; k < rem_units; ++k)
+                    if (w[(size_t)k] > 1 && (best < 0 || load(k) < load(best))) best = k;
+                if (best < 0) break;
+                --w[(size_t)best];
+            }
+            for (; used < G; ++used) {
+                int64_t best = 0;
+                for (int64_t k = 1; k < rem_units; ++k)
+                    if (load(k) > load(best)) best = k;
+                ++w[(size_t)best];
+            }
+            if (used == G) {
+                cost_aligned = 0;
+                for (int64_t k = 0; k < rem_units; ++k) cost_aligned = std::max(cost_aligned, load(k));
+            }
+        }
         if (cost_aligned <= cost_stream) {
             int g = 0;
-            for (int64_t unit = 0; unit < rem_units; ++unit) {
-                const int64_t w = w_min + (unit < G % rem_units ? 1 : 0);
-                for (int64_t q = 0; q < w; ++q, ++g) {
-                    const int64_t s0 = slabs * q / w, s1 = slabs * (q + 1) / w;
-                    if (s0 < s1) add_range(g, unit, s0, s1);
+            for (int64_t k = 0; k < rem_units; ++k)
+                for (int64_t q = 0; q < w[(size_t)k]; ++q, ++g) {
+                    const int64_t s0 = slabs * q / w[(size_t)k], s1 = slabs * (q + 1) / w[(size_t)k];
+                    if (s0 < s1) add_range(g, rem[(size_t)k], s0, s1);
                 }
-            }
         } else {
-            for (int g = 0; g < G; ++g) {
-                int64_t a2 = (int64_t)g * share;
-                const int64_t b2 = std::min(total, a2 + share);
-                while (a2 < b2) {
-                    const int64_t unit = a2 / slabs, s0 = a2 % slabs;
-                    const int64_t s1 = std::min<int64_t>(slabs, s0 + (b2 - a2));
-                    add_range(g, unit, s0, s1);
-                    a2 += s1 - s0;
-                }
-            }
+            for (int g = 0; g < G; ++g)
+                stream_ranges(g, [&](int64_t k, int64_t s0, int64_t s1) { add_range(g, rem[(size_t)k], s0, s1); });
         }
     }
     // Ordinals of the private tiles, tile by tile: partial_tiles lists the tiles that own any,

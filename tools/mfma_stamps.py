@@ -24,8 +24,11 @@ if wl in synth.CONFIGS:
 else:
     ns, nl = wl.split("x")
     tree, ptr, idx, val = synth.make(int(ns), int(nl), 0.1, 77)
+if os.environ.get("FF_STAMPS_INEXACT"):  # lengths off the binary grid: three digits, two sweeps
+    tree.branch_len = tree.branch_len * (1.0 + 1e-3 * np.random.default_rng(5).random(tree.branch_len.shape[0]))
 nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
 plan = ff.Plan(nodes, False, precision="fixed32")
+print("digits %d, items %d" % (plan.info.n_digits, plan.info.n_items))
 out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
 for _ in range(3):
     plan.run(out.data_ptr())
