@@ -47,6 +47,13 @@ constexpr int M_QUAD_SLABS = 4;
 // and its prologue four pairs whatever the item's length: up to 8 slabs past an item's end are read.
 constexpr int M_PAD_SLABS = 12;
 static_assert(M_PAD_SLABS >= 8 && M_PAD_SLABS % 2 == 0, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
+#ifndef FF_MFMA_DIRECT_WORDS
+#define FF_MFMA_DIRECT_WORDS 1
+#endif
+// 1: every lane loads the words of the rows its fragments hold (rows lane & 31 of each 32-row block: six
+// loads per pair of slabs, two lanes per address); 0: one row per lane (three loads) and a
+// v_permlane32_swap per word and k-step to bring them there.
+constexpr bool M_DIRECT_WORDS = FF_MFMA_DIRECT_WORDS != 0;
 constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time (128 bytes each: 64 KiB)
 
 // Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,
@@ -148,8 +155,9 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         const int nslab = (item.k1 - item.k0) / M_KSLAB;
         __builtin_assume(nslab >= M_QUAD_SLABS);  // (ff_schedule.cpp: whole quads of slabs, at least one)
         // this lane's samples: rows `lane` and 64 + `lane` of the wave's 128 i-samples, row `lane` of its 64 j-samples
-        const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + lane;
-        const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + lane;
+        const int wlane = M_DIRECT_WORDS ? (lane & 31) : lane;
+        const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + wlane;
+        const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + wlane;
         const int8_t *dig_src[2] = {Kd + (int64_t)item.d0 * ldb + item.k0,
                                     Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0};
         // An item with a single digit plane (the last group of an odd number of digits) runs without the
@@ -170,14 +178,20 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 const int nseg = nslab - seg < M_TABLE_SLABS ? nslab - seg : M_TABLE_SLABS;
                 // the words of the segment's first four pairs are requested before anything else: their latency
                 // passes while the digit table is copied
-                uint4 wa0[4], wa1[4], wb[4];  // [pair & 3]: i-words of rows lane / 64 + lane, j-words; component c =
-                                              // the 32 branches of k-step c of the pair
+                // [pair & 3][block]: the words of i-rows / j-rows; component c = the 32 branches of k-step c of
+                // the pair.  Direct: block m = rows 32 m + (lane & 31); else blocks 0, 1 = rows lane, 64 + lane.
+                constexpr int NWA = M_DIRECT_WORDS ? 4 : 2, NWB = M_DIRECT_WORDS ? 2 : 1, WSTEP = M_DIRECT_WORDS ? 32 : 64;
+                uint4 wa[4][NWA], wb[4][NWB];
                 const uint4 *qa = pa + (int64_t)(seg / 2) * n8, *qb = pb + (int64_t)(seg / 2) * n8;
+                auto request_words = [&](int buf) {
+#pragma unroll
+                    for (int m = 0; m < NWA; ++m) wa[buf][m] = qa[WSTEP * m];
+#pragma unroll
+                    for (int n = 0; n < NWB; ++n) wb[buf][n] = qb[WSTEP * n];
+                };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    wa0[q] = qa[0];
-                    wa1[q] = qa[64];
-                    wb[q] = qb[0];
+                    request_words(q);
                     qa += n8;
                     qb += n8;
                 }
@@ -207,11 +221,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) shk[kk] = (uint32_t)(sh + kk);
                 auto load_words = [&](int buf) {  // the next pair not yet requested, into buffer `buf` (reads past the
-                    if constexpr (!(DIAG & 2)) {  // item's end hit the arrays' padding and are never multiplied)
-                        wa0[buf] = qa[0];
-                        wa1[buf] = qa[64];
-                        wb[buf] = qb[0];
-                    }
+                    if constexpr (!(DIAG & 2)) request_words(buf);  // item's end hit the arrays' padding and are never multiplied)
                     qa += n8;
                     qb += n8;
                 };
@@ -224,10 +234,17 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                         dg0[set] = dg1[set] = mfma_v4i{kstep, half, lane, 3};
                     }
                 };
-                // component `c` of the words in buffer `buf` to where the fragments want them (3 swaps)
+                // component `c` of the words in buffer `buf` to where the fragments want them (3 swaps, or nothing)
                 auto take_words = [&](int buf, int c) {
                     auto comp = [c](const uint4 &w) { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
-                    const uint32_t w0 = comp(wa0[buf]), w1 = comp(wa1[buf]), wy = comp(wb[buf]);
+                    if constexpr (M_DIRECT_WORDS) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) swx[m] = comp(wa[buf][m % NWA]);
+                        swy[0] = comp(wb[buf][0]);
+                        swy[1] = comp(wb[buf][1 % NWB]);
+                        return;
+                    }
+                    const uint32_t w0 = comp(wa[buf][0]), w1 = comp(wa[buf][1 % NWA]), wy = comp(wb[buf][0]);
                     if constexpr (!(DIAG & 4)) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(w0, w0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(w1, w1, false, false);
