@@ -65,6 +65,13 @@ for k in range(4):
     cyc = (st[have, k, 6] - st[have, k, 5]).astype(np.float64)
     dt = (st[have, k, 2] - st[have, k, 1]) / 100.0
     print("   %-40s median %7.0f cycles = %.3f GHz" % ("loop, shader clock (s_memtime)", np.median(cyc), np.median(cyc / dt) / 1000.0))
+    if k == 0 and have.all():  # by XCD (workgroup g runs on XCD g mod 8): is the spread a property of the place?
+        dt_all = (st[:, 0, 2] - st[:, 0, 1]) / 100.0
+        cyc_all = (st[:, 0, 6] - st[:, 0, 5]).astype(np.float64)
+        print("   loop by XCD, median us:     " + " ".join("%7.1f" % np.median(dt_all[x::8]) for x in range(8)))
+        print("   loop by XCD, median cycles: " + " ".join("%7.0f" % np.median(cyc_all[x::8]) for x in range(8)))
+        print("   loop, all workgroups: us min %.1f max %.1f; cycles min %.0f max %.0f" % (
+            dt_all.min(), dt_all.max(), cyc_all.min(), cyc_all.max()))
     if k:
         gap = (st[have, k, 0] - st[have, k - 1, 4]) / 100.0
         print("   %-40s median %7.2f us" % ("(gap after previous item)", np.median(gap)))
