@@ -678,8 +678,8 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     // slots of tiles that are not split that way are never written in planes 1..: zero once
     FF_HIP(hipMemset(pl->d_num, 0, sizeof(uint32_t) * (size_t)pl->plane_stride * (size_t)pl->n_planes));
     if (env_int("FF_STAMPS", 0)) {
-        FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)U));
-        FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 2 * (size_t)U));
+        FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 4 * (size_t)U));
+        FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)U));
     }
     if (pl->waves_per_wg == L_WAVES_PER_WG) {
         FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
@@ -1519,12 +1519,13 @@ int ff_device_copy_async(void *dst, const void *src, size_t bytes, void *stream,
 }
 
 // Diagnostics, not part of the public header: copies the per-wave start/end stamps
-// of the last pair_sad_kernel launch (FF_STAMPS=1) into out[2 * n_wave_slots].
+// of the last pair_sad_kernel launch (FF_STAMPS=1) into out[4 * n_wave_slots]: 2 per wave on the 100 MHz
+// wall clock, then 2 per wave on the shader clock.
 int ff_debug_read_stamps(ff_plan *pl, unsigned long long *out)
 {
     if (!pl || !pl->d_stamps || !out) return FF_ERR_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return FF_ERR_DEVICE;
-    if (hipMemcpy(out, pl->d_stamps, sizeof(unsigned long long) * 2 * (size_t)pl->info.n_wave_slots,
+    if (hipMemcpy(out, pl->d_stamps, sizeof(unsigned long long) * 4 * (size_t)pl->info.n_wave_slots,
                   hipMemcpyDeviceToHost) != hipSuccess)
         return FF_ERR_DEVICE;
     return FF_OK;

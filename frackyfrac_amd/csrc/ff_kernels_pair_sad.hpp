@@ -133,8 +133,11 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * WAVES_PER_WG + wave;
     const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock and, behind those, on the shader clock
+    if (stamps && lane == 0) {
+        stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot)] = __builtin_amdgcn_s_memtime();  // (the SIMD's own clock)
+    }
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
@@ -142,7 +145,10 @@ void pair_sad_kernel(const uint32_t *__restrict__ QT, int64_t ld,
         else
             run_item<4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
     }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && lane == 0) {
+        stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot) + 1] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // The same with half the vector buffers (2 x 4 rows): 168 VGPRs, three waves per SIMD.
@@ -156,8 +162,11 @@ void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x * L_WAVES_PER_WG + wave;
     const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
-    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    // diagnostics (FF_STAMPS=1): start/end of every wave on the 100 MHz wall clock and, behind those, on the shader clock
+    if (stamps && lane == 0) {
+        stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot)] = __builtin_amdgcn_s_memtime();  // (the SIMD's own clock)
+    }
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
@@ -165,7 +174,10 @@ void pair_sad_kernel12(const uint32_t *__restrict__ QT, int64_t ld,
         else
             run_item<4, 4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane);
     }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && lane == 0) {
+        stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot) + 1] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // ---- LDS-staged variant: three waves per SIMD ----------------------------------------------
@@ -312,7 +324,10 @@ void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
     const int it_begin = item_ptr[slot], it_end = item_ptr[slot + 1];
     uint32_t __attribute__((address_space(3))) *ring =
         (uint32_t __attribute__((address_space(3))) *)lds_ring + wave * (L_RING * 256);
-    if (stamps && lane == 0) stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && lane == 0) {
+        stamps[2 * slot] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot)] = __builtin_amdgcn_s_memtime();  // (the SIMD's own clock)
+    }
     for (int it = it_begin; it < it_end; ++it) {
         const Item item = items[it];
         if (item.flags & 4u)
@@ -320,7 +335,10 @@ void pair_sad_lds_kernel(const uint32_t *__restrict__ QT, int64_t ld,
         else
             run_item_lds<4>(QT, ld, item, num, plane_stride, row_begin, row_end, slot_begin, sync_trips, lane, ring);
     }
-    if (stamps && lane == 0) stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && lane == 0) {
+        stamps[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[2 * (gridDim.x * (blockDim.x / 64) + slot) + 1] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // ---- Sparse-aware variant of the pair-tile reduction ----------------------------------

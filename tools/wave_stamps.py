@@ -16,11 +16,12 @@ for _ in range(3):
     plan.run(out.data_ptr())
 torch.cuda.synchronize()
 U = plan.info.n_wave_slots
-st = np.zeros(2 * U, dtype=np.uint64)
+st = np.zeros(4 * U, dtype=np.uint64)
 fn = L.lib().ff_debug_read_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 assert fn(plan._h, st.ctypes.data) == 0
-st = st.reshape(U, 2).astype(np.int64)
+clk = st[2 * U:].reshape(U, 2).astype(np.int64)
+st = st[:2 * U].reshape(U, 2).astype(np.int64)
 t0 = st[:, 0].min()
 start = (st[:, 0] - t0) / 100.0   # us
 end = (st[:, 1] - t0) / 100.0
@@ -38,3 +39,11 @@ for x in range(8):
 for w in range(8):
     e = end.reshape(-1, 8)[:, w]
     print("  wave %d: end med %.1f" % (w, np.median(e)))
+cyc = (clk[:, 1] - clk[:, 0]).astype(np.float64)
+ghz = cyc / np.maximum(dur, 1e-9) / 1000.0
+print("shader clock (s_memtime / s_memrealtime) per wave: min %.3f p50 %.3f max %.3f GHz; cycles p50 %.0f" % (
+    ghz.min(), np.median(ghz), ghz.max(), np.median(cyc)))
+wpw = U // plan.info.n_compute_units
+by_xcd = [np.median(ghz[[w for w in range(U) if (w // wpw) % 8 == x]]) for x in range(8)]
+print("by XCD (workgroup g on XCD g mod 8): " + " ".join("%.3f" % v for v in by_xcd))
+
