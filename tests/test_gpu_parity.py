@@ -316,6 +316,43 @@ def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch):
     assert np.array_equal(outs["1"], want)
 
 
+@pytest.mark.parametrize("digits3", [False, True])
+def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch, digits3):
+    """4,600 samples = 342 tiles on 256 workgroups: whole rounds and a remainder.  The matrix-core kernel
+    has three ways out -- a private tile per item in the accumulators' order (the default within
+    FF_MFMA_PRIVATE_MB), private tiles for the remainder only + plain stores through LDS (budget 0), and
+    atomics (several digit groups over the budget) -- with the finish fused into the reduce kernel or
+    not; all must give the vector-ALU kernel's bits (unifrac.go:144-171 for the values, tested elsewhere)."""
+    import torch
+    tree, ptr, idx, val = synth.make(4600, 600, 0.1, 17)
+    if digits3:
+        rng = np.random.default_rng(9)
+        tree.branch_len = rng.integers(1, 1 << 19, size=tree.n).astype(np.float64) / 64.0
+        tree.branch_len[0] = 0.0
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = ff.Plan(nodes, False, precision="fixed32")
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        got, info = out.cpu().numpy(), plan.info
+        plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return got, info
+
+    want, info = run({"FF_UNWEIGHTED_MFMA": "0"})
+    assert info.kernel in (0, 3)
+    for env in ({}, {"FF_MFMA_PRIVATE_MB": "0"}, {"FF_MFMA_FUSED_FINISH": "0"},
+                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_PARTIALS": "0"}):
+        got, info = run(env)
+        assert info.kernel == 2 and info.n_digits == (3 if digits3 else 2) and info.n_tiles == 342
+        assert np.array_equal(got, want), env
+
+
 def test_unweighted_mfma_five_digits_and_long_lengths():
     """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps)."""
     tree, ptr, idx, val = synth.make(130, 20, 0.3, 93)
