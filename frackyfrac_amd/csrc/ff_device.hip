@@ -668,7 +668,7 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     inf.n_items = (int64_t)items.size();
     pl->n_planes = 1;
     for (const Item &it : items) pl->n_planes = std::max(pl->n_planes, (int)((it.flags >> 3) & 255u) + 1);
-    pl->plane_stride = std::max<int64_t>(n_slots, 1);
+    pl->plane_stride = round_up(std::max<int64_t>(n_slots, 1), FINISH_RUN);  // (planes start 16-byte aligned: finish_fixed32_kernel)
     FF_HIP(hipMalloc(&pl->d_items, sizeof(Item) * std::max<size_t>(items.size(), 1)));
     FF_HIP(hipMalloc(&pl->d_item_ptr, sizeof(int32_t) * item_ptr.size()));
     if (!items.empty())
@@ -1246,7 +1246,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 inf.slot_begin, pl->d_stamps, pl->sync_trips);
         if (timed && !pl->mfma) FF_HIP(hipEventRecord(ev1, st));
         if (!fused) {
-            const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 255) / 256, 1 << 22);
+            const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 256 * FINISH_RUN - 1) / (256 * FINISH_RUN), 1 << 22);
             finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->n_planes, pl->plane_stride, fin, inf.slot_begin, n_slots);
         }
         if (pl->refine)

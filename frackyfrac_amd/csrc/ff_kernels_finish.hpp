@@ -2,19 +2,34 @@
 // A fragment of ff_device.hip: included there, once, inside its anonymous namespace
 // (one translation unit, so the kernels stay internal and need no relocatable device code).
 
-// Integer sums -> distances: finish_pair (ff_kernels_finish_pair.hpp) for every slot of the shard.
-__global__ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
-                                      int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
-                                      const FinishArgs f, int64_t slot_begin, int64_t n_slots)
+// Integer sums -> distances: finish_pair (ff_kernels_finish_pair.hpp) for every slot of the shard.  A workgroup
+// takes FINISH_RUN x 256 consecutive slots, thread t of it slots t, t + 256, ...: every access is a wave's
+// contiguous 256 / 512 bytes, and the slot -> (i, j) conversion (a square root) is done once per thread, the
+// later ones by stepping j and wrapping into the next row.
+constexpr int FINISH_RUN = 4;
+__global__ __launch_bounds__(256)
+void finish_fixed32_kernel(const uint32_t *__restrict__ num,
+                           int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
+                           const FinishArgs f, int64_t slot_begin, int64_t n_slots)
 {
     // grid-stride: a launch carries at most 2^32 - 1 threads, a shard can have more slots
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots;
-         t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = (int64_t)blockIdx.x * (256 * FINISH_RUN) + threadIdx.x; t < n_slots;
+         t += ((int64_t)gridDim.x - 1) * (256 * FINISH_RUN)) {
         int64_t i, j;
         slot_to_pair(slot_begin + t, &i, &j);
-        uint32_t u32 = num[t];
-        for (int q = 1; q < n_planes; ++q) u32 += num[(int64_t)q * plane_stride + t];
-        finish_pair(f, t, i, j, u32);
+#pragma unroll
+        for (int e = 0; e < FINISH_RUN; ++e, t += 256) {
+            if (t < n_slots) {
+                uint32_t u32 = num[t];
+                for (int q = 1; q < n_planes; ++q) u32 += num[(int64_t)q * plane_stride + t];
+                finish_pair(f, t, i, j, u32);
+            }
+            j += 256;
+            while (j >= i) {  // (rows are shorter than 256 only at the top of the triangle)
+                j -= i;
+                ++i;
+            }
+        }
     }
 }
 

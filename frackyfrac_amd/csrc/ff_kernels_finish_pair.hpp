@@ -50,7 +50,8 @@ __device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int6
     f.out[t] = d;
     if (f.indptr && w != 0) {
         const double k = (double)((f.indptr[i + 1] - f.indptr[i]) + (f.indptr[j + 1] - f.indptr[j]));
-        if ((double)u * REFINE_BAR < REFINE_C * sqrt(k) + 2.0) {
+        const double a = (double)u * REFINE_BAR - 2.0;  // u * 1e-6 < C sqrt(k) + 2, without the square root
+        if (a < 0.0 || a * a < REFINE_C * REFINE_C * k) {
             const unsigned long long at = atomicAdd(f.refine_count, 1ull);
             if (at < f.refine_cap) f.refine_list[at] = (unsigned long long)t;
         }
