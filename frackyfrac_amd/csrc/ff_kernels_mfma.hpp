@@ -12,9 +12,9 @@
 // are identical bit for bit; only the unit that does the work changes.
 //
 // What travels is the INFORMATION, not the int8 operands: presence is one bit per (sample,
-// branch) -- Pbits[slab][sample], a 64-bit word per 64-branch slab, sample-minor so that the words
-// a wave needs are contiguous -- and a digit is a property of the BRANCH (Kd[digit][branch], one
-// byte).  Every wave builds its own MFMA fragments in registers from those words: no int8 plane
+// branch) -- a 64-bit word per 64-branch slab and sample, the words of two consecutive slabs side
+// by side (Pbits[slab / 2][sample]), sample-minor so that the words a wave needs are contiguous --
+// and a digit is a property of the BRANCH (Kd[digit][branch], one byte).  Every wave builds its own MFMA fragments in registers from those words: no int8 plane
 // is ever stored, in HBM or in LDS.  History, all at C3 unweighted (tools/mfma_diag.py times the
 // kernel with parts compiled out): int8 planes streamed by LDS-DMA 0.385 ms, bound by the stream
 // (32 KiB per slab and workgroup, 13 B/clk/CU arriving, 32 needed); bit-packed words expanded
@@ -40,9 +40,8 @@ typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 
 // The presence words are staged in PAIRS of slabs -- Pbits[slab / 2][sample] = the sample's 64-bit words of
 // slabs 2p and 2p + 1 -- so that one 16-byte load per lane fetches two slabs; the kernel's loop keeps four
-// pairs in flight.  An item is a whole number of M_QUAD_SLABS slabs (the branch rows are zero padded to that)
-// and starts at a multiple of it.
-constexpr int M_QUAD_SLABS = 4;
+// pairs in flight.  An item is a whole number of M_QUAD_SLABS (ff_schedule.hpp: 4) slabs -- the branch rows are
+// zero padded to that -- and starts at a multiple of it.
 // Slabs of zero padding behind the staged arrays: the loop requests pair p + 4 when it is done with pair p,
 // and its prologue four pairs whatever the item's length: up to 8 slabs past an item's end are read.
 constexpr int M_PAD_SLABS = 12;
@@ -102,20 +101,22 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
 // cycles per MFMA; with 4 x 2 tiles every B fragment serves four MFMAs per plane: 4.7 per MFMA.
 //
 // The loop runs over k-steps (two per slab).  K-step u issues the 16 MFMAs of fragment set u & 1
-// while the vector ALU builds set (u + 1) & 1, a piece of at most six instructions behind each MFMA.
+// while the vector ALU builds set (u + 1) & 1, a piece of four to six instructions behind each MFMA.
 // The MFMAs are inline asm: volatile asm statements keep their program order, which is the only
 // way to hold this interleave (the compiler's own schedule is "all vector work, then all MFMAs",
 // and a pure intrinsic has no place of its own in the instruction selector's order).  The price is
 // that the compiler no longer sees matrix instructions: nothing here reads an accumulator or
 // rewrites a fragment register within 16 MFMAs of the instruction concerned, and the epilogue
 // waits out the last MFMA with explicit s_nop.
-// Inputs of a piece: the lane's presence words of i-samples `lane`, 64 + `lane` and j-sample `lane`
-// of the wave's 128 + 64 (one 512-byte load each per slab, two slabs ahead; v_permlane32_swap then
-// gives every lane the words of rows lane & 31 and 32 + (lane & 31) of each 64, which is what the
-// MFMA fragments hold) and the half-wave's 2 x 16 digits from the LDS table (two k-steps ahead).
+// Inputs of a piece: the presence words of the rows the lane's fragments hold -- row lane & 31 of each of the
+// wave's four 32-row i-blocks and two j-blocks, one 16-byte load per block and PAIR of slabs, four pairs in
+// flight (first use 5.5 slabs after the request) -- and the half-wave's 2 x 16 digits from the LDS table (two
+// k-steps ahead).
 //
-// ALL_PRIVATE: every item of the launch has a private partial tile (a problem smaller than one
-// round); the epilogue is then the plain stores alone.
+// ALL_PRIVATE: every item of the launch owns a partial tile (the schedule fits FF_MFMA_PRIVATE_MB); the way
+// out is then 16-byte stores of the accumulators in their own order, which reduce_private_kernel reads.
+// An item with a single digit plane runs its own instantiation of everything between the accumulators'
+// declaration and the way out (run_item), without the second plane.
 // DIAG (builds with -DFF_MFMA_DIAG only; results are then WRONG, the time is what is asked for):
 // bit 1 drops the global loads inside the loop, bit 2 the expansion (vector work), bit 3 the
 // digit reads, bit 4 the MFMAs.
