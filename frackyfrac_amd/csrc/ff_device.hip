@@ -718,13 +718,22 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     // copy-out is then aligned 512-byte rows into a contiguous tile (2.8 us a tile at C3) instead of 4-byte
     // stores into rows of the triangle that start anywhere (12.8 us), and reduce_partials_kernel writes the
     // distances straight from the sums -- no num[] round trip, no finish launch.
-    const int64_t private_tiles = (int64_t)env_int("FF_MFMA_PRIVATE_MB", 2048) * (1 << 20) / (M_TILE_I * M_TILE_J * 4);
-    const int64_t n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr,
-                                                 want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr,
-                                                 private_tiles);
+    int64_t private_tiles = (int64_t)env_int("FF_MFMA_PRIVATE_MB", 2048) * (1 << 20) / (M_TILE_I * M_TILE_J * 4);
+    int64_t n_mtiles = 0;
+    for (;;) {
+        n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr,
+                                       want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr, private_tiles);
+        if (pptr.empty()) break;
+        if (hipMalloc(&pl->d_partial, sizeof(uint32_t) * (size_t)pptr.back() * M_TILE_I * M_TILE_J) == hipSuccess) break;
+        (void)hipGetLastError();  // (the device is short of memory: only the remainder's ranges get private tiles)
+        pl->d_partial = nullptr;
+        if (private_tiles == 0)
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "out of device memory for %lld partial tiles of the matrix-core schedule",
+                            (long long)pptr.back());
+        private_tiles = 0;
+    }
     if (!pptr.empty()) {
         pl->n_ptiles = (int)pptr.size() - 1;
-        FF_HIP(hipMalloc(&pl->d_partial, sizeof(uint32_t) * (size_t)pptr.back() * M_TILE_I * M_TILE_J));
         FF_HIP(hipMalloc(&pl->d_ptiles, sizeof(int32_t) * ptiles.size()));
         FF_HIP(hipMalloc(&pl->d_ptile_ptr, sizeof(int32_t) * pptr.size()));
         FF_HIP(hipMemcpy(pl->d_ptiles, ptiles.data(), sizeof(int32_t) * ptiles.size(), hipMemcpyHostToDevice));
