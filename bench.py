@@ -305,8 +305,9 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: about a second of GPU time in the timed region, so that an outside sampler of GPU activity sees it)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", help="C2|C3|C4|C5 or SAMPLESxLEAVES (e.g. 2048x5000)")
     ap.add_argument("--precision", default="fixed32", choices=["auto", "fixed32", "exact64"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
