@@ -113,6 +113,7 @@ struct ff_plan {
     double *d_len_rows = nullptr;  // EXACT64 with compacted rows: treeDists by staged row
     XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
+    int x_tile_h = 0;  // EXACT64 tile height in use (0: not chosen yet)
     // timing: one event pair per timed run since the last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -763,14 +764,46 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     return FF_OK;
 }
 
-int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
+// One launch of the EXACT64 pair kernel with the plan's tile height.
+int launch_exact64(ff_plan *pl, hipStream_t st, double *d_out, char *err, size_t errlen)
+{
+    const ff_plan_info &inf = pl->info;
+    if (pl->n_xtiles <= 0) return FF_OK;
+    const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
+    const double *len = pl->d_len_rows ? pl->d_len_rows : pl->d_len;
+#define FF_X_CASE(H)                                                                                              \
+    case H:                                                                                                       \
+        if (pl->weighted)                                                                                         \
+            pair_exact64_kernel<true, H><<<dim3(nb), dim3(256), 0, st>>>(pl->d_DT, inf.ld, len, inf.n_rows, pl->d_xtiles, \
+                                                                        pl->n_xtiles, inf.row_begin, inf.row_end,  \
+                                                                        inf.slot_begin, d_out);                    \
+        else                                                                                                      \
+            pair_exact64_kernel<false, H><<<dim3(nb), dim3(256), 0, st>>>(pl->d_DT, inf.ld, len, inf.n_rows, pl->d_xtiles, \
+                                                                         pl->n_xtiles, inf.row_begin, inf.row_end, \
+                                                                         inf.slot_begin, d_out);                   \
+        break;
+    switch (pl->x_tile_h) {
+        FF_X_CASE(8)
+        FF_X_CASE(10)
+        FF_X_CASE(12)
+        FF_X_CASE(14)
+        FF_X_CASE(16)
+    default: return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: no kernel for tile height %d", pl->x_tile_h);
+    }
+#undef FF_X_CASE
+    FF_HIP(hipGetLastError());
+    return FF_OK;
+}
+
+// Tiles of height h for the plan's shard.
+int upload_exact64_tiles(ff_plan *pl, int h, char *err, size_t errlen)
 {
     ff_plan_info &inf = pl->info;
     free_and_null(pl->d_xtiles);
     std::vector<Tile> tiles;
-    build_tiles(inf.n_samples, inf.row_begin, inf.row_end, X_TILE_I, X_TILE_J, false, &tiles);
+    build_tiles(inf.n_samples, inf.row_begin, inf.row_end, h, X_TILE_J, false, &tiles);
     inf.n_tiles = inf.n_items = (int64_t)tiles.size();
-    inf.elements = (double)tiles.size() * X_TILE_I * X_TILE_J * (double)inf.n_rows;
+    inf.elements = (double)tiles.size() * h * X_TILE_J * (double)inf.n_rows;
     std::vector<XTile> xt(tiles.size());
     for (size_t k = 0; k < tiles.size(); ++k) xt[k] = {tiles[k].i0, tiles[k].j0};
     // one wave per tile, 4 per block: a launch carries fewer than 2^32 threads
@@ -778,10 +811,71 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
                         xt.size(), ((size_t)1 << 26) - 1);
     pl->n_xtiles = (int)xt.size();
+    pl->x_tile_h = h;
     FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
     if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
     inf.n_wave_slots = (int64_t)xt.size();
     return FF_OK;
+}
+
+// The tile height is picked once per plan.  Every height gives every pair the same operations in the
+// same order; what differs is the number of waves and how their count divides into rounds of resident
+// waves (C3: 33.9 ms with 16 rows, 29.8 with 12; 2,500 samples x 20,000 leaves: 34.1 with 16, 27.2 with 10).
+// The default is 12 rows (the best or second best at the three shapes above); FF_X_TILE_H forces another,
+// and with FF_X_CALIBRATE=1 -- for a host that runs a plan many times -- a shard big enough for it to
+// matter (a quarter as many tiles of 16 rows as waves fit the device, or more) is timed with each height when it is
+// scheduled, results into a scratch array, and keeps the fastest (eleven extra launches at plan time).
+int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    if (pl->x_tile_h == 0) {
+        const int forced = env_int("FF_X_TILE_H", 0);
+        int h = X_TILE_H_DEFAULT;
+        for (int cand : X_TILE_HEIGHTS)
+            if (cand == forced) h = forced;
+        const int64_t n_slots = inf.slot_end - inf.slot_begin;
+        std::vector<Tile> probe;
+        build_tiles(inf.n_samples, inf.row_begin, inf.row_end, 16, X_TILE_J, false, &probe);
+        const bool big = (int64_t)probe.size() * 4 > (int64_t)inf.n_compute_units * 4 * 6 && inf.n_rows > 0;
+        if (!forced && big && env_int("FF_X_CALIBRATE", 0)) {
+            double *scratch = nullptr;
+            if (hipMalloc(&scratch, sizeof(double) * (size_t)std::max<int64_t>(n_slots, 1)) == hipSuccess) {
+                hipEvent_t e0, e1;
+                FF_HIP(hipEventCreate(&e0));
+                FF_HIP(hipEventCreate(&e1));
+                float best = 0;
+                bool warm = false;
+                for (int cand : X_TILE_HEIGHTS) {
+                    int rc = upload_exact64_tiles(pl, cand, err, errlen);
+                    if (rc == FF_OK && !warm) rc = launch_exact64(pl, nullptr, scratch, err, errlen);  // (clocks up)
+                    warm = true;
+                    for (int rep = 0; rep < 2 && rc == FF_OK; ++rep) {
+                        FF_HIP(hipEventRecord(e0, nullptr));
+                        rc = launch_exact64(pl, nullptr, scratch, err, errlen);
+                        FF_HIP(hipEventRecord(e1, nullptr));
+                        FF_HIP(hipEventSynchronize(e1));
+                        float ms = 0;
+                        FF_HIP(hipEventElapsedTime(&ms, e0, e1));
+                        if (rc == FF_OK && (best == 0 || ms < best)) {
+                            best = ms;
+                            h = cand;
+                        }
+                    }
+                    if (rc != FF_OK) {
+                        (void)hipFree(scratch);
+                        return rc;
+                    }
+                }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                (void)hipFree(scratch);
+            } else {
+                (void)hipGetLastError();  // (no room for the scratch array: the default height)
+            }
+        }
+        pl->x_tile_h = h;
+    }
+    return upload_exact64_tiles(pl, pl->x_tile_h, err, errlen);
 }
 
 // The queue of pairs to recompute exactly holds up to an eighth of the shard (at least 2^20);
@@ -1063,7 +1157,8 @@ int stage_for_exact64(StageCtx &x, char *err, size_t errlen)
     const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
     inf.ld = ld;
     inf.rows_padded = R;
-    const size_t dt_bytes = sizeof(double) * (size_t)std::max<int64_t>(R, 1) * (size_t)ld;
+    // (+ 16 values: a tile whose height does not divide 64 reads up to H - 1 operands past the last row's end)
+    const size_t dt_bytes = sizeof(double) * ((size_t)std::max<int64_t>(R, 1) * (size_t)ld + 16);
     inf.staged_bytes = (double)dt_bytes;
     FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
     FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
@@ -1267,16 +1362,9 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_audit_slots, pl->d_audit_exact, pl->n_audit, d_out, pl->d_refine_count);
     } else {
         if (timed) FF_HIP(hipEventRecord(ev0, st));
-        if (pl->n_xtiles > 0) {
-            const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
-            if (pl->weighted)
-                pair_exact64_kernel<true><<<dim3(nb), dim3(256), 0, st>>>(
-                    pl->d_DT, inf.ld, pl->d_len_rows ? pl->d_len_rows : pl->d_len, inf.n_rows, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
-                    inf.row_end, inf.slot_begin, d_out);
-            else
-                pair_exact64_kernel<false><<<dim3(nb), dim3(256), 0, st>>>(
-                    pl->d_DT, inf.ld, pl->d_len_rows ? pl->d_len_rows : pl->d_len, inf.n_rows, pl->d_xtiles, pl->n_xtiles, inf.row_begin,
-                    inf.row_end, inf.slot_begin, d_out);
+        {
+            const int rc = launch_exact64(pl, st, d_out, err, errlen);
+            if (rc != FF_OK) return rc;
         }
         if (timed) FF_HIP(hipEventRecord(ev1, st));
     }

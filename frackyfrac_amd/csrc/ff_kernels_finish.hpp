@@ -163,9 +163,13 @@ __global__ void refine_exact_kernel(const unsigned long long *__restrict__ refin
     }
 }
 
-// EXACT64: each lane owns the pairs (i0..i0+15, j0+lane) and walks every branch in
+// EXACT64: each lane owns the pairs (i0..i0+H-1, j0+lane) and walks every branch in
 // ascending id with the reference's operations.  Compiled with -ffp-contract=off.
-template <bool WEIGHTED>
+// The tile height H changes nothing in any pair's arithmetic; it sets how many waves a shard makes and how
+// many fit a SIMD (the row's H scalar operands cannot be prefetched, so a wave issues about a third of the
+// time and the kernel lives on occupancy): which H is fastest depends on how the shard's tiles divide
+// into rounds of resident waves, and the plan measures it (schedule_exact64).
+template <bool WEIGHTED, int H>
 __global__ __launch_bounds__(256)
 void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
                          const double *__restrict__ branch_len, int64_t n_branches,
@@ -177,21 +181,22 @@ void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
     const int t = blockIdx.x * 4 + wave;
     if (t >= n_tiles) return;
     const XTile tile = tiles[t];
-    double a[X_TILE_I], c[X_TILE_I];  // numer/denom, or result/common
+    double a[H], c[H];  // numer/denom, or result/common
 #pragma unroll
-    for (int r = 0; r < X_TILE_I; ++r) {
+    for (int r = 0; r < H; ++r) {
         a[r] = 0.0;
         c[r] = 0.0;
     }
     const double *pj = DT + tile.j0 + lane;
     const double *pi = DT + tile.i0;
-#pragma unroll 2
+    constexpr int ROWS_PER_TRIP = H <= 8 ? 4 : 2;  // (the trip's scalar operands must fit the SGPRs)
+#pragma unroll ROWS_PER_TRIP
     for (int64_t k = 0; k < n_branches; ++k) {
         const double l = branch_len[k];
         const double y = pj[k * ld];
         const double *row = pi + k * ld;
 #pragma unroll
-        for (int r = 0; r < X_TILE_I; ++r) {
+        for (int r = 0; r < H; ++r) {
             const double x = row[r];
             if (WEIGHTED) {
                 a[r] = a[r] + l * fabs(x - y);  // numer += treeDists[id] * |a-b|  (:191)
@@ -204,7 +209,7 @@ void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
     }
     const int64_t j = tile.j0 + lane;
 #pragma unroll
-    for (int r = 0; r < X_TILE_I; ++r) {
+    for (int r = 0; r < H; ++r) {
         const int64_t i = tile.i0 + r;
         if (i < row_begin || i >= row_end || j >= i) continue;
         const double d = WEIGHTED ? a[r] / c[r] : a[r] / (a[r] + c[r]);

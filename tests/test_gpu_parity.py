@@ -353,6 +353,34 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
         assert np.array_equal(got, want), env
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
+    """EXACT64's tile height (FF_X_TILE_H: 8..16 rows per wave; FF_X_CALIBRATE=1 times them at plan creation)
+    only changes which wave computes a pair: every pair still walks all branches in ascending id with the
+    reference's operations (unifrac.go:174-205), so all heights -- and the oracle -- agree bit for bit.  The
+    sample count is no multiple of any height, and large enough for the calibration to run."""
+    import torch
+    tree, ptr, idx, val = synth.make(2231, 120, 0.2, 23)
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=8)
+    for env in ({"FF_X_TILE_H": "8"}, {"FF_X_TILE_H": "10"}, {}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"},
+                {"FF_X_CALIBRATE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for rank, world in ((0, 1), (1, 3)):
+            plan = ff.Plan(nodes, weighted, precision="exact64", rank=rank, world=world)
+            out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+            plan.run(out.data_ptr())
+            torch.cuda.synchronize()
+            a, b = ff.shard_slots(2231, rank, world)
+            assert np.array_equal(out.cpu().numpy(), want[a:b], equal_nan=True), (env, rank, world)
+            plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_unweighted_mfma_five_digits_and_long_lengths():
     """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps)."""
     tree, ptr, idx, val = synth.make(130, 20, 0.3, 93)
