@@ -783,6 +783,7 @@ int launch_exact64(ff_plan *pl, hipStream_t st, double *d_out, char *err, size_t
                                                                          inf.slot_begin, d_out);                   \
         break;
     switch (pl->x_tile_h) {
+        FF_X_CASE(4)
         FF_X_CASE(8)
         FF_X_CASE(10)
         FF_X_CASE(12)
@@ -831,6 +832,18 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
     if (pl->x_tile_h == 0) {
         const int forced = env_int("FF_X_TILE_H", 0);
         int h = X_TILE_H_DEFAULT;
+        // A shard whose waves all fit the device at once is bound by one wave's chain of trips, not by the
+        // vector ALU: the lowest tile that still keeps them all resident (C2: 1.31 ms with 16 rows, 0.84 with 8,
+        // 0.56 with 4; 2 rows and 16 two-value scalar loads per trip are slower again: 0.75).
+        const int64_t resident = (int64_t)inf.n_compute_units * 4 * 8;
+        for (int cand : {4, 8}) {
+            std::vector<Tile> count;
+            build_tiles(inf.n_samples, inf.row_begin, inf.row_end, cand, X_TILE_J, false, &count);
+            if ((int64_t)count.size() <= resident) {
+                h = cand;
+                break;
+            }
+        }
         for (int cand : X_TILE_HEIGHTS)
             if (cand == forced) h = forced;
         const int64_t n_slots = inf.slot_end - inf.slot_begin;

@@ -189,7 +189,9 @@ void pair_exact64_kernel(const double *__restrict__ DT, int64_t ld,
     }
     const double *pj = DT + tile.j0 + lane;
     const double *pi = DT + tile.i0;
-    constexpr int ROWS_PER_TRIP = H <= 8 ? 4 : 2;  // (the trip's scalar operands must fit the SGPRs)
+    // (the trip's H x ROWS_PER_TRIP scalar operands must fit the SGPRs: 64 of them; a shard of few waves is bound by
+    // the chain of trips -- each waits out its loads -- so low tiles, many rows per trip, are what small problems want)
+    constexpr int ROWS_PER_TRIP = H <= 4 ? 8 : H <= 8 ? 4 : 2;
 #pragma unroll ROWS_PER_TRIP
     for (int64_t k = 0; k < n_branches; ++k) {
         const double l = branch_len[k];

@@ -20,7 +20,7 @@ constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
 constexpr int L_WAVES_PER_WG = 12;  // 768-thread workgroups of the LDS-staged pair kernel: three per SIMD
 constexpr int L_RING = 8;           // rows of its per-wave LDS ring (1 KiB each)
 // EXACT64 tile: H rows x 64 columns per wave, H one of these (picked per plan: ff_device.hip schedule_exact64)
-constexpr int X_TILE_HEIGHTS[] = {8, 10, 12, 14, 16};
+constexpr int X_TILE_HEIGHTS[] = {4, 8, 10, 12, 14, 16};
 constexpr int X_TILE_H_DEFAULT = 12;
 constexpr int X_TILE_J = 64;
 

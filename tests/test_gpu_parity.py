@@ -355,7 +355,7 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
 
 @pytest.mark.parametrize("weighted", [True, False])
 def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
-    """EXACT64's tile height (FF_X_TILE_H: 8..16 rows per wave; FF_X_CALIBRATE=1 times them at plan creation)
+    """EXACT64's tile height (FF_X_TILE_H: 4..16 rows per wave; FF_X_CALIBRATE=1 times them at plan creation)
     only changes which wave computes a pair: every pair still walks all branches in ascending id with the
     reference's operations (unifrac.go:174-205), so all heights -- and the oracle -- agree bit for bit.  The
     sample count is no multiple of any height, and large enough for the calibration to run."""
@@ -365,8 +365,8 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=8)
-    for env in ({"FF_X_TILE_H": "8"}, {"FF_X_TILE_H": "10"}, {}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"},
-                {"FF_X_CALIBRATE": "1"}):
+    for env in ({"FF_X_TILE_H": "4"}, {"FF_X_TILE_H": "8"}, {"FF_X_TILE_H": "10"}, {},
+                {"FF_X_TILE_H": "12"}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"}, {"FF_X_CALIBRATE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for rank, world in ((0, 1), (1, 3)):
