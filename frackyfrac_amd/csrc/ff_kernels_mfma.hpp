@@ -155,7 +155,8 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         const int nd = item.nd;
         const int nslab = (item.k1 - item.k0) / M_KSLAB;
         __builtin_assume(nslab >= M_QUAD_SLABS);  // (ff_schedule.cpp: whole quads of slabs, at least one)
-        // this lane's samples: rows `lane` and 64 + `lane` of the wave's 128 i-samples, row `lane` of its 64 j-samples
+        // this lane's samples: row lane & 31 of every 32-row block of the wave's 128 i-samples and 64 j-samples
+        // (without M_DIRECT_WORDS: rows `lane` and 64 + `lane`, and row `lane`)
         const int wlane = M_DIRECT_WORDS ? (lane & 31) : lane;
         const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + wlane;
         const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + wlane;
