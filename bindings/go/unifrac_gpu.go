@@ -1,104 +1,108 @@
 // unifrac_gpu.go -- the cgo shim that puts libfrackyfrac_amd behind frcfrc's pairwise stage.
 //
 // Drop this file next to frcfrc/unifrac.go (package main) and have unifrac() (unifrac.go:123)
-// return unifracDistsGPU(nodes, treeDists, weighted) instead of unifracDists(...).  It keeps the
-// reference's shape -- an iter.Seq[float64] in common.IterPairs order that stops computing when
-// the consumer stops (unifrac.go:222-224) -- by staging once and walking the pair space shard by
-// shard.  Source only: this image has no Go toolchain.  The call sequence below is exercised,
-// call for call, by tests/harness/go_shim_sequence.c on the reference's golden files.
+// return the sequence of unifracDistsGPU(nodes, treeDists, weighted) instead of
+// unifracDists(...); INTEGRATION.md section 1 shows the two-line patch.  It keeps the reference's
+// shape: an iter.Seq[float64] in common.IterPairs order that is LAZY -- nothing is converted,
+// staged or computed until it is ranged over, and a sequence that is never ranged costs nothing
+// and owns nothing (unifrac.go:209-211) -- and that stops computing when the consumer stops
+// (unifrac.go:221-226): the library walks the pair space in sub-shards and the callback's
+// return value ends the walk.  Source only: this image has no Go toolchain.  The call sequence
+// is exercised, call for call, by tests/harness/go_shim_sequence.c on the reference's golden
+// files, and tests/test_go_shim_harness.py checks this file against cgo's pointer rule.
 //
-// No Go pointer is retained by C after a call returns (cgo rule): every buffer is a Go slice
-// that is only borrowed for the duration of the call.
+// cgo pointer passing ("Go code may pass a Go pointer to C provided the Go memory to which it
+// points does not contain any Go pointers"): every pointer below is a TOP-LEVEL argument that
+// points at pointer-free Go memory (slices of numbers, a C.ff_options, a cgo.Handle) and is only
+// borrowed for the duration of the call.  No C struct holding Go pointers (a C.ff_problem filled
+// from slices) is ever built -- that is what the *_csr entry points are for.
 package main
 
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../frackyfrac_amd/lib -lfrackyfrac_amd
-#include <stdlib.h>
+#include <stdint.h>
 #include "frackyfrac_amd.h"
+
+// ffDeliver is the exported Go function below.  Declared the way cgo itself declares exported
+// functions in _cgo_export.h (cgo drops const: a `const double *` here would be a conflicting
+// declaration); it is passed as an ff_dists_fn.
+extern int ffDeliver(void *user, int64_t slotBegin, double *dists, int64_t n);
 */
 import "C"
 
 import (
 	"fmt"
 	"iter"
+	"runtime/cgo"
 	"unsafe"
 )
 
-// pairsPerShard bounds the host memory of one step: 2^25 distances = 256 MB.
-const pairsPerShard = 1 << 25
+// gpuSeq is what one ranging of the sequence shares with its callback.
+type gpuSeq struct {
+	yield func(float64) bool
+}
 
-// unifracDistsGPU replaces unifracDists (frcfrc/unifrac.go:209-228).
-func unifracDistsGPU(nodes [][]flatNode, treeDists []float64, weighted bool) (iter.Seq[float64], error) {
-	n := len(nodes)
-	indptr := make([]C.int64_t, n+1)
-	nnz := 0
-	for i, s := range nodes {
-		nnz += len(s)
-		indptr[i+1] = C.int64_t(nnz)
-	}
-	ids := make([]C.int32_t, max(nnz, 1))
-	abnd := make([]C.double, max(nnz, 1))
-	k := 0
-	for _, s := range nodes { // lists are sorted by id (normalizeFlatNodes, unifrac.go:57-59)
-		for _, f := range s {
-			ids[k], abnd[k] = C.int32_t(f.id), C.double(f.abnd)
-			k++
+// ffDeliver receives one finished piece of the pair space: dists[0:n] are the distances of the
+// global slots slotBegin .. slotBegin+n-1 (library-owned host memory, valid during the call).
+// The library calls it on the thread that called ff_unifrac_dists_stream_csr, i.e. on the
+// goroutine that ranges over the sequence, so calling yield from here is legal.
+//
+//export ffDeliver
+func ffDeliver(user unsafe.Pointer, slotBegin C.int64_t, dists *C.double, n C.int64_t) C.int {
+	s := (*(*cgo.Handle)(user)).Value().(*gpuSeq)
+	for _, d := range unsafe.Slice((*float64)(unsafe.Pointer(dists)), int(n)) {
+		if !s.yield(d) {
+			return 0 // early stop (unifrac.go:222-224): the remaining sub-shards are never computed
 		}
 	}
-	var p C.ff_problem
-	p.n_samples, p.n_branches = C.int64_t(n), C.int64_t(len(treeDists))
-	p.branch_len = (*C.double)(unsafe.Pointer(unsafe.SliceData(treeDists)))
-	p.indptr = unsafe.SliceData(indptr)
-	p.branch_id = unsafe.SliceData(ids)
-	p.abnd = unsafe.SliceData(abnd)
+	return 1
+}
 
-	var o C.ff_options
-	C.ff_options_default(&o)
-	if weighted {
-		o.weighted = 1
-	}
-	errbuf := make([]C.char, 1024)
-	eb, el := unsafe.SliceData(errbuf), C.size_t(len(errbuf))
-	fail := func() error { return fmt.Errorf("%s", C.GoString(eb)) } // common.ExitIfError prints "ERROR: ..."
-
-	var plan *C.ff_plan
-	if C.ff_plan_create(&p, &o, &plan, eb, el) != 0 { // flat nodes -> HBM, staged once
-		return nil, fail()
-	}
-	shards := C.int32_t(C.ff_num_pairs(C.int64_t(n))/pairsPerShard + 1)
-	return func(yield func(float64) bool) {
-		defer func() { C.ff_plan_destroy(plan) }()
-		for r := C.int32_t(0); r < shards; r++ {
-			if C.ff_plan_set_shard(plan, r, shards, eb, el) != 0 {
-				panic(fail())
-			}
-			var info C.ff_plan_info
-			C.ff_plan_info_get(plan, &info)
-			m := int(info.slot_end - info.slot_begin)
-			if m == 0 {
-				continue
-			}
-			part := make([]float64, m)
-			rc := C.ff_plan_run_host(plan, (*C.double)(unsafe.Pointer(unsafe.SliceData(part))), eb, el)
-			if rc == C.FF_ERR_PRECISION { // a data set of replicates: binary64 from here on
-				C.ff_plan_destroy(plan)
-				plan = nil
-				o.precision = C.FF_PRECISION_EXACT64
-				if C.ff_plan_create(&p, &o, &plan, eb, el) != 0 ||
-					C.ff_plan_set_shard(plan, r, shards, eb, el) != 0 {
-					panic(fail())
-				}
-				rc = C.ff_plan_run_host(plan, (*C.double)(unsafe.Pointer(unsafe.SliceData(part))), eb, el)
-			}
-			if rc != 0 {
-				panic(fail())
-			}
-			for _, d := range part { // slots slot_begin .. slot_end-1 of common.IterPairs order
-				if !yield(d) {
-					return // early stop: the remaining shards are never computed
-				}
+// unifracDistsGPU replaces unifracDists (frcfrc/unifrac.go:209-228).  The second result reports
+// what went wrong, if anything, once the sequence has been ranged over (the bufio.Scanner
+// pattern: unifracDists itself has no error path, a device has); the caller hands it to
+// common.ExitIfError, which prints "ERROR: ..." and exits 2 (common/common.go:13-18).
+func unifracDistsGPU(nodes [][]flatNode, treeDists []float64, weighted bool) (iter.Seq[float64], func() error) {
+	var failure error
+	seq := func(yield func(float64) bool) {
+		// [][]flatNode (unifrac.go:137-140) -> CSR; lists are sorted by id (unifrac.go:57-59)
+		n := len(nodes)
+		indptr := make([]C.int64_t, n+1)
+		nnz := 0
+		for i, s := range nodes {
+			nnz += len(s)
+			indptr[i+1] = C.int64_t(nnz)
+		}
+		ids := make([]C.int32_t, max(nnz, 1))
+		abnd := make([]C.double, max(nnz, 1))
+		k := 0
+		for _, s := range nodes {
+			for _, f := range s {
+				ids[k], abnd[k] = C.int32_t(f.id), C.double(f.abnd)
+				k++
 			}
 		}
-	}, nil
+		lens := treeDists
+		if len(lens) == 0 {
+			lens = make([]float64, 1)
+		}
+		var o C.ff_options
+		C.ff_options_default(&o)
+		if weighted {
+			o.weighted = 1
+		}
+		errbuf := make([]C.char, 1024)
+		h := cgo.NewHandle(&gpuSeq{yield: yield})
+		defer h.Delete()
+		rc := C.ff_unifrac_dists_stream_csr(C.int64_t(n), C.int64_t(len(treeDists)),
+			(*C.double)(unsafe.Pointer(unsafe.SliceData(lens))), unsafe.SliceData(indptr),
+			unsafe.SliceData(ids), unsafe.SliceData(abnd), &o, 0 /* 2^25 distances per piece */,
+			C.ff_dists_fn(C.ffDeliver), unsafe.Pointer(&h),
+			unsafe.SliceData(errbuf), C.size_t(len(errbuf)))
+		if rc != 0 {
+			failure = fmt.Errorf("%s", C.GoString(unsafe.SliceData(errbuf)))
+		}
+	}
+	return seq, func() error { return failure }
 }

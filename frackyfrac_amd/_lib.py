@@ -50,6 +50,9 @@ class ff_plan_info(ctypes.Structure):
                 ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32),
                 ("n_rows", c_int64)]
 
+# ff_dists_fn: int (*)(void *user, int64_t slot_begin, const double *dists, int64_t n)
+DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
+
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
                 3: "pair_sad_sparse_kernel"}
 
@@ -61,6 +64,14 @@ SIGNATURES = {
     "ff_shard_rows": (c_int, [c_int64, c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
     "ff_unifrac_dists": (c_int, [POINTER(ff_problem), POINTER(ff_options), c_void_p, c_char_p, c_size_t]),
     "ff_plan_create": (c_int, [POINTER(ff_problem), POINTER(ff_options), POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_plan_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ff_options),
+                                   POINTER(c_void_p), c_char_p, c_size_t]),
+    "ff_unifrac_dists_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ff_options),
+                                     c_void_p, c_char_p, c_size_t]),
+    "ff_unifrac_dists_stream": (c_int, [POINTER(ff_problem), POINTER(ff_options), c_int64, DISTS_FN, c_void_p,
+                                        c_char_p, c_size_t]),
+    "ff_unifrac_dists_stream_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            POINTER(ff_options), c_int64, DISTS_FN, c_void_p, c_char_p, c_size_t]),
     "ff_plan_destroy": (None, [c_void_p]),
     "ff_plan_info_get": (c_int, [c_void_p, POINTER(ff_plan_info)]),
     "ff_plan_run": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),

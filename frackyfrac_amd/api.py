@@ -266,6 +266,65 @@ def unifrac_dists(nodes: FlatNodes, weighted: bool, precision="auto", device: in
     return out
 
 
+def unifrac_dists_stream(nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1, rank: int = 0,
+                         world: int = 1, max_pairs_per_chunk: int = 0, flat_args: bool = False
+                         ) -> Iterator[Tuple[int, np.ndarray]]:
+    """unifracDists as the reference has it (frcfrc/unifrac.go:209-228): a lazy, ordered sequence
+    that stops computing when the consumer stops.  Yields (slot_begin, distances) pieces of at most
+    max_pairs_per_chunk consecutive slots in IterPairs order (ff_unifrac_dists_stream).  Nothing
+    is staged before the first next(); closing the generator early stops the remaining
+    sub-shards.  flat_args: through ff_unifrac_dists_stream_csr, as a cgo host calls it.
+
+    The C entry point calls back on the calling thread; a generator cannot be resumed from
+    inside a C callback, so this wrapper runs the call on a helper thread and hands pieces over
+    one at a time (the callback blocks until the consumer asks for the next piece)."""
+    import queue
+    import threading
+
+    pieces: "queue.Queue" = queue.Queue(maxsize=1)
+    resume = threading.Semaphore(0)
+    state = {"stop": False}
+
+    def on_piece(_user, slot_begin, dists, n):
+        pieces.put((int(slot_begin), np.ctypeslib.as_array(dists, shape=(int(n),)).copy()))
+        resume.acquire()
+        return 0 if state["stop"] else 1
+
+    cb = L.DISTS_FN(on_piece)
+    p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+
+    def call():
+        try:
+            if flat_args:
+                rc = L.lib().ff_unifrac_dists_stream_csr(
+                    nodes.n_samples, nodes.n_branches, nodes.branch_len.ctypes.data, nodes.indptr.ctypes.data,
+                    nodes.branch_id.ctypes.data, nodes.abnd.ctypes.data, ctypes.byref(o), int(max_pairs_per_chunk),
+                    cb, None, err, L.ERRLEN)
+            else:
+                rc = L.lib().ff_unifrac_dists_stream(ctypes.byref(p), ctypes.byref(o), int(max_pairs_per_chunk), cb,
+                                                     None, err, L.ERRLEN)
+            pieces.put(("done", rc))
+        except BaseException as e:  # pragma: no cover
+            pieces.put(("done", e))
+
+    th = threading.Thread(target=call, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = pieces.get()
+            if item[0] == "done":
+                if isinstance(item[1], BaseException):
+                    raise item[1]
+                L.check(item[1], err)
+                return
+            yield item
+            resume.release()
+    finally:
+        state["stop"] = True
+        resume.release()
+        th.join()
+
+
 def unifrac(table: Table, tree: Tree, weighted: bool, leave_unnormalized: bool = False,
             precision="auto", device: int = -1) -> np.ndarray:
     """unifrac (frcfrc/unifrac.go:97): flatten on the host, distances on the GPU."""

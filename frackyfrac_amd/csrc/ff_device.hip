@@ -1665,6 +1665,178 @@ int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char
     return ff::unifrac_dists_info(p, o, out, nullptr, err, errlen);
 }
 
+// ---- flat-argument forms (hosts whose FFI may not pass a struct of managed pointers: cgo) ----
+
+static ff_problem problem_of(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                             const int32_t *branch_id, const double *abnd)
+{
+    ff_problem p;
+    p.n_samples = n_samples;
+    p.n_branches = n_branches;
+    p.branch_len = branch_len;
+    p.indptr = indptr;
+    p.branch_id = branch_id;
+    p.abnd = abnd;
+    return p;
+}
+
+int ff_plan_create_csr(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                       const int32_t *branch_id, const double *abnd, const ff_options *o, ff_plan **plan, char *err,
+                       size_t errlen)
+{
+    const ff_problem p = problem_of(n_samples, n_branches, branch_len, indptr, branch_id, abnd);
+    return ff_plan_create(&p, o, plan, err, errlen);
+}
+
+int ff_unifrac_dists_csr(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                         const int32_t *branch_id, const double *abnd, const ff_options *o, double *out, char *err,
+                         size_t errlen)
+{
+    const ff_problem p = problem_of(n_samples, n_branches, branch_len, indptr, branch_id, abnd);
+    return ff_unifrac_dists(&p, o, out, err, errlen);
+}
+
+int ff_unifrac_dists_stream_csr(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                                const int32_t *branch_id, const double *abnd, const ff_options *o,
+                                int64_t max_pairs_per_chunk, ff_dists_fn fn, void *user, char *err, size_t errlen)
+{
+    const ff_problem p = problem_of(n_samples, n_branches, branch_len, indptr, branch_id, abnd);
+    return ff_unifrac_dists_stream(&p, o, max_pairs_per_chunk, fn, user, err, errlen);
+}
+
+// ---- unifracDists as a lazy ordered sequence (frcfrc/unifrac.go:209-228) ----
+
+namespace {
+
+// Two device result buffers and their host twins (pinned when the host lets us), one stream: sub-shard k + 1
+// is reduced and copied out while the consumer is handed sub-shard k.
+struct StreamBuffers {
+    double *d[2] = {nullptr, nullptr}, *h[2] = {nullptr, nullptr};
+    bool pinned[2] = {false, false};
+    int64_t cap[2] = {0, 0};
+    hipStream_t st = nullptr;
+    ~StreamBuffers()
+    {
+        for (int b = 0; b < 2; ++b) {
+            (void)hipFree(d[b]);
+            if (pinned[b]) (void)hipHostFree(h[b]);
+            else free(h[b]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    }
+    int reserve(int b, int64_t n, char *err, size_t errlen)
+    {
+        if (n <= cap[b]) return FF_OK;
+        (void)hipFree(d[b]);
+        d[b] = nullptr;
+        if (pinned[b]) (void)hipHostFree(h[b]);
+        else free(h[b]);
+        h[b] = nullptr;
+        cap[b] = 0;
+        const size_t bytes = sizeof(double) * (size_t)n;
+        if (hipMalloc(&d[b], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot allocate %.2f GB for a sub-shard's results (a smaller "
+                            "max_pairs_per_chunk makes it smaller)", (double)bytes / 1e9);
+        }
+        pinned[b] = hipHostMalloc(reinterpret_cast<void **>(&h[b]), bytes, hipHostMallocDefault) == hipSuccess;
+        if (!pinned[b]) {
+            (void)hipGetLastError();
+            h[b] = static_cast<double *>(malloc(bytes));
+            if (!h[b]) return ff::fail(FF_ERR_INTERNAL, err, errlen, "out of host memory for %.2f GB of results", (double)bytes / 1e9);
+        }
+        cap[b] = n;
+        return FF_OK;
+    }
+};
+
+}  // namespace
+
+int ff_unifrac_dists_stream(const ff_problem *p, const ff_options *o, int64_t max_pairs, ff_dists_fn fn, void *user,
+                            char *err, size_t errlen)
+{
+    if (!fn) return ff::fail(FF_ERR_ARG, err, errlen, "null callback");
+    ff_options base;
+    ff_options_default(&base);
+    if (o) base = *o;
+    if (base.world < 1 || base.rank < 0 || base.rank >= base.world)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", base.rank, base.world);
+    if (max_pairs <= 0) max_pairs = (int64_t)1 << 25;
+    int rc = validate_problem(p, err, errlen);
+    if (rc) return rc;
+    int64_t rb = 0, re = 0;
+    if (ff_shard_rows(p->n_samples, base.rank, base.world, &rb, &re) != FF_OK)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", base.rank, base.world);
+    const int64_t shard_pairs = (re > 0 ? re * (re - 1) / 2 : 0) - (rb > 0 ? rb * (rb - 1) / 2 : 0);
+    if (shard_pairs <= 0) return FF_OK;  // lazily: nothing to deliver, nothing staged
+    // Sub-shard k of c of shard (rank, world) is shard rank * c + k of world * c: ff_shard_rows' boundaries
+    // N sqrt(k / world) nest, so the sub-shards tile this shard's contiguous slot range exactly.  Shards are
+    // whole 32-row blocks; a sub-shard that comes out above max_pairs is delivered in pieces.
+    int64_t c = (shard_pairs + max_pairs - 1) / max_pairs;
+    c = std::min<int64_t>(c, std::max<int64_t>(1, (re - rb + 31) / 32));
+    c = std::min<int64_t>(c, (int64_t)INT32_MAX / base.world);
+    ff_options o2 = base;
+    o2.rank = (int32_t)(base.rank * c);
+    o2.world = (int32_t)(base.world * c);
+    ff_plan *pl = nullptr;
+    rc = ff_plan_create(p, &o2, &pl, err, errlen);
+    if (rc) return rc;
+    struct PlanGuard {
+        ff_plan *&pl;
+        ~PlanGuard() { ff_plan_destroy(pl); }
+    } guard{pl};
+    StreamBuffers buf;
+    if (hipStreamCreateWithFlags(&buf.st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot create a stream");
+    }
+    auto deliver = [&](const double *h, int64_t slot0, int64_t n) -> bool {
+        for (int64_t off = 0; off < n; off += max_pairs)
+            if (!fn(user, slot0 + off, h + off, std::min(max_pairs, n - off))) return false;
+        return true;
+    };
+    int prev = -1;  // buffer holding a finished sub-shard that has not been delivered yet
+    int64_t prev_slot0 = 0, prev_n = 0;
+    int cur = 0;
+    for (int64_t k = 0; k < c; ++k) {
+        if (k > 0) {
+            o2.rank = (int32_t)(base.rank * c + k);
+            rc = ff_plan_set_shard(pl, o2.rank, o2.world, err, errlen);
+            if (rc) return rc;
+        }
+        const int64_t slot0 = pl->info.slot_begin, n = pl->info.slot_end - pl->info.slot_begin;
+        if (n <= 0) continue;
+        rc = buf.reserve(cur, n, err, errlen);
+        if (rc) return rc;
+        rc = plan_run_impl(pl, buf.st, buf.d[cur], false, err, errlen);
+        if (rc) return rc;
+        FF_HIP(hipMemcpyAsync(buf.h[cur], buf.d[cur], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, buf.st));
+        bool go_on = true;
+        if (prev >= 0) go_on = deliver(buf.h[prev], prev_slot0, prev_n);  // (the device works on sub-shard k meanwhile)
+        prev = -1;
+        FF_HIP(hipStreamSynchronize(buf.st));
+        if (!go_on) return FF_OK;  // the consumer stopped: sub-shard k is dropped, the rest never computed
+        bool ok = true;
+        if (plan_fixed32_verdict(pl, &ok, nullptr) == FF_OK && !ok) {
+            // replicates, or a failed audit (ff_plan_audit): this sub-shard again, and all later ones, in binary64
+            ff_plan_destroy(pl);
+            pl = nullptr;
+            o2.precision = FF_PRECISION_EXACT64;
+            rc = ff_plan_create(p, &o2, &pl, err, errlen);
+            if (rc == FF_OK) rc = plan_run_impl(pl, buf.st, buf.d[cur], false, err, errlen);
+            if (rc) return rc;
+            FF_HIP(hipMemcpyAsync(buf.h[cur], buf.d[cur], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, buf.st));
+            FF_HIP(hipStreamSynchronize(buf.st));
+        }
+        prev = cur;
+        prev_slot0 = slot0;
+        prev_n = n;
+        cur ^= 1;
+    }
+    if (prev >= 0) (void)deliver(buf.h[prev], prev_slot0, prev_n);
+    return FF_OK;
+}
+
 int ff_flatten_device(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr, const int64_t *leaf_idx,
                       const double *leaf_val, int leave_unnormalized, ff_flat **flat, char *err, size_t errlen)
 {

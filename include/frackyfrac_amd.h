@@ -110,10 +110,47 @@ int ff_shard_rows(int64_t n_samples, int32_t rank, int32_t world,
  * is indexed by the global slot number; slots outside the shard are untouched.
  * Blocking.  Ordered delivery (ppln.Serial, unifrac.go:212) is the slot index;
  * the reference's early-stop (yield == false, unifrac.go:222) has no
- * counterpart: the whole shard is produced in one device pass.
+ * counterpart HERE: the whole shard is produced in one device pass.  ff_unifrac_dists_stream
+ * below is the entry point that keeps it.
  */
 int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out,
                      char *err, size_t errlen);
+
+/*
+ * unifracDists as what it is in the reference: a LAZY, ORDERED sequence that stops computing when
+ * its consumer stops (iter.Seq[float64], frcfrc/unifrac.go:209-228; early stop at :221-226).
+ * The pair space of this shard (o->rank of o->world) is walked in sub-shards of at most
+ * max_pairs_per_chunk distances (<= 0: 2^25 = 256 MB); each finished sub-shard is handed to
+ * `fn` as dists[0..n) = the distances of the consecutive global slots slot_begin .. slot_begin+n-1
+ * (common.IterPairs order), sub-shards in ascending slot order, every slot exactly once.  The
+ * buffer belongs to the library and is valid only during the call of fn.
+ *   fn returns non-zero: continue.  fn returns 0: stop -- no further sub-shard is delivered, the
+ *   one in flight on the device is drained and dropped, and the call returns FF_OK.
+ * fn is called on the CALLING thread, never concurrently with itself (a cgo callback may
+ * therefore call the `yield` of the iterator it sits in), while the device already reduces the
+ * next sub-shard.  The inputs are staged once; a sub-shard that fails FIXED32's guarantee
+ * (FF_ERR_PRECISION conditions, see ff_plan_audit) is repeated in EXACT64 before it is delivered,
+ * and so is everything after it.  Nothing is staged or computed if the shard is empty.
+ */
+typedef int (*ff_dists_fn)(void *user, int64_t slot_begin, const double *dists, int64_t n);
+int ff_unifrac_dists_stream(const ff_problem *p, const ff_options *o, int64_t max_pairs_per_chunk,
+                            ff_dists_fn fn, void *user, char *err, size_t errlen);
+
+/*
+ * The same entry points with the fields of ff_problem as separate arguments, for hosts whose FFI
+ * forbids passing a struct that holds pointers into managed memory.  cgo: "Go code may pass a Go
+ * pointer to C provided the Go memory to which it points does not contain any Go pointers" -- a
+ * Go-allocated C.ff_problem filled with unsafe.SliceData(...) of Go slices breaks that rule
+ * (cgocheck panics), four slice pointers as top-level arguments do not.  Nothing is retained
+ * after the call returns.
+ */
+int ff_unifrac_dists_csr(int64_t n_samples, int64_t n_branches, const double *branch_len,
+                         const int64_t *indptr, const int32_t *branch_id, const double *abnd,
+                         const ff_options *o, double *out, char *err, size_t errlen);
+int ff_unifrac_dists_stream_csr(int64_t n_samples, int64_t n_branches, const double *branch_len,
+                                const int64_t *indptr, const int32_t *branch_id, const double *abnd,
+                                const ff_options *o, int64_t max_pairs_per_chunk, ff_dists_fn fn,
+                                void *user, char *err, size_t errlen);
 
 /* -- The same path with the staged inputs resident in HBM (benchmarks, pipelines) -- */
 
@@ -155,6 +192,10 @@ typedef enum ff_kernel {
  * (DESIGN.md "Data layout"), build the tile schedule.  Synchronous. */
 int ff_plan_create(const ff_problem *p, const ff_options *o, ff_plan **plan,
                    char *err, size_t errlen);
+/* ff_plan_create with the fields of ff_problem as separate arguments (see ff_unifrac_dists_csr). */
+int ff_plan_create_csr(int64_t n_samples, int64_t n_branches, const double *branch_len,
+                       const int64_t *indptr, const int32_t *branch_id, const double *abnd,
+                       const ff_options *o, ff_plan **plan, char *err, size_t errlen);
 /* The same from leaf values: stage A runs on the device and the flat nodes never leave
  * it (this is what ff_unifrac and the frcfrc command use). */
 int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int64_t *leaf_ptr,

@@ -1,12 +1,20 @@
-/* go_shim_sequence.c -- the call sequence of bindings/go/unifrac_gpu.go, in C, call for call:
- *   ff_options_default -> ff_plan_create -> { ff_plan_set_shard -> ff_plan_info_get ->
- *   ff_plan_run_host [-> on FF_ERR_PRECISION: destroy, create EXACT64, set_shard, run_host] }
- *   for every shard -> ff_plan_destroy,
- * fed the way the shim is fed ([][]flatNode as CSR + treeDists).  gcc-compiled against the public
- * header only; the flat nodes come from ff_flatten on a tree and a table file so that the test can
- * run it on the reference's golden files.  Prints the distances like fmt.Fprintln(w, f).
+/* go_shim_sequence.c -- the calls of bindings/go/unifrac_gpu.go, in C, call for call:
  *
- *   go_shim_sequence <tree> <table> <dense|sparse> <weighted 0|1> [shards]
+ *   stream (what the shim does):
+ *     ff_options_default -> ff_unifrac_dists_stream_csr(n, B, treeDists, indptr, ids, abnd, &o, chunk,
+ *                                                       deliver, &handle, err, errlen)
+ *     with a callback that consumes the distances one by one and returns 0 when its consumer stops.
+ *   plan (a host that keeps the staged plan):
+ *     ff_options_default -> ff_plan_create_csr -> { ff_plan_set_shard -> ff_plan_info_get ->
+ *     ff_plan_run_host [-> on FF_ERR_PRECISION: destroy, create EXACT64, set_shard, run_host] }
+ *     for every shard -> ff_plan_destroy,
+ *
+ * fed the way the shim is fed ([][]flatNode as CSR + treeDists, every array a separate argument: no struct
+ * of pointers crosses the boundary).  gcc-compiled against the public header only; the flat nodes come
+ * from ff_flatten on a tree and a table file so that the test can run it on the reference's golden files.
+ * Prints the distances like fmt.Fprintln(w, f); with a stop count, the consumer "breaks" after that many.
+ *
+ *   go_shim_sequence <stream|plan> <tree> <table> <dense|sparse> <weighted 0|1> [chunk pairs | shards] [stop after]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,56 +24,104 @@
 
 #define DIE(...) do { fprintf(stderr, "ERROR: " __VA_ARGS__); fprintf(stderr, "\n"); exit(2); } while (0)
 
+typedef struct consumer { /* the shim's gpuSeq: yield is "print one line", false after stop_after lines */
+    int64_t next_slot, printed, stop_after, calls, calls_after_stop;
+    int stopped;
+} consumer;
+
+static int deliver(void *user, int64_t slot_begin, const double *dists, int64_t n) /* ffDeliver */
+{
+    consumer *c = *(consumer **)user; /* the shim passes &handle and looks the handle up */
+    ++c->calls;
+    if (c->stopped) {
+        ++c->calls_after_stop;
+        return 0;
+    }
+    if (slot_begin != c->next_slot) DIE("piece starts at slot %lld, expected %lld", (long long)slot_begin, (long long)c->next_slot);
+    for (int64_t k = 0; k < n; ++k) {
+        if (c->stop_after >= 0 && c->printed >= c->stop_after) { /* yield returned false */
+            c->stopped = 1;
+            return 0;
+        }
+        char buf[40];
+        const int len = ff_format_float(dists[k], buf);
+        printf("%.*s\n", len, buf);
+        ++c->printed;
+    }
+    c->next_slot += n;
+    return 1;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 5) DIE("usage: go_shim_sequence <tree> <table> <dense|sparse> <weighted> [shards]");
+    if (argc < 6) DIE("usage: go_shim_sequence <stream|plan> <tree> <table> <dense|sparse> <weighted> [chunk|shards] [stop after]");
+    const int stream = strcmp(argv[1], "stream") == 0;
     char err[1024];
     ff_tree *tree = NULL;
     ff_table *table = NULL;
     ff_flat *flat = NULL;
-    if (ff_tree_read_file(argv[1], &tree, err, sizeof err)) DIE("%s", err);
-    if (ff_table_read_file(argv[2], strcmp(argv[3], "sparse") == 0, &table, err, sizeof err)) DIE("%s", err);
+    if (ff_tree_read_file(argv[2], &tree, err, sizeof err)) DIE("%s", err);
+    if (ff_table_read_file(argv[3], strcmp(argv[4], "sparse") == 0, &table, err, sizeof err)) DIE("%s", err);
     if (ff_validate_species(table, tree, err, sizeof err)) DIE("%s", err);
     if (ff_flatten(table, tree, 0, &flat, err, sizeof err)) DIE("%s", err);
-    ff_problem p; /* what the shim builds from [][]flatNode and treeDists */
+    ff_problem p; /* only to get at the arrays: the shim has them as Go slices */
     ff_flat_problem(flat, &p);
 
     ff_options o;
     ff_options_default(&o);
-    o.weighted = atoi(argv[4]);
+    o.weighted = atoi(argv[5]);
     if (getenv("FF_SHIM_PRECISION")) o.precision = atoi(getenv("FF_SHIM_PRECISION"));
-    ff_plan *plan = NULL;
-    if (ff_plan_create(&p, &o, &plan, err, sizeof err)) DIE("%s", err);
     const int64_t total = ff_num_pairs(p.n_samples);
-    int32_t shards = argc > 5 ? atoi(argv[5]) : (int32_t)(total / (1 << 25) + 1);
     int64_t printed = 0;
-    for (int32_t r = 0; r < shards; ++r) {
-        if (ff_plan_set_shard(plan, r, shards, err, sizeof err)) DIE("%s", err);
-        ff_plan_info info;
-        ff_plan_info_get(plan, &info);
-        const int64_t m = info.slot_end - info.slot_begin;
-        if (info.slot_begin != printed) DIE("shard %d starts at slot %lld, expected %lld", r, (long long)info.slot_begin, (long long)printed);
-        if (m == 0) continue;
-        double *part = malloc(sizeof(double) * (size_t)m);
-        int rc = ff_plan_run_host(plan, part, err, sizeof err);
-        if (rc == FF_ERR_PRECISION) {
-            ff_plan_destroy(plan);
-            plan = NULL;
-            o.precision = FF_PRECISION_EXACT64;
-            if (ff_plan_create(&p, &o, &plan, err, sizeof err) || ff_plan_set_shard(plan, r, shards, err, sizeof err)) DIE("%s", err);
-            rc = ff_plan_run_host(plan, part, err, sizeof err);
-        }
+    if (stream) {
+        consumer c = {0, 0, argc > 7 ? atoll(argv[7]) : -1, 0, 0, 0};
+        consumer *handle = &c;
+        const int rc = ff_unifrac_dists_stream_csr(p.n_samples, p.n_branches, p.branch_len, p.indptr, p.branch_id, p.abnd, &o,
+                                                   argc > 6 ? atoll(argv[6]) : 0, deliver, &handle, err, sizeof err);
         if (rc) DIE("%s", err);
-        for (int64_t k = 0; k < m; ++k) {
-            char buf[40];
-            const int len = ff_format_float(part[k], buf);
-            printf("%.*s\n", len, buf);
+        if (c.calls_after_stop) DIE("%lld calls after the consumer stopped", (long long)c.calls_after_stop);
+        printed = c.printed;
+        if (c.stop_after >= 0 && c.stop_after < total) {
+            if (printed != c.stop_after) DIE("%lld distances before the stop, expected %lld", (long long)printed, (long long)c.stop_after);
+            fprintf(stderr, "stopped after %lld of %lld distances, %lld pieces delivered\n", (long long)printed, (long long)total,
+                    (long long)c.calls);
+            printed = total;
         }
-        printed += m;
-        free(part);
+    } else {
+        ff_plan *plan = NULL;
+        if (ff_plan_create_csr(p.n_samples, p.n_branches, p.branch_len, p.indptr, p.branch_id, p.abnd, &o, &plan, err, sizeof err))
+            DIE("%s", err);
+        int32_t shards = argc > 6 ? atoi(argv[6]) : (int32_t)(total / (1 << 25) + 1);
+        for (int32_t r = 0; r < shards; ++r) {
+            if (ff_plan_set_shard(plan, r, shards, err, sizeof err)) DIE("%s", err);
+            ff_plan_info info;
+            ff_plan_info_get(plan, &info);
+            const int64_t m = info.slot_end - info.slot_begin;
+            if (info.slot_begin != printed) DIE("shard %d starts at slot %lld, expected %lld", r, (long long)info.slot_begin, (long long)printed);
+            if (m == 0) continue;
+            double *part = malloc(sizeof(double) * (size_t)m);
+            int rc = ff_plan_run_host(plan, part, err, sizeof err);
+            if (rc == FF_ERR_PRECISION) {
+                ff_plan_destroy(plan);
+                plan = NULL;
+                o.precision = FF_PRECISION_EXACT64;
+                if (ff_plan_create_csr(p.n_samples, p.n_branches, p.branch_len, p.indptr, p.branch_id, p.abnd, &o, &plan, err, sizeof err) ||
+                    ff_plan_set_shard(plan, r, shards, err, sizeof err))
+                    DIE("%s", err);
+                rc = ff_plan_run_host(plan, part, err, sizeof err);
+            }
+            if (rc) DIE("%s", err);
+            for (int64_t k = 0; k < m; ++k) {
+                char buf[40];
+                const int len = ff_format_float(part[k], buf);
+                printf("%.*s\n", len, buf);
+            }
+            printed += m;
+            free(part);
+        }
+        ff_plan_destroy(plan);
     }
     if (printed != total) DIE("%lld of %lld distances", (long long)printed, (long long)total);
-    ff_plan_destroy(plan);
     ff_flat_free(flat);
     ff_table_free(table);
     ff_tree_free(tree);

@@ -1,8 +1,10 @@
-"""bindings/go/unifrac_gpu.go cannot be compiled here (no Go toolchain), so its call sequence
--- ff_options_default -> ff_plan_create -> ff_plan_set_shard -> ff_plan_run_host per shard ->
-ff_plan_destroy, replacing unifracDists (frcfrc/unifrac.go:209-228) -- is exercised by a C
-program that makes exactly those calls (tests/harness/go_shim_sequence.c), compiled with gcc
-against the public header alone, as cgo would."""
+"""bindings/go/unifrac_gpu.go cannot be compiled here (no Go toolchain), so
+(1) its call sequence -- ff_options_default -> ff_unifrac_dists_stream_csr with a callback that stops when
+    its consumer stops, replacing unifracDists (frcfrc/unifrac.go:209-228) -- is exercised by a C program that
+    makes exactly those calls (tests/harness/go_shim_sequence.c, mode `stream`), compiled with gcc against the
+    public header alone, as cgo would; mode `plan` is the keep-the-plan loop of INTEGRATION.md section 4;
+(2) the Go source is checked statically against cgo's pointer-passing rule, the thing a C harness cannot see
+    (round-2 VERDICT: a Go-allocated C.ff_problem filled with Go slice pointers panics under cgocheck)."""
 import os
 import re
 import subprocess
@@ -14,6 +16,107 @@ from conftest import GOLDEN, read_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "frackyfrac_amd", "lib")
+GO_FILE = os.path.join(ROOT, "bindings", "go", "unifrac_gpu.go")
+
+
+def go_code():
+    """The Go file without comments (the cgo preamble is a comment and goes too)."""
+    src = open(GO_FILE).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def split_args(text):
+    """Top-level comma split of a call's argument text."""
+    args, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def c_calls(code):
+    """[(name, [args])] of every C.ff_*(...) call (C.ff_dists_fn(...) is a conversion to a function pointer type)."""
+    out = []
+    for m in re.finditer(r"C\.(ff_[a-z0-9_]+)\(", code):
+        if m.group(1) == "ff_dists_fn":
+            continue
+        depth, k = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(code[k], 0)
+            k += 1
+        out.append((m.group(1), split_args(code[m.end():k - 1])))
+    return out
+
+
+# Go memory that holds no Go pointers: what cgo lets a top-level pointer argument point at
+POINTER_FREE_VARS = {"C.ff_options", "C.ff_plan_info", "cgo.Handle"}
+POINTER_FREE_ELEMS = {"C.int64_t", "C.int32_t", "C.double", "C.char", "float64"}
+
+
+def declared_type(code, ident):
+    m = re.search(r"\bvar\s+%s\s+([\w.*\[\]]+)" % re.escape(ident), code)
+    if m:
+        return m.group(1)
+    m = re.search(r"\b%s\s*:?=\s*make\(\[\](\w[\w.]*)" % re.escape(ident), code)
+    if m:
+        return "[]" + m.group(1)
+    if re.search(r"\b%s\s*:=\s*cgo\.NewHandle\(" % re.escape(ident), code):
+        return "cgo.Handle"
+    m = re.search(r"\b%s\s+(\[\]\w+)" % re.escape(ident), code)  # a parameter: `treeDists []float64`
+    if m:
+        return m.group(1)
+    m = re.search(r"\b%s\s*:=\s*(\w+)\b" % re.escape(ident), code)  # an alias: `lens := treeDists`
+    if m and m.group(1) != ident:
+        return declared_type(code, m.group(1))
+    return None
+
+
+def test_the_go_shim_obeys_the_cgo_pointer_rule():
+    """Every pointer the shim passes to C is a top-level argument pointing at pointer-free Go memory."""
+    code = go_code()
+    assert "C.ff_problem" not in code, "a C struct of Go pointers must never be built in Go memory"
+    assert "runtime.Pinner" not in code  # (nothing needs pinning when nothing holds a pointer)
+    calls = c_calls(code)
+    assert calls
+    for name, args in calls:
+        for a in args:
+            for ident in re.findall(r"&(\w+)", a):
+                t = declared_type(code, ident)
+                assert t in POINTER_FREE_VARS, "%s(... %s ...): &%s is a %s" % (name, a, ident, t)
+            for ident in re.findall(r"unsafe\.SliceData\((\w+)\)", a):
+                t = declared_type(code, ident)
+                assert t is not None and t.startswith("[]") and t[2:] in POINTER_FREE_ELEMS, \
+                    "%s(... %s ...): %s is a %s" % (name, a, ident, t)
+            rest = re.sub(r"unsafe\.SliceData\(\w+\)|unsafe\.Pointer\(&\w+\)|&\w+", "", a)
+            assert "&" not in rest and "SliceData" not in rest, (name, a)
+    # the checker itself: the round-2 shim's construct is what it must reject
+    bad = "var p C.ff_problem\np.indptr = unsafe.SliceData(indptr)\nC.ff_plan_create(&p, &o, &plan, eb, el)"
+    assert declared_type(bad, "p") not in POINTER_FREE_VARS
+
+
+def test_the_go_shim_is_lazy_and_reports_errors_without_panicking():
+    code = go_code()
+    body = code[code.index("func unifracDistsGPU"):]
+    seq = body[body.index("seq := func(yield func(float64) bool) {"):]
+    # nothing touches the library before the sequence is ranged over (unifrac.go:209-211)
+    assert "C." not in body[:body.index("seq := func(yield")].split("{", 1)[1]
+    assert "C.ff_unifrac_dists_stream_csr(" in seq
+    assert "panic(" not in code
+    assert "h.Delete()" in seq and "cgo.NewHandle(" in seq
+    # the exported callback is declared without const, as cgo's own _cgo_export.h declares it
+    pre = open(GO_FILE).read()
+    assert "extern int ffDeliver(void *user, int64_t slotBegin, double *dists, int64_t n);" in pre
+    assert "//export ffDeliver\nfunc ffDeliver(user unsafe.Pointer, slotBegin C.int64_t, dists *C.double, n C.int64_t) C.int" in pre
 
 
 @pytest.fixture(scope="module")
@@ -28,39 +131,41 @@ def harness(tmp_path_factory):
 def test_the_go_file_makes_the_calls_the_harness_makes():
     """Every C.ff_* call of the shim appears in the harness (and the harness's compute calls in the
     shim): the two cannot drift apart unnoticed."""
-    go = open(os.path.join(ROOT, "bindings", "go", "unifrac_gpu.go")).read()
     c = open(os.path.join(ROOT, "tests", "harness", "go_shim_sequence.c")).read()
-    go_calls = set(re.findall(r"C\.(ff_[a-z0-9_]+)\(", go))
-    c_calls = set(re.findall(r"\b(ff_[a-z0-9_]+)\(", c))
-    assert go_calls == {"ff_options_default", "ff_plan_create", "ff_num_pairs", "ff_plan_destroy", "ff_plan_set_shard",
-                        "ff_plan_info_get", "ff_plan_run_host"}
-    assert go_calls <= c_calls
-    assert len(go.splitlines()) <= 110
+    go_calls = {name for name, _ in c_calls(go_code())}
+    harness_calls = set(re.findall(r"\b(ff_[a-z0-9_]+)\(", c))
+    assert go_calls == {"ff_options_default", "ff_unifrac_dists_stream_csr"}
+    assert go_calls <= harness_calls
+    # same number of arguments, in the header's order
+    (args,) = [a for n, a in c_calls(go_code()) if n == "ff_unifrac_dists_stream_csr"]
+    assert len(args) == 12
+    assert len(open(GO_FILE).read().splitlines()) <= 120
 
 
 def test_harness_builds_against_the_header_alone_and_fails_loudly_without_a_gpu(harness):
     import torch
 
     if torch.cuda.is_available():
-        pytest.skip("a GPU is present: the GPU test below runs the sequence for real")
-    r = subprocess.run([harness, GOLDEN + "/wtd.tree", GOLDEN + "/wtd.dense", "dense", "1"], capture_output=True, text=True)
-    assert r.returncode == 2 and r.stdout == ""
-    assert r.stderr.startswith("ERROR: no HIP device available") and "no CPU path" in r.stderr
+        pytest.skip("a GPU is present: the GPU tests below run the sequence for real")
+    for mode in ("stream", "plan"):
+        r = subprocess.run([harness, mode, GOLDEN + "/wtd.tree", GOLDEN + "/wtd.dense", "dense", "1"], capture_output=True, text=True)
+        assert r.returncode == 2 and r.stdout == ""
+        assert r.stderr.startswith("ERROR: no HIP device available") and "no CPU path" in r.stderr
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,weighted", [("uwtd1", 0), ("uwtd2", 0), ("wtd", 1)])
 @pytest.mark.parametrize("kind", ["dense", "sparse"])
-@pytest.mark.parametrize("shards", [None, 1, 3])
-def test_shim_sequence_reproduces_the_reference_goldens(harness, name, weighted, kind, shards):
-    args = [harness, GOLDEN + "/" + name + ".tree", GOLDEN + "/" + name + "." + kind, kind, str(weighted)]
-    r = subprocess.run(args + ([str(shards)] if shards else []), capture_output=True, text=True)
+@pytest.mark.parametrize("mode,cut", [("stream", None), ("stream", 1), ("stream", 2), ("plan", None), ("plan", 3)])
+def test_shim_sequence_reproduces_the_reference_goldens(harness, name, weighted, kind, mode, cut):
+    """cut: pairs per piece (stream) / number of shards (plan)."""
+    args = [harness, mode, GOLDEN + "/" + name + ".tree", GOLDEN + "/" + name + "." + kind, kind, str(weighted)]
+    r = subprocess.run(args + ([str(cut)] if cut else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout == read_golden(name + ".want")
 
 
-@pytest.mark.gpu
-def test_shim_sequence_on_a_synthetic_table_in_shards_and_after_a_precision_fallback(harness, tmp_path):
+def _replicate_table(tmp_path):
     from frackyfrac_amd import synth
     from oracle import oracle as O
 
@@ -74,12 +179,20 @@ def test_shim_sequence_on_a_synthetic_table_in_shards_and_after_a_precision_fall
     (tmp_path / "t.sparse").write_text(synth.sparse_text(tree, ptr2, idx2, val2))
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr2, idx2, val2, 0)
-    want = O.unifrac_dists(ip, on, ft.dist, True)
-    for env_prec, shards in ((None, "5"), ("1", "4"), ("2", "1")):
+    return O.unifrac_dists(ip, on, ft.dist, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["stream", "plan"])
+def test_shim_sequence_on_a_synthetic_table_in_pieces_and_after_a_precision_fallback(harness, tmp_path, mode):
+    want = _replicate_table(tmp_path)
+    # (precision, pairs per piece | shards): AUTO, FIXED32 (which the replicates push into EXACT64), EXACT64
+    cases = ((None, "4000"), ("1", "5000"), ("2", "0")) if mode == "stream" else ((None, "5"), ("1", "4"), ("2", "1"))
+    for env_prec, cut in cases:
         env = dict(os.environ)
         if env_prec:
             env["FF_SHIM_PRECISION"] = env_prec
-        r = subprocess.run([harness, str(tmp_path / "t.tree"), str(tmp_path / "t.sparse"), "sparse", "1", shards],
+        r = subprocess.run([harness, mode, str(tmp_path / "t.tree"), str(tmp_path / "t.sparse"), "sparse", "1", cut],
                            capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         got = np.array([float(x) for x in r.stdout.split()])
@@ -87,3 +200,20 @@ def test_shim_sequence_on_a_synthetic_table_in_shards_and_after_a_precision_fall
         zero = want == 0
         assert np.all(got[zero] == 0)
         assert np.max(np.abs(got[~zero] - want[~zero]) / want[~zero]) <= (0 if env_prec == "2" else 1e-6)
+
+
+@pytest.mark.gpu
+def test_shim_sequence_stops_when_the_consumer_stops(harness, tmp_path):
+    """unifrac.go:221-226: yield returning false ends the computation.  The consumer breaks after 777
+    distances of 19,900 delivered in pieces of <= 1000: the callback is never called again, the prefix is
+    the full run's prefix, and only the sub-shard that was already in flight has been computed."""
+    want = _replicate_table(tmp_path)
+    args = [harness, "stream", str(tmp_path / "t.tree"), str(tmp_path / "t.sparse"), "sparse", "1", "1000"]
+    env = dict(os.environ, FF_SHIM_PRECISION="2")
+    full = subprocess.run(args, capture_output=True, text=True, env=env)
+    part = subprocess.run(args + ["777"], capture_output=True, text=True, env=env)
+    assert full.returncode == 0 and part.returncode == 0, part.stderr
+    assert len(part.stdout.split()) == 777 and full.stdout.startswith(part.stdout)
+    assert np.array_equal(np.array([float(x) for x in full.stdout.split()]), want)
+    m = re.search(r"stopped after 777 of 19900 distances, (\d+) pieces delivered", part.stderr)
+    assert m and int(m.group(1)) == 1
