@@ -192,6 +192,9 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     hbm = {"bound": "hbm", "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
     common = {"kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
+    # the binding floor of THIS launch (one rank's shard): its algorithmic work at the unit's peak
+    peak_ops = {2: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
+    common["floor_ms"] = (6.0 if info.kernel == 1 else 2.0) * B * shard_pairs / peak_ops * 1e3
     common.update(traffic or {"traffic": None})
     if info.kernel == 2:
         # unweighted on the matrix cores: one multiply-add per branch and pair is the
@@ -267,7 +270,19 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
     barrier(ctx)
     elapsed = time.perf_counter() - t0
     kernel_ms_total, launches = run.timing_collect()
+    per_rank = None
     if ctx.world > 1:
+        # what a post-mortem of the first multi-GPU run needs, from every rank: its own clock around the
+        # timed steps, its kernel's HIP-event time, how long its last slice took from "kernels done" to
+        # "in the root's array", what it computed and where
+        mine = {"rank": ctx.rank, "device": torch.cuda.get_device_name(ctx.local_rank), "local_rank": ctx.local_rank,
+                "pairs": int(run.n_slots), "elapsed_ms_per_step": elapsed / steps * 1e3,
+                "kernel_ms": kernel_ms_total / max(launches, 1), "launches": launches,
+                "exposed_gather_ms_last_step": run.exposed_gather_ms(),
+                "transport": run.transport, "transport_note": run.transport_note,
+                "ipc_probe_GBps": None if run.ipc_gbps in (None, float("inf")) else run.ipc_gbps}
+        per_rank = [None] * ctx.world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -295,9 +310,11 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
         if n_audit:
             entry["audit"] = {"pairs": n_audit, "failed": bad, "worst_rel_err": worst}
         if ctx.world > 1:
-            entry["gather"] = {"transport": run.transport, "ipc_probe_GBps_rank1": ctx.ipc_gbps_rank1(run)}
-    else:
-        ctx.ipc_gbps_rank1(run)
+            entry["gather"] = {"transport": run.transport, "fallback_reason": run.transport_note or None,
+                               "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "chunks": run.chunks, "ipc_probe_GBps_rank1": per_rank[1]["ipc_probe_GBps"],
+                               "exposed_ms_last_step_max": max(r["exposed_gather_ms_last_step"] for r in per_rank)}
+            entry["ranks"] = per_rank
     run.close()
     return entry
 
@@ -351,17 +368,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", ctx.local_rank))
 
-    def ipc_gbps_rank1(run):
-        """Rank 1's probe of the ipc transport (GB/s into the root's buffer), known on rank 0."""
-        if world == 1:
-            return None
-        box = [run.ipc_gbps if rank == 1 else None]
-        dist.broadcast_object_list(box, src=1)
-        v = box[0]
-        return None if v is None or v == float("inf") else v
-
-    ctx.ipc_gbps_rank1 = ipc_gbps_rank1
-
     # ---- primary: BASELINE's metric on its configuration --------------------------------
     from frackyfrac_amd import synth
 
@@ -396,7 +402,7 @@ def main():
                "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": primary["dtype"],
                "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if ctx.rehearse else ""),
                "config": primary["config"], "roofline": primary["roofline"]}
-        for k in ("audit", "gather"):
+        for k in ("audit", "gather", "ranks"):
             if k in primary:
                 out[k] = primary[k]
         if e2e is not None:

@@ -72,10 +72,8 @@ struct ff_plan {
     int64_t host_out_cap = 0;
     int n_workgroups = 0;
     int waves_per_wg = WAVES_PER_WG;
-    bool reg12 = false;          // 12 waves per workgroup: the register-buffered kernel with 2 x 4-row buffers (else the LDS-ring one)
     size_t lds_bytes = 0;
     unsigned long long *d_stamps = nullptr;  // FF_STAMPS=1 diagnostics
-    int sync_trips = 0;                      // workgroup barrier every this many loop trips (0 = never)
     // sparse-aware variant: activity bits per (i-block, 16-row trip)
     bool sparse = false;
     uint32_t *d_arows = nullptr, *d_aptr16 = nullptr, *d_cs16 = nullptr;
@@ -106,6 +104,7 @@ struct ff_plan {
     int n_ptiles = 0;
     bool m_all_private = false;  // every item has a private partial tile
     bool m_any_atomic = true;    // some item adds into num[] atomically: num[] has to be zero before a run
+    bool m_fused = false;        // the kernels that hold a slot's final sum write its distance (no num[] round trip, no finish launch)
     int n_mitems = 0, n_mgroups = 0;
     // EXACT64
     double *d_DT = nullptr;
@@ -162,9 +161,9 @@ template <typename T> struct Scratch {
 
 int env_int(const char *name, int dflt)
 {
-    const char *v = ff::tuning(name);
-    if (!v || !*v) return dflt;
-    return atoi(v);
+    const auto v = ff::tuning(name);
+    if (!v || v->empty()) return dflt;
+    return atoi(v->c_str());
 }
 
 int validate_problem(const ff_problem *p, char *err, size_t errlen)
@@ -394,7 +393,7 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
     FF_HIP(hipGetDevice(&pl->device));
     (void)hipGetLastError();  // a stale error of the caller's (or of a failed plan) is not ours
     FF_HIP(hipGetDeviceProperties(prop, pl->device));
-    if (strncmp(prop->gcnArchName, "gfx950", 6) != 0 && !ff::tuning("FF_ALLOW_ANY_ARCH"))
+    if (strncmp(prop->gcnArchName, "gfx950", 6) != 0)
         return ff::fail(FF_ERR_DEVICE, err, errlen, "device %d is %s; this engine is built for gfx950 only",
                         pl->device, prop->gcnArchName);
     pl->weighted = o->weighted != 0;
@@ -640,23 +639,19 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_num);
     free_and_null(pl->d_stamps);
     std::vector<Tile> tiles;
-    build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, env_int("FF_NARROW_TILES", 1) != 0, &tiles);
+    build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, true, &tiles);
     inf.n_tiles = (int64_t)tiles.size();
-    // 8 waves per workgroup for the register-buffered and the sparse-aware kernel, 12 for the
-    // three-waves-per-SIMD variants.  FF_WAVES_PER_WG / FF_REG12 force one; otherwise the 12-wave
-    // register variant (pair_sad_kernel12: a third wave per SIMD, paid for with half the vector
-    // prefetch) takes shards that fill its 12 x CUs wave slots for at least two whole rounds and whose
-    // matrix is small enough for four rows of prefetch -- measured: 16384 x 10k leaves (1.3 GB, 5.4
-    // rounds) 80.3 -> 77.3 ms; one round or less (4096 samples; an eighth of 16384) and the 3.3 GB
-    // matrix of 8192 x 50k leaves lose 1-2 % with it.
+    // 8 waves per workgroup (two per SIMD) for pair_sad_kernel and the sparse-aware kernel, 12 (three
+    // per SIMD, paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12
+    // forces one; otherwise the 12-wave variant takes shards that fill its 12 x CUs wave slots for at
+    // least two whole rounds and whose matrix is small enough for four rows of prefetch -- measured:
+    // 16384 x 10k leaves (1.3 GB, 5.4 rounds) 80.3 -> 77.3 ms; one round or less (4096 samples; an
+    // eighth of 16384) and the 3.3 GB matrix of 8192 x 50k leaves lose 1-2 % with it.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-    pl->reg12 = env_int("FF_REG12", 0) != 0;
-    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG") &&
-        inf.n_tiles >= 2 * (int64_t)pl->n_workgroups * L_WAVES_PER_WG && inf.staged_bytes <= 2.0e9) {
+    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() &&
+        inf.n_tiles >= 2 * (int64_t)pl->n_workgroups * L_WAVES_PER_WG && inf.staged_bytes <= 2.0e9)
         pl->waves_per_wg = L_WAVES_PER_WG;
-        pl->reg12 = true;
-    }
-    if (pl->waves_per_wg == L_WAVES_PER_WG) pl->lds_bytes = (size_t)L_WAVES_PER_WG * L_RING * 1024;
+    pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     const int U = pl->n_workgroups * pl->waves_per_wg;
     inf.n_wave_slots = U;
     std::vector<Item> items;
@@ -678,13 +673,13 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)pl->plane_stride * (size_t)pl->n_planes, "the pair accumulators");
     // slots of tiles that are not split that way are never written in planes 1..: zero once
     FF_HIP(hipMemset(pl->d_num, 0, sizeof(uint32_t) * (size_t)pl->plane_stride * (size_t)pl->n_planes));
+#ifdef FF_MFMA_DIAG  // (diagnostic build: per-wave clock stamps, tools/wave_stamps.py)
     if (env_int("FF_STAMPS", 0)) {
         FF_HIP(hipMalloc(&pl->d_stamps, sizeof(unsigned long long) * 4 * (size_t)U));
         FF_HIP(hipMemset(pl->d_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)U));
     }
+#endif
     if (pl->waves_per_wg == L_WAVES_PER_WG) {
-        FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_lds_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
         FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_sad_kernel12),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     } else if (pl->sparse) {
@@ -714,7 +709,7 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     std::vector<MItem> mi;
     std::vector<int32_t> mptr;
     std::vector<int32_t> ptiles, pptr;
-    const bool want_partials = env_int("FF_MFMA_PARTIALS", 1) != 0;
+    const bool want_partials = true;
     // Up to FF_MFMA_PRIVATE_MB of partial tiles (128 KiB each), every item gets its own: the kernel's
     // copy-out is then aligned 512-byte rows into a contiguous tile (2.8 us a tile at C3) instead of 4-byte
     // stores into rows of the triangle that start anywhere (12.8 us), and reduce_partials_kernel writes the
@@ -755,6 +750,14 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     for (const MItem &it : mi) {
         pl->m_all_private = pl->m_all_private && it.pad > 0;
         pl->m_any_atomic = pl->m_any_atomic || it.pad == 0;
+    }
+    // The matrix-core path can finish in place when every slot has exactly one writer (its tile's
+    // only item, or a reduce kernel): the integer sums then never go through num[], and there is
+    // neither a memset nor a finish launch.  FF_MFMA_FUSED_FINISH=1 / 0 forces either where possible;
+    // by default whenever every item owns a private partial tile.  Read here, once per schedule.
+    {
+        const int fuse_env = env_int("FF_MFMA_FUSED_FINISH", -1);
+        pl->m_fused = !pl->m_any_atomic && (fuse_env < 0 ? pl->m_all_private : fuse_env != 0);
     }
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
@@ -851,40 +854,42 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         build_tiles(inf.n_samples, inf.row_begin, inf.row_end, 16, X_TILE_J, false, &probe);
         const bool big = (int64_t)probe.size() * 4 > (int64_t)inf.n_compute_units * 4 * 6 && inf.n_rows > 0;
         if (!forced && big && env_int("FF_X_CALIBRATE", 0)) {
-            double *scratch = nullptr;
-            if (hipMalloc(&scratch, sizeof(double) * (size_t)std::max<int64_t>(n_slots, 1)) == hipSuccess) {
-                hipEvent_t e0, e1;
-                FF_HIP(hipEventCreate(&e0));
-                FF_HIP(hipEventCreate(&e1));
-                float best = 0;
-                bool warm = false;
-                for (int cand : X_TILE_HEIGHTS) {
-                    int rc = upload_exact64_tiles(pl, cand, err, errlen);
-                    if (rc == FF_OK && !warm) rc = launch_exact64(pl, nullptr, scratch, err, errlen);  // (clocks up)
-                    warm = true;
-                    for (int rep = 0; rep < 2 && rc == FF_OK; ++rep) {
-                        FF_HIP(hipEventRecord(e0, nullptr));
-                        rc = launch_exact64(pl, nullptr, scratch, err, errlen);
-                        FF_HIP(hipEventRecord(e1, nullptr));
-                        FF_HIP(hipEventSynchronize(e1));
-                        float ms = 0;
-                        FF_HIP(hipEventElapsedTime(&ms, e0, e1));
-                        if (rc == FF_OK && (best == 0 || ms < best)) {
-                            best = ms;
-                            h = cand;
-                        }
-                    }
-                    if (rc != FF_OK) {
-                        (void)hipFree(scratch);
-                        return rc;
+            // Anything that goes wrong here (no room for the scratch array, a failed launch or event) only
+            // costs the calibration: the plan keeps the default height.  Scratch and events are released on
+            // every path out.
+            Scratch<double> scratch;
+            struct Events {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                ~Events()
+                {
+                    if (e0) (void)hipEventDestroy(e0);
+                    if (e1) (void)hipEventDestroy(e1);
+                }
+            } ev;
+            bool ok = scratch.alloc((size_t)std::max<int64_t>(n_slots, 1)) == hipSuccess &&
+                      hipEventCreate(&ev.e0) == hipSuccess && hipEventCreate(&ev.e1) == hipSuccess;
+            float best = 0;
+            int best_h = h;
+            bool warm = false;
+            for (int cand : X_TILE_HEIGHTS) {
+                if (!ok) break;
+                ok = upload_exact64_tiles(pl, cand, err, errlen) == FF_OK;
+                if (ok && !warm) ok = launch_exact64(pl, nullptr, scratch.p, err, errlen) == FF_OK;  // (clocks up)
+                warm = true;
+                for (int rep = 0; rep < 2 && ok; ++rep) {
+                    float ms = 0;
+                    ok = hipEventRecord(ev.e0, nullptr) == hipSuccess &&
+                         launch_exact64(pl, nullptr, scratch.p, err, errlen) == FF_OK &&
+                         hipEventRecord(ev.e1, nullptr) == hipSuccess && hipEventSynchronize(ev.e1) == hipSuccess &&
+                         hipEventElapsedTime(&ms, ev.e0, ev.e1) == hipSuccess;
+                    if (ok && (best == 0 || ms < best)) {
+                        best = ms;
+                        best_h = cand;
                     }
                 }
-                (void)hipEventDestroy(e0);
-                (void)hipEventDestroy(e1);
-                (void)hipFree(scratch);
-            } else {
-                (void)hipGetLastError();  // (no room for the scratch array: the default height)
             }
+            if (ok) h = best_h;
+            else (void)hipGetLastError();
         }
         pl->x_tile_h = h;
     }
@@ -1021,15 +1026,15 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
     pl->m_digits = digits;
     inf.n_digits = digits;
     const int64_t n8 = round_up(N, M_TILE_I);
-    const int64_t ldb = round_up(std::max<int64_t>(R, 1), M_KSLAB * M_QUAD_SLABS);  // whole quads of slabs
-    const int64_t n_slabs = ldb / M_KSLAB;
+    const int64_t n_slabs = mfma_staged_slabs(R);  // whole quads of slabs
+    const int64_t ldb = n_slabs * M_KSLAB;
     pl->m_ldb = ldb;
     pl->m_n8 = n8;
     inf.ld = n8;
     inf.rows_padded = ldb;
     // (+ M_PAD_SLABS slabs of zeros behind both arrays: the kernel's prefetches run past an item's end)
-    const size_t bits_bytes = sizeof(unsigned long long) * (size_t)(n_slabs + M_PAD_SLABS) * (size_t)n8;
-    const size_t digit_bytes = (size_t)(ldb + M_PAD_SLABS * M_KSLAB) * (size_t)(digits + 1);  // (+1: a single-digit item reads its plane twice)
+    const size_t bits_bytes = sizeof(unsigned long long) * (size_t)mfma_alloc_slabs(R) * (size_t)n8;
+    const size_t digit_bytes = (size_t)(mfma_alloc_slabs(R) * M_KSLAB) * (size_t)(digits + 1);  // (+1: a single-digit item reads its plane twice)
     inf.staged_bytes = (double)bits_bytes + (double)digit_bytes;
     FF_ALLOC(pl->d_Pbits, bits_bytes, "the presence bits");
     FF_HIP(hipMalloc(&pl->d_Kd, digit_bytes));
@@ -1066,11 +1071,11 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
     const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
-    const int64_t rows = round_up(R, 2 * KSTEP);
+    const int64_t rows = sad_staged_rows(R);
     inf.ld = ld;
     inf.rows_padded = rows;
     inf.lengths_exact = weighted ? 0 : q.lengths_exact;
-    const size_t qt_bytes = sizeof(uint32_t) * (size_t)(rows + SLACK_ROWS) * (size_t)ld;
+    const size_t qt_bytes = sizeof(uint32_t) * (size_t)sad_alloc_rows(R) * (size_t)ld;
     inf.staged_bytes = (double)qt_bytes;
     FF_ALLOC(pl->d_QT, qt_bytes, "the staged branch x sample matrix");
     FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
@@ -1103,13 +1108,8 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     }
     klen.release();
     inf.scale_log2 = e;
-    int wgs_per_cu = env_int("FF_WGS_PER_CU", 1);
-    if (wgs_per_cu < 1) wgs_per_cu = 1;
-    if (wgs_per_cu > 2) wgs_per_cu = 2;
-    pl->n_workgroups = prop.multiProcessorCount * wgs_per_cu;
-    pl->sync_trips = env_int("FF_SYNC_TRIPS", 16);
-    // unused dynamic LDS sized so that exactly wgs_per_cu workgroups fit a CU
-    pl->lds_bytes = wgs_per_cu == 1 ? 96 * 1024 : 64 * 1024;
+    pl->n_workgroups = prop.multiProcessorCount;  // persistent: one workgroup per CU
+    pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     // activity of every (i-block, branch row): decides between the dense and the
     // sparse-aware kernel
     if (env_int("FF_SPARSE", 1) != 0 && rows > 0 && N > 0) {
@@ -1129,15 +1129,15 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
         const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
         const double inactive = 1.0 - (double)active / total;
-        const char *thr = ff::tuning("FF_SPARSE_MIN");
+        const auto thr = ff::tuning("FF_SPARSE_MIN");
         // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
         // prefetch, per-row address arithmetic), so it pays from about a quarter upwards
-        if (inactive >= (thr && *thr ? atof(thr) : 0.28)) {
+        if (inactive >= (thr && !thr->empty() ? atof(thr->c_str()) : 0.28)) {
             // per i-block: the list of active rows and, every 16 rows, where the list stands
             const int64_t marks = rows / (2 * KSTEP) + 1;
             pl->aptr_stride = marks;
             std::vector<uint32_t> arows, aptr((size_t)(n_iblocks * marks), 0u);
-            arows.reserve((size_t)active + 16);
+            arows.reserve((size_t)active + SPARSE_LIST_PAD);
             for (int64_t ib = 0; ib < n_iblocks; ++ib)
                 for (int64_t r = 0; r <= rows; ++r) {
                     if (r % (2 * KSTEP) == 0) aptr[(size_t)(ib * marks + r / (2 * KSTEP))] = (uint32_t)arows.size();
@@ -1145,7 +1145,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                 }
             if (arows.size() >= 0xFFFFFFF0ull)
                 return ff::fail(FF_ERR_INTERNAL, err, errlen, "active-row list too long");
-            arows.resize(arows.size() + 16, (uint32_t)rows);
+            arows.resize(arows.size() + SPARSE_LIST_PAD, (uint32_t)rows);  // (spare entries: the batch prefetch, ff_schedule.hpp)
             pl->zero_row = (int32_t)rows;  // first slack row: zero in every column
             FF_HIP(hipMalloc(&pl->d_arows, sizeof(uint32_t) * arows.size()));
             FF_HIP(hipMemcpy(pl->d_arows, arows.data(), sizeof(uint32_t) * arows.size(), hipMemcpyHostToDevice));
@@ -1170,8 +1170,8 @@ int stage_for_exact64(StageCtx &x, char *err, size_t errlen)
     const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
     inf.ld = ld;
     inf.rows_padded = R;
-    // (+ 16 values: a tile whose height does not divide 64 reads up to H - 1 operands past the last row's end)
-    const size_t dt_bytes = sizeof(double) * ((size_t)std::max<int64_t>(R, 1) * (size_t)ld + 16);
+    // (+ X_VALUES_PAD values: a tile whose height does not divide 64 reads up to H - 1 operands past the last row's end)
+    const size_t dt_bytes = sizeof(double) * ((size_t)std::max<int64_t>(R, 1) * (size_t)ld + X_VALUES_PAD);
     inf.staged_bytes = (double)dt_bytes;
     FF_ALLOC(pl->d_DT, dt_bytes, "the staged binary64 matrix");
     FF_HIP(hipMemset(pl->d_DT, 0, dt_bytes));
@@ -1310,15 +1310,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         fin.refine_cap = pl->refine_cap;
         fin.scale_log2 = inf.scale_log2;
         fin.weighted = pl->weighted;
-        // The matrix-core path can finish in place when every slot has exactly one writer (its tile's
-        // only item, or reduce_partials_kernel): the integer sums then never go through num[], and
-        // there is neither a memset nor a finish launch.  Worth it where launches are what a step
-        // costs -- a problem smaller than one round, all of whose items are private partials (C2:
-        // 0.049 -> 0.038 ms per step); at C3 the divisions and 8-byte stores cost the persistent
-        // kernel's epilogue almost what the separate, chip-wide finish launch costs (0.290 -> 0.282 ms
-        // per step), so full rounds keep it.  FF_MFMA_FUSED_FINISH=1 / 0 forces either where possible.
-        const int fuse_env = env_int("FF_MFMA_FUSED_FINISH", -1);
-        const bool fused = pl->mfma && !pl->m_any_atomic && (fuse_env < 0 ? pl->m_all_private : fuse_env != 0);
+        const bool fused = pl->mfma && pl->m_fused;  // (decided when the shard was scheduled: schedule_mfma)
         if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long) * 3, st));
         if (!fused && (!pl->mfma || pl->m_any_atomic))
             FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
@@ -1343,7 +1335,6 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 kern<<<dim3((unsigned)pl->n_mgroups), dim3(M_THREADS), pl->lds_bytes, st>>>(
                     reinterpret_cast<const uint4 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
                     pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, fused ? fin : none);
-            if (timed) FF_HIP(hipEventRecord(ev1, st));  // the timed region is the pair kernel alone
             if (pl->n_ptiles > 0 && pl->m_all_private)
                 reduce_private_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
                     pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_W, pl->d_num, inf.row_begin, inf.row_end,
@@ -1352,15 +1343,18 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 reduce_partials_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
                     pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_num, inf.row_begin, inf.row_end, inf.slot_begin,
                     fused ? fin : none);
+            // the timed region is the pair kernel AND the reduction of its partial tiles (sums, W_i + W_j,
+            // divisions: work that round 1's pair kernel did itself)
+            if (timed) FF_HIP(hipEventRecord(ev1, st));
         } else if (inf.n_items > 0 && pl->sparse)
             pair_sad_sparse_kernel<<<dim3((unsigned)pl->n_workgroups), dim3(WAVES_PER_WG * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_arows, pl->d_aptr16, pl->aptr_stride, pl->d_cs16,
                 pl->zero_row, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end, inf.slot_begin);
         else if (inf.n_items > 0)
-            (pl->waves_per_wg == L_WAVES_PER_WG ? (pl->reg12 ? pair_sad_kernel12 : pair_sad_lds_kernel) : pair_sad_kernel)
+            (pl->waves_per_wg == L_WAVES_PER_WG ? pair_sad_kernel12 : pair_sad_kernel)
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
-                inf.slot_begin, pl->d_stamps, pl->sync_trips);
+                inf.slot_begin, pl->d_stamps, SYNC_TRIPS);
         if (timed && !pl->mfma) FF_HIP(hipEventRecord(ev1, st));
         if (!fused) {
             const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 256 * FINISH_RUN - 1) / (256 * FINISH_RUN), 1 << 22);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <optional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,8 +36,9 @@ int read_all(const char *path, std::string *out, char *err, size_t errlen);
 unsigned clamp_threads(int requested);
 
 // A tuning switch (the FF_* names of INTEGRATION.md): the value given through ff_tune, else the
-// environment variable of that name, else null.  The pointer stays valid until the next ff_tune.
-const char *tuning(const char *name);
+// environment variable of that name, else nothing.  A copy: a concurrent ff_tune cannot invalidate it.
+// Switches are read when a plan is created or re-targeted, never on the launch path.
+std::optional<std::string> tuning(const char *name);
 
 // Runs fn(t, begin, end) over [0, n) split into contiguous chunks on `threads` threads.
 void parallel_for(int64_t n, unsigned threads,

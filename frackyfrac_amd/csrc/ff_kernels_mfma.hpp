@@ -42,10 +42,10 @@ typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 // slabs 2p and 2p + 1 -- so that one 16-byte load per lane fetches two slabs; the kernel's loop keeps four
 // pairs in flight.  An item is a whole number of M_QUAD_SLABS (ff_schedule.hpp: 4) slabs -- the branch rows are
 // zero padded to that -- and starts at a multiple of it.
-// Slabs of zero padding behind the staged arrays: the loop requests pair p + 4 when it is done with pair p,
-// and its prologue four pairs whatever the item's length: up to 8 slabs past an item's end are read.
-constexpr int M_PAD_SLABS = 12;
-static_assert(M_PAD_SLABS >= 8 && M_PAD_SLABS % 2 == 0, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
+// Slabs of zero padding behind the staged arrays (M_PAD_SLABS, ff_schedule.hpp): the loop requests pair
+// p + M_PAIRS_IN_FLIGHT when it is done with pair p, and its prologue that many pairs whatever the item's length:
+// up to M_SLABS_AHEAD = 8 slabs past an item's end are read.  The loop below is written for four buffers:
+static_assert(M_PAIRS_IN_FLIGHT == 4 && M_QUAD_SLABS == 4, "pair_common_mfma_kernel: four word buffers, k-steps in groups of a quad of slabs");
 #ifndef FF_MFMA_DIRECT_WORDS
 #define FF_MFMA_DIRECT_WORDS 1
 #endif

@@ -34,17 +34,17 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
 // cost 0.2 % and 1.5 %: more, shorter items).
 int xcd_slices()
 {
-    const char *e = ff::tuning("FF_XCD_SLICES");
-    const int v = e && *e ? atoi(e) : 2;
+    const auto e = ff::tuning("FF_XCD_SLICES");
+    const int v = e && !e->empty() ? atoi(e->c_str()) : 2;
     return v < 0 ? 0 : v;
 }
 
-// FF_WAVES_PER_WG: 12 = the pair kernel that stages its vector operand through LDS and so
-// fits three waves per SIMD; 8 = the register-buffered kernel with two.
+// FF_WAVES_PER_WG: 12 = pair_sad_kernel12, the pair kernel with half the vector buffers and so
+// three waves per SIMD; 8 = pair_sad_kernel with two.
 int waves_per_wg()
 {
-    const char *e = ff::tuning("FF_WAVES_PER_WG");
-    const int v = e && *e ? atoi(e) : WAVES_PER_WG;
+    const auto e = ff::tuning("FF_WAVES_PER_WG");
+    const int v = e && !e->empty() ? atoi(e->c_str()) : WAVES_PER_WG;
     return v == L_WAVES_PER_WG ? L_WAVES_PER_WG : WAVES_PER_WG;
 }
 
@@ -71,10 +71,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     // (one vector row of 1 KiB per branch for all 8 waves, through L1) and differ in their 32 rows
     // (8 x 128 B of scalar operands): 2 KiB per workgroup and branch instead of 8 KiB + 128 B with
     // row-block major order.  Measured: fabric traffic 280 -> 101 GB per launch at C4, 2.30 -> 2.09
-    // at C3, kernel times unchanged (FF_TILE_ORDER=row restores the old order).
-    const char *order = ff::tuning("FF_TILE_ORDER");
-    if (!(order && order[0] == 'r'))
-        std::stable_sort(wide.begin(), wide.end(), [](const Tile &a, const Tile &b) { return a.j0 < b.j0; });
+    // at C3, kernel times unchanged.
+    std::stable_sort(wide.begin(), wide.end(), [](const Tile &a, const Tile &b) { return a.j0 < b.j0; });
     const int64_t T = (int64_t)wide.size();
     std::vector<std::vector<Item>> per((size_t)U);
     auto push = [&](int u, const Tile &t, int64_t k0, int64_t k1) {
@@ -436,4 +434,18 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
     }
     memcpy(item_ptr_out, ptr.data(), sizeof(int32_t) * ptr.size());
     return n;
+}
+
+// Diagnostics / tests: the constants that tie the kernels' prefetch depths to the padding of the staged
+// arrays (ff_schedule.hpp), and the allocation sizes ff_device.hip derives from them for R staged rows.
+// out[0..15] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
+//               M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
+//               mfma_staged_slabs(R), mfma_alloc_slabs(R)}
+extern "C" void ff_debug_layout(int64_t R, int64_t *out)
+{
+    using namespace ff::sched;
+    const int64_t v[16] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
+                           M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
+                           mfma_staged_slabs(R), mfma_alloc_slabs(R)};
+    memcpy(out, v, sizeof v);
 }

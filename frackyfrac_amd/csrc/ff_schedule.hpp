@@ -17,12 +17,34 @@ constexpr int TILE_J = 256;   // columns: 4 per lane (one 16-byte load per lane 
 constexpr int KSTEP = 8;      // branch rows per vector buffer; the loop body covers 2*KSTEP rows
 constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefetch
 constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
-constexpr int L_WAVES_PER_WG = 12;  // 768-thread workgroups of the LDS-staged pair kernel: three per SIMD
-constexpr int L_RING = 8;           // rows of its per-wave LDS ring (1 KiB each)
+constexpr int L_WAVES_PER_WG = 12;  // 768-thread workgroups of pair_sad_kernel12 (half the vector buffers): three per SIMD
+constexpr int SYNC_TRIPS = 16;      // main-round items: a workgroup barrier every this many loop trips
 // EXACT64 tile: H rows x 64 columns per wave, H one of these (picked per plan: ff_device.hip schedule_exact64)
 constexpr int X_TILE_HEIGHTS[] = {4, 8, 10, 12, 14, 16};
 constexpr int X_TILE_H_DEFAULT = 12;
 constexpr int X_TILE_J = 64;
+
+// ---- How far past an item's end the kernels read, and the padding that covers it --------------------
+// Three kernels over-read BY DESIGN (their prefetches run ahead of the loop's exit test; what they fetch
+// past the end is zero padding or never used).  Every such distance is a constant here, next to the
+// padding that has to cover it, and the two are tied at compile time; the kernels static_assert their own
+// loop shape against the same constants, ff_device.hip sizes the allocations with the functions below, and
+// tests/test_schedule_cpu.py replays each kernel's address stream per item against those sizes.
+//   pair_sad_kernel / pair_sad_kernel12: the vector buffer refilled during an item's last trip holds the rows
+//   k1 .. k1 + KS - 1 (KS = KSTEP or KSTEP / 2 rows per buffer); the scalar operands stop at row k1.
+constexpr int SAD_ROWS_AHEAD = KSTEP;
+//   pair_sad_sparse_kernel: absent list entries are replaced by the FIRST slack row (all zero); row numbers
+//   are fetched in batches of four, two batches ahead: the trip at list position t < a1 reads entries up to t + 11.
+constexpr int SPARSE_LIST_AHEAD = 11;
+constexpr int SPARSE_LIST_PAD = 16;  // spare entries behind the active-row list
+static_assert(SLACK_ROWS >= SAD_ROWS_AHEAD && SLACK_ROWS >= 1, "the staged matrix's slack rows must cover the pair kernels' prefetch");
+static_assert(SPARSE_LIST_PAD > SPARSE_LIST_AHEAD, "the active-row list's spare entries must cover the batch prefetch");
+inline int64_t sad_staged_rows(int64_t R) { return round_up(R, 2 * KSTEP); }  // rows the items cover
+inline int64_t sad_alloc_rows(int64_t R) { return sad_staged_rows(R) + SLACK_ROWS; }
+//   pair_exact64_kernel<.., H>: a wave reads H consecutive operands from column i0 of every row; in the last
+//   row of the matrix that is up to H - 1 values past the end.
+constexpr int X_VALUES_PAD = 16;
+static_assert(X_VALUES_PAD >= X_TILE_HEIGHTS[sizeof(X_TILE_HEIGHTS) / sizeof(int) - 1] - 1, "EXACT64: padding behind the last row");
 
 struct Item {        // one unit of work for a persistent wave: a pair tile over a
     int32_t i0, j0;  // branch range [k0, k1)
@@ -46,6 +68,15 @@ constexpr int M_THREADS = 256; // one wave per SIMD (256 accumulator registers p
 constexpr int M_WGS_PER_CU = 1;
 constexpr int M_KSLAB = 64;    // branches per LDS slab (two K = 32 MFMA steps) = bits of a presence word
 constexpr int M_QUAD_SLABS = 4; // an item of pair_common_mfma_kernel is a whole number of these, and starts at one
+//   pair_common_mfma_kernel keeps M_PAIRS_IN_FLIGHT pairs of slabs of presence words in flight: its prologue
+//   requests that many pairs whatever the item's length, and the loop requests pair p + M_PAIRS_IN_FLIGHT when
+//   it is done with pair p: up to 2 * M_PAIRS_IN_FLIGHT slabs past an item's end are read (zeros).
+constexpr int M_PAIRS_IN_FLIGHT = 4;
+constexpr int M_SLABS_AHEAD = 2 * M_PAIRS_IN_FLIGHT;
+constexpr int M_PAD_SLABS = 12; // slabs of zero padding behind the presence words and the digit arrays
+static_assert(M_PAD_SLABS >= M_SLABS_AHEAD && M_PAD_SLABS % 2 == 0, "the prefetch of pair_common_mfma_kernel must stay inside the padding");
+inline int64_t mfma_staged_slabs(int64_t R) { return round_up(R > 0 ? R : 1, (int64_t)M_KSLAB * M_QUAD_SLABS) / M_KSLAB; }
+inline int64_t mfma_alloc_slabs(int64_t R) { return mfma_staged_slabs(R) + M_PAD_SLABS; }
 constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
 constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB, ff_kernels_mfma.hpp
                                                       // M_TABLE_SLABS), then the epilogue's 256 x 128 tile of 32-bit sums

@@ -179,9 +179,6 @@ struct Partial {
 int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_table **out, char *err, size_t errlen)
 {
     if (!text || !out) return ff::fail(FF_ERR_ARG, err, errlen, "ff_table_parse: null argument");
-    const bool trace = getenv("FF_TRACE_PARSE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double T0 = now();
     std::vector<LineRef> lines;
     {
         Lines ls{text, text + len};
@@ -217,7 +214,6 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
     unsigned nt = ff::clamp_threads(nthreads);
     if ((int64_t)nt > std::max<int64_t>(nrows, 1)) nt = (unsigned)std::max<int64_t>(nrows, 1);
     std::vector<Partial> parts(nt);
-    const double T1 = now();
     ff::parallel_for(nrows, nt, [&](unsigned tid, int64_t b, int64_t e) {
         Partial &pt = parts[tid];
         Row row;
@@ -236,7 +232,6 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
             pt.val.insert(pt.val.end(), row.val.begin(), row.val.end());
         }
     });
-    const double T2 = now();
     // the first failing row in row order wins, as with the reference's ordered pipeline
     for (const Partial &pt : parts)
         if (pt.err_code) {
@@ -257,7 +252,6 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
                 remap[q][k] = t->intern(pt.names[k].data(), pt.names[k].data() + pt.names[k].size());
         }
     }
-    const double T3 = now();
     t->key.resize(key_at.back());
     t->val.resize(key_at.back());
     t->ptr.resize(row_at.back() + 1);
@@ -277,9 +271,6 @@ int parse_table(const char *text, size_t len, bool sparse, int nthreads, ff_tabl
             }
         }
     });
-    if (trace)
-        fprintf(stderr, "parse_table: lines %.3f rows %.3f dict-merge %.3f copy %.3f s (threads %u)\n", T1 - T0, T2 - T1,
-                T3 - T2, now() - T3, nt);
     *out = t;
     return FF_OK;
 }

@@ -486,14 +486,14 @@ std::mutex g_tune_mu;
 std::unordered_map<std::string, std::string> g_tune;
 }  // namespace
 
-const char *ff::tuning(const char *name)
+std::optional<std::string> ff::tuning(const char *name)
 {
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune.find(name);
-        if (it != g_tune.end()) return it->second.c_str();
-    }
-    return getenv(name);
+    std::lock_guard<std::mutex> lk(g_tune_mu);  // (also serialises the getenv calls of this library)
+    auto it = g_tune.find(name);
+    if (it != g_tune.end()) return it->second;
+    const char *e = getenv(name);
+    if (e) return std::string(e);
+    return std::nullopt;
 }
 
 extern "C" int ff_tune(const char *name, const char *value)

@@ -29,6 +29,38 @@ import numpy as np
 from . import api
 
 
+def bounded_barrier(group=None, what: str = "a barrier", timeout_s: float = 120.0) -> None:
+    """dist.barrier that gives up: a peer that died (or never arrives) makes this rank raise after
+    timeout_s instead of hanging for the process group's own timeout (minutes to forever).  Used at
+    the set-up and tear-down points of the "ipc" transport, where a peer may have failed in code of
+    its own (mapping another process's memory); not on the data path."""
+    import time
+
+    import torch.distributed as dist
+
+    work = dist.barrier(group=group, async_op=True)
+    t0 = time.monotonic()
+    while not work.is_completed():
+        if time.monotonic() - t0 > timeout_s:
+            raise RuntimeError("frackyfrac_amd: rank %d waited %.0f s at %s; a peer is gone or stuck -- giving up "
+                               "(start the job again; FF_GATHER=nccl avoids the ipc set-up)"
+                               % (dist.get_rank(group), timeout_s, what))
+        time.sleep(0.002)
+    work.wait()
+
+
+def status_all(code: int, group=None, device=None) -> int:
+    """Largest `code` over all ranks (one all_reduce that every rank always reaches): 0 = fine,
+    1 = FIXED32's guarantee missed somewhere, 2 = some other error somewhere."""
+    import torch
+    import torch.distributed as dist
+
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    t = torch.tensor([int(code)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, full=None, group=None):
     """local: this rank's distances (torch tensor, shard_slots(n, rank, world) long).
     Returns on root the full [P] tensor (IterPairs order), on other ranks None."""
@@ -153,13 +185,15 @@ class ShardedRun:
 
     def __init__(self, nodes: api.FlatNodes, weighted: bool, rank: int, world: int,
                  precision="auto", device: Optional[int] = None, root: int = 0, group=None,
-                 chunks: Optional[int] = None, transport: Optional[str] = None):
+                 chunks: Optional[int] = None, transport: Optional[str] = None, ipc_timeout_s: float = 120.0):
         import os
 
         import torch
 
         self.torch = torch
         self.rank, self.world, self.root, self.group = rank, world, root, group
+        self.ipc_timeout_s = float(ipc_timeout_s)
+        self.gather_events = None  # (kernels done, slice delivered) of the last step, for exposed_gather_ms()
         self.n_samples = nodes.n_samples
         if not torch.cuda.is_available():
             raise RuntimeError("frackyfrac_amd: no GPU visible; the engine has no CPU path")
@@ -256,7 +290,7 @@ class ShardedRun:
             except Exception as e:  # noqa: BLE001
                 ok, note = False, "open/write: %r" % (e,)
         torch.cuda.synchronize(self.device)
-        dist.barrier(group=self.group)
+        bounded_barrier(self.group, "the ipc set-up (peers mapping the root's result array)", self.ipc_timeout_s)
         if self.rank == self.root and ok:
             torch.cuda.synchronize(self.device)
             for r in range(self.world):
@@ -281,7 +315,7 @@ class ShardedRun:
             if self.rank != self.root and b > a:
                 api.device_copy_async(self.remote.ptr + 8 * a, self.local.data_ptr(), 8 * (b - a), st)  # first touch
                 torch.cuda.synchronize(self.device)
-            dist.barrier(group=self.group)
+            bounded_barrier(self.group, "the ipc bandwidth probe", self.ipc_timeout_s)
             if self.rank != self.root and b > a:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -319,13 +353,14 @@ class ShardedRun:
         if self.copy_done[q] is not None:
             main.wait_event(self.copy_done[q])  # the copy that last read this buffer
         self.plan.run(self.locals[q].data_ptr(), main.cuda_stream, timed=timed)
-        ready = torch.cuda.Event()
+        ready = torch.cuda.Event(enable_timing=True)
         ready.record(main)
         self.side.wait_event(ready)
         api.device_copy_async(self.remote.ptr + 8 * a, self.locals[q].data_ptr(), 8 * (b - a), self.side.cuda_stream)
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=True)
         done.record(self.side)
         self.copy_done[q] = done
+        self.gather_events = (ready, done)
         return None
 
     def wait(self):
@@ -344,20 +379,36 @@ class ShardedRun:
         that all of them re-stage in EXACT64 together (unifrac_dists_sharded does)."""
         from ._lib import FF_ERR_PRECISION, FFError
 
-        self.torch.cuda.synchronize(self.device)
-        msg = ""
-        for p in self.plans:
-            try:
-                p.check_precision()
-            except FFError as e:
-                if e.code != FF_ERR_PRECISION:
-                    raise
-                msg = str(e)
+        msg, other = "", None
+        try:
+            self.torch.cuda.synchronize(self.device)
+            for p in self.plans:
+                try:
+                    p.check_precision()
+                except FFError as e:
+                    if e.code != FF_ERR_PRECISION:
+                        raise
+                    msg = str(e)
+        except Exception as e:  # noqa: BLE001 -- whatever happened here, the collective below must be reached
+            other = e
+        worst = 2 if other is not None else (1 if msg else 0)
         if self.world > 1:
-            if not self._flag_all(msg == ""):
-                raise FFError(FF_ERR_PRECISION, msg or "another rank's shard missed the FIXED32 tolerance")
-        elif msg:
-            raise FFError(FF_ERR_PRECISION, msg)
+            worst = status_all(worst, self.group, self.device)
+        if other is not None:
+            raise other
+        if worst == 2:
+            raise RuntimeError("frackyfrac_amd: another rank failed while checking its results")
+        if worst == 1:
+            raise FFError(FF_ERR_PRECISION, msg or "another rank's shard missed the FIXED32 tolerance")
+
+    def exposed_gather_ms(self) -> float:
+        """After wait(): how long the last step's slice took from "this rank's kernels are done" to "its
+        slice is in the root's array" -- the part of the gather no compute of THIS step hides (the next
+        step's kernels may still overlap it).  0 on the root and for world 1."""
+        if self.gather_events is None:
+            return 0.0
+        a, b = self.gather_events
+        return float(a.elapsed_time(b))
 
     @property
     def n_slots(self) -> int:
@@ -375,7 +426,15 @@ class ShardedRun:
         stream = torch.cuda.current_stream(self.device)
         if self.chunks == 1:
             self.plan.run(self.local.data_ptr(), stream.cuda_stream, timed=timed)
-            return gather_slices(self.local, self.n_samples, self.rank, self.world, self.root, self.full, self.group)
+            if self.world == 1:
+                return self.local
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record(stream)
+            res = gather_slices(self.local, self.n_samples, self.rank, self.world, self.root, self.full, self.group)
+            done = torch.cuda.Event(enable_timing=True)
+            done.record(stream)  # (the requests' wait() made this stream wait for the RCCL transfers)
+            self.gather_events = (ready, done)
+            return res
         def produce(c):
             self.plans[c].run(self.locals[c].data_ptr(), stream.cuda_stream, timed=timed)
             return self.locals[c]
@@ -397,16 +456,18 @@ class ShardedRun:
             self.remote.close()  # ff_ipc_close
         self.remote = None
 
-    def close(self):
+    def close(self, collective: bool = True):
         """Collective when the "ipc" transport is in use: every peer unmaps the root's array before
-        the root frees it."""
+        the root frees it.  The meeting is bounded (ipc_timeout_s), and a caller that is unwinding
+        from an error of its own passes collective=False: it must not wait for peers that may be
+        waiting for it somewhere else."""
         if getattr(self, "plans", None) is None:
             return
         if self.transport == "ipc":
-            import torch.distributed as dist
-
             self._drop_mapping()
-            dist.barrier(group=self.group)
+            if collective:
+                bounded_barrier(self.group, "the ipc tear-down (peers unmapping the root's result array)",
+                                self.ipc_timeout_s)
         if self._full_buf is not None:
             self.torch.cuda.synchronize(self.device)
             self.full = None
@@ -434,18 +495,35 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
 
         for attempt in (precision, "exact64"):
             run = ShardedRun(nodes, weighted, rank, world, precision=attempt, root=root, group=group)
+            # Every rank walks the same sequence of collectives whatever fails locally: local work
+            # (no collective inside a try that can be left early), then one joint status, then the joint
+            # precision verdict, then the collective close.
+            res, failure = None, None
             try:
                 res = run.step()
+                torch.cuda.synchronize(run.device)
+            except Exception as e:  # noqa: BLE001
+                failure = e
+            worst = status_all(2 if failure is not None else 0, group, run.device) if world > 1 else (2 if failure else 0)
+            if worst:
+                run.close(collective=world > 1 and failure is None)
+                raise failure if failure is not None else RuntimeError("frackyfrac_amd: another rank's step failed")
+            try:
                 run.wait()
                 run.check_precision()  # joint: raises on every rank or on none
-                return res.cpu().numpy() if res is not None else None
             except FFError as e:
+                run.close()
                 if e.code != FF_ERR_PRECISION or attempt == "exact64":
                     raise
                 # a shard somewhere holds mostly replicates (or failed its audit): every rank
                 # stages again in binary64, as ff_unifrac_dists does for one device
-            finally:
-                run.close()
+                continue
+            except Exception:
+                run.close(collective=False)
+                raise
+            out = res.cpu().numpy() if res is not None else None
+            run.close()
+            return out
     local = compute(nodes, weighted, rank, world)
     res = gather_slices(local, nodes.n_samples, rank, world, root, None, group)
     return res.numpy() if res is not None else None

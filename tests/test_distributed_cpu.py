@@ -168,3 +168,60 @@ def test_flat_nodes_of_sample_blocks_allgather_to_the_whole_table(world, n_sampl
         p.join(120)
         assert p.exitcode == 0
     assert all(q.get(timeout=5) for _ in range(world))
+
+
+def _worker_bounded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+
+    import torch.distributed as dist
+
+    from frackyfrac_amd.distributed import bounded_barrier, status_all
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank reaches the joint status whatever happened to it locally; the worst code wins everywhere
+    q.put(("status", rank, status_all(2 if rank == 1 else 0)))
+    q.put(("status", rank, status_all(1 if rank == 0 else 0)))
+    q.put(("status", rank, status_all(0)))
+    bounded_barrier(None, "a meeting everybody attends", 30.0)
+    if rank == 1:
+        q.close()
+        q.join_thread()
+        time.sleep(6.0)     # a peer that is stuck somewhere else: never arrives in time
+        os._exit(0)
+    t0 = time.monotonic()
+    try:
+        bounded_barrier(None, "the ipc set-up", 1.5)
+        q.put(("barrier", rank, "returned"))
+    except RuntimeError as e:
+        q.put(("barrier", rank, "%.1f %s" % (time.monotonic() - t0, e)))
+    q.close()
+    q.join_thread()
+    os._exit(0)  # (the group is broken by design: no orderly shutdown)
+
+
+def test_joint_status_and_bounded_barrier_gloo():
+    """The pieces that keep a failing rank from hanging the others (ShardedRun.check_precision,
+    unifrac_dists_sharded, the ipc set-up / tear-down): status_all is reached by every rank and returns the worst
+    code everywhere; bounded_barrier raises after its timeout when a peer does not come, instead of hanging."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bounded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = []
+    while not q.empty():
+        got.append(q.get(timeout=5))
+    status = sorted(x[1:] for x in got if x[0] == "status")
+    assert status == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]
+    (b,) = [x for x in got if x[0] == "barrier"]
+    assert b[1] == 0 and " s at the ipc set-up; a peer is gone or stuck" in b[2], b
+    assert float(b[2].split()[0]) < 5.0

@@ -33,6 +33,19 @@ def test_self_launch_runs_two_ranks_and_prints_one_line():
     assert out["gather"]["transport"] in ("ipc", "nccl")
     assert "REHEARSAL" in out["data"]
     assert out["roofline"]["launches"] == 3 and out["roofline"]["kernel_ms"] > 0
+    # what the first real multi-GPU run will need for a post-mortem: every rank's own figures, the transport
+    # that ran and why the other did not, the process group as the backend saw it
+    g = out["gather"]
+    assert g["backend"] == "gloo" and g["world_size"] == 2 and g["chunks"] == 1
+    assert (g["fallback_reason"] is None) == (g["transport"] == "ipc")
+    assert g["exposed_ms_last_step_max"] >= 0
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and sum(r["pairs"] for r in ranks) == 768 * 767 // 2
+    for r in ranks:
+        assert r["kernel_ms"] > 0 and r["launches"] == 3 and r["elapsed_ms_per_step"] >= r["kernel_ms"] * 0.5
+        assert r["transport"] == g["transport"] and "MI3" in r["device"]
+    assert ranks[0]["exposed_gather_ms_last_step"] == 0 or g["transport"] == "nccl"
+    assert out["roofline"]["floor_ms"] > 0 and out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"]
     # weak scaling: the sample count grows as sqrt(N), rounded to 32
     out, _ = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--workload",
                        "768x1500", "--no-cpu-baseline", "--no-secondary")

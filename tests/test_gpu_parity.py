@@ -347,7 +347,7 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
     want, info = run({"FF_UNWEIGHTED_MFMA": "0"})
     assert info.kernel in (0, 3)
     for env in ({}, {"FF_MFMA_PRIVATE_MB": "0"}, {"FF_MFMA_FUSED_FINISH": "0"},
-                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_PARTIALS": "0"}):
+                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_FUSED_FINISH": "0"}):
         got, info = run(env)
         assert info.kernel == 2 and info.n_digits == (3 if digits3 else 2) and info.n_tiles == 342
         assert np.array_equal(got, want), env
@@ -464,13 +464,13 @@ def test_tuning_switches_through_the_c_abi():
     nodes, ip, on, ft = synth_problem(700, 900, 0.1, 52)
     lib = L.lib()
     try:
-        assert lib.ff_tune(b"FF_WAVES_PER_WG", b"12") == 0 and lib.ff_tune(b"FF_REG12", b"1") == 0
+        assert lib.ff_tune(b"FF_WAVES_PER_WG", b"12") == 0
         plan = ff.Plan(nodes, True, precision="fixed32")
         assert plan.info.n_wave_slots == 12 * plan.info.n_compute_units
         got12 = plan.run_host()
         plan.close()
     finally:
-        assert lib.ff_tune(b"FF_WAVES_PER_WG", None) == 0 and lib.ff_tune(b"FF_REG12", None) == 0
+        assert lib.ff_tune(b"FF_WAVES_PER_WG", None) == 0
     plan = ff.Plan(nodes, True, precision="fixed32")
     assert plan.info.n_wave_slots == 8 * plan.info.n_compute_units
     assert np.array_equal(plan.run_host(), got12)
@@ -701,16 +701,14 @@ def test_c4_c5_full_size_sampled_parity(name):
     assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
 
 
-@pytest.mark.parametrize("reg12", ["0", "1"])
-def test_three_waves_per_simd_kernels_give_the_same_integers(monkeypatch, reg12):
-    """FF_WAVES_PER_WG=12 selects the 768-thread variants of the pair kernel (vector rows
-    staged through an LDS ring, or FF_REG12=1: 4-row register buffers): other schedule,
-    other data path, same sums -- bit-identical distances, weighted and unweighted."""
+def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
+    """FF_WAVES_PER_WG=12 selects the 768-thread variant of the pair kernel (pair_sad_kernel12: 4-row
+    register buffers, three waves per SIMD): other schedule, same sums -- bit-identical distances,
+    weighted and unweighted."""
     nodes, ip, on, ft = synth_problem(900, 2500, 0.1, 77)
     monkeypatch.setenv("FF_UNWEIGHTED_MFMA", "0")
     base = [ff.unifrac_dists(nodes, w, precision="fixed32") for w in (True, False)]
     monkeypatch.setenv("FF_WAVES_PER_WG", "12")
-    monkeypatch.setenv("FF_REG12", reg12)
     for w, want in zip((True, False), base):
         plan = ff.Plan(nodes, w, precision="fixed32")
         assert plan.info.n_wave_slots % 12 == 0 and plan.info.kernel == 0
@@ -996,3 +994,34 @@ def test_c3_unweighted_full_size_bit_exact_on_ranges():
     for a in (0, P // 4, P // 2, P - 250_000):
         want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 250_000)
         assert np.array_equal(got[a:a + 250_000], want)
+
+
+def test_remaining_schedule_and_audit_switches_are_bit_neutral(monkeypatch):
+    """FF_XCD_SLICES (how the main rounds pin branch slices to XCD groups: 0 = not at all, 2 default, 4, 8) changes
+    which wave sweeps which rows, never a sum; FF_AUDIT=0 drops the run-time audit (ff_plan_audit then reports
+    nothing checked) and changes no distance.  5,000 samples: two whole XCD-sliced rounds and a remainder."""
+    nodes, ip, on, ft = synth_problem(5000, 300, 0.15, 91)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    want = plan.run_host()
+    checked, failed, worst = plan.audit()
+    assert checked == 4096 and failed == 0 and 0 < worst <= 5e-7
+    items = plan.info.n_items
+    plan.close()
+    seen = {items}
+    for slices in ("0", "4", "8"):
+        monkeypatch.setenv("FF_XCD_SLICES", slices)
+        plan = ff.Plan(nodes, True, precision="fixed32")
+        seen.add(plan.info.n_items)
+        assert np.array_equal(plan.run_host(), want), slices
+        plan.close()
+    assert len(seen) >= 3  # (the switch did change the schedule)
+    monkeypatch.delenv("FF_XCD_SLICES")
+    monkeypatch.setenv("FF_AUDIT", "0")
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert np.array_equal(plan.run_host(), want)
+    assert plan.audit() == (0, 0, 0.0)
+    plan.close()
+    rng = np.random.default_rng(5)
+    for slot in rng.integers(0, len(want), size=40):
+        o = O.unifrac_dists(ip, on, ft.dist, True, pair_begin=int(slot), pair_end=int(slot) + 1)[0]
+        assert abs(want[slot] - o) <= WEIGHTED_RTOL * o

@@ -173,3 +173,138 @@ def test_mfma_rounds_do_not_mix_digit_groups_and_the_remainder_is_cut_by_cost():
     cost = np.array(cost)
     assert cost.max() - cost.min() <= 4 * 4 * 2                   # within two quads of slabs of each other
 
+
+
+# ---- Bounds: what the kernels' loops can touch, item by item, against what the engine allocates ----------------
+#
+# Three kernels over-read by design (their prefetches run ahead of the loop's exit test).  Each replay below
+# follows the kernel's own loop -- the order and the distance of its loads, nothing else -- and returns the
+# highest index it touches; the allocation sizes come from the functions ff_device.hip allocates with
+# (ff_debug_layout), so a change of prefetch depth, padding or item granularity on either side shows up here
+# on the CPU instead of as a page fault on the GPU (round 2: a 32-slab problem read one slab past Pbits).
+
+def layout(R):
+    fn = L.lib().ff_debug_layout
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+    v = np.zeros(16, dtype=np.int64)
+    fn(R, v.ctypes.data)
+    names = ("TILE_I TILE_J KSTEP SLACK_ROWS SAD_ROWS_AHEAD SPARSE_LIST_AHEAD SPARSE_LIST_PAD M_KSLAB M_QUAD_SLABS "
+             "M_PAIRS_IN_FLIGHT M_PAD_SLABS X_VALUES_PAD sad_staged_rows sad_alloc_rows mfma_staged_slabs mfma_alloc_slabs")
+    return dict(zip(names.split(), (int(x) for x in v)))
+
+
+def sad_item_reach(k0, k1, ks):
+    """run_item<NC, KS> (ff_kernels_pair_sad.hpp): (highest vector row, highest scalar row) read."""
+    hi_v = k0 + ks - 1                      # prologue: vA = rows k0 .. k0 + KS - 1
+    pv = k0 + ks
+    hi_s = k0                               # prologue: the scalars of row k0
+    nk = k1 - k0
+    assert nk % (2 * ks) == 0
+    for _k in range(0, nk, 2 * ks):
+        for _fill in ("vB", "vA"):          # FF_FILL in the first step of each half of the trip
+            hi_v = max(hi_v, pv + ks - 1)
+            pv += ks
+        hi_s += 2 * ks                      # every step fetches the next row's scalars
+    return hi_v, hi_s
+
+
+@pytest.mark.parametrize("n,R,n_cu", [(1, 1, 4), (33, 40, 4), (300, 3999, 8), (1000, 19999, 256), (4096, 19999, 256),
+                                      (700, 50, 256), (5000, 99999, 256), (16384, 19999, 256)])
+@pytest.mark.parametrize("wpw", ["8", "12"])
+def test_sad_items_stay_inside_the_staged_matrix(monkeypatch, n, R, n_cu, wpw):
+    monkeypatch.setenv("FF_WAVES_PER_WG", wpw)
+    lay = layout(R)
+    rows, alloc_rows = lay["sad_staged_rows"], lay["sad_alloc_rows"]
+    ld = (max(n, 1) + lay["TILE_J"] - 1) // lay["TILE_J"] * lay["TILE_J"]
+    ks = lay["KSTEP"] if wpw == "8" else lay["KSTEP"] // 2
+    fn = L.lib().ff_debug_schedule
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    cap = 1 << 21
+    items = np.zeros((cap, 8), dtype=np.int32)
+    ptr = np.zeros(n_cu * int(wpw) + 1, dtype=np.int32)
+    nt = ctypes.c_int64()
+    k = fn(0, n, rows, 0, n, n_cu, 2, 1, items.ctypes.data, cap, ptr.ctypes.data, ctypes.byref(nt))
+    assert k >= 0
+    worst_v = worst_s = -1
+    for i0, j0, k0, k1, flags, *_ in items[:k]:
+        hi_v, hi_s = sad_item_reach(int(k0), int(k1), ks)
+        worst_v, worst_s = max(worst_v, hi_v), max(worst_s, hi_s)
+        nc = 2 if flags & 4 else 4
+        assert j0 + nc * 63 + nc - 1 < ld and i0 + lay["TILE_I"] - 1 < ld     # columns: vector lanes, scalar operands
+    if k:
+        assert worst_v == rows + ks - 1 and worst_s == rows                    # (the model sees the over-read)
+        assert worst_v < alloc_rows and worst_s < alloc_rows
+    # the sparse-aware kernel replaces absent list entries by the first slack row
+    assert rows < alloc_rows
+
+
+def test_sparse_list_prefetch_stays_inside_the_spare_entries():
+    lay = layout(100)
+    pad = lay["SPARSE_LIST_PAD"]
+    rng = np.random.default_rng(1)
+    worst = 0
+    for _ in range(2000):
+        size = int(rng.integers(0, 200))
+        a0 = int(rng.integers(0, size + 1))
+        a1 = int(rng.integers(a0, size + 1))
+        for a0_, a1_ in ((a0, a1), (a0, size), (size, size), (max(size - 1, 0), size)):
+            # run_item_sparse: cur = batch(a0), nxt = batch(a0 + 4); every trip t < a1 (t += 4) reads batch(t + 8)
+            hi = a0_ + 7
+            t = a0_
+            while t < a1_:
+                hi = max(hi, t + 8 + 3)
+                t += 4
+            assert hi < size + pad, (size, a0_, a1_, hi)
+            worst = max(worst, hi - size)
+    assert worst == lay["SPARSE_LIST_AHEAD"] - 1  # reached: entries up to a1 + 10 when a1 = size
+
+
+def mfma_item_reach(k0, k1, lay, table_slabs=512):
+    """pair_common_mfma_kernel (ff_kernels_mfma.hpp): highest slab of presence words requested."""
+    ks = lay["M_KSLAB"]
+    assert k0 % (2 * ks) == 0 and (k1 - k0) % (lay["M_QUAD_SLABS"] * ks) == 0
+    nslab = (k1 - k0) // ks
+    hi_pair = -1
+    for seg in range(0, nslab, table_slabs):
+        nseg = min(table_slabs, nslab - seg)
+        pair = k0 // (2 * ks) + seg // 2            # qa: pair pointer of the segment
+        for _q in range(lay["M_PAIRS_IN_FLIGHT"]):  # prologue: four pairs whatever the length
+            hi_pair = max(hi_pair, pair)
+            pair += 1
+        sl = 0
+        while sl + 7 < nseg:                        # groups of eight slabs: one load_words per pair done
+            for _p in range(4):
+                hi_pair = max(hi_pair, pair)
+                pair += 1
+            sl += 8
+    return 2 * hi_pair + 1
+
+
+@pytest.mark.parametrize("n,R,n_cu,digits", [(5, 100, 8, 1), (300, 2047, 8, 2), (300, 2048, 8, 2), (300, 2049, 8, 2),
+                                             (1000, 19999, 256, 3), (4096, 19999, 256, 2), (512, 3999, 256, 2),
+                                             (777, 2500, 256, 5), (130, 39999, 256, 2), (2, 79999, 256, 2),
+                                             (4096, 99999, 256, 2)])
+def test_mfma_items_stay_inside_the_presence_words(n, R, n_cu, digits):
+    lay = layout(R)
+    slabs, alloc = lay["mfma_staged_slabs"], lay["mfma_alloc_slabs"]
+    items, ptr, n_tiles = schedule(2, n, slabs, 0, n, n_cu, digits=digits)
+    n8 = (n + 255) // 256 * 256
+    worst = -1
+    for i0, j0, k0, k1, d0, nd, first, _ in items:
+        worst = max(worst, mfma_item_reach(int(k0), int(k1), lay))
+        assert i0 + 255 < n8 and j0 + 127 < n8
+    assert worst >= slabs                      # (the model sees the over-read: the prologue alone passes a short item's end)
+    assert worst <= slabs + 2 * lay["M_PAIRS_IN_FLIGHT"] - 1
+    assert worst < alloc
+
+
+def test_exact64_operands_past_the_last_row_are_padded():
+    lay = layout(10)
+    for h in (4, 8, 10, 12, 14, 16):
+        for n in (1, 63, 64, 65, 1000, 4096):
+            ld = (n + 63) // 64 * 64
+            i0_max = (n - 1) // h * h          # build_tiles: i0 = multiples of h below the shard's end
+            assert i0_max + h - 1 < ld + lay["X_VALUES_PAD"]

@@ -1,6 +1,9 @@
-"""Diagnostics: distribution of per-wave run times of pair_sad_kernel (FF_STAMPS=1)."""
+"""Diagnostics: distribution of per-wave run times of pair_sad_kernel.  The stamps are only armed in the
+diagnostic build of the library (make -C frackyfrac_amd/csrc diag; FF_STAMPS=1 is read by that build alone)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FF_LIB_PATH", os.path.join(ROOT, "frackyfrac_amd", "lib", "libfrackyfrac_amd_diag.so"))
 os.environ["FF_STAMPS"] = "1"
 import numpy as np, torch
 import frackyfrac_amd as ff
