@@ -193,10 +193,10 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
     common = {"kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
     # the binding floor of THIS launch (one rank's shard): its algorithmic work at the unit's peak
-    peak_ops = {2: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
+    peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
     common["floor_ms"] = (6.0 if info.kernel == 1 else 2.0) * B * shard_pairs / peak_ops * 1e3
     common.update(traffic or {"traffic": None})
-    if info.kernel == 2:
+    if info.kernel in (2, 4):
         # unweighted on the matrix cores: one multiply-add per branch and pair is the
         # algorithmic work (the base-128 digit passes are the implementation's)
         achieved = 2.0 * B * shard_pairs / sec / 1e12
@@ -235,9 +235,12 @@ def traffic_of(name, world, info, weighted):
     return None
 
 
-def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
+def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
     """Stages the problem on this rank, runs `warmup` untimed and `steps` timed steps, returns
-    rank 0's entry (None on other ranks)."""
+    rank 0's entry (None on other ranks).  event_every: the HIP-event pair that times the dominant kernel
+    brackets every launch (1) or every event_every-th launch of the timed region -- for steps of a few
+    microseconds, where two event records per launch cost as much as the launch itself (C2: 6.4 us per step
+    without them, about 10 with)."""
     import frackyfrac_amd as ff
     from frackyfrac_amd.distributed import ShardedRun
 
@@ -265,8 +268,8 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
     run.timing_collect()
     t0 = time.perf_counter()
     res = None
-    for _ in range(steps):
-        res = run.step(timed=True)
+    for k in range(steps):
+        res = run.step(timed=(k % event_every == 0))
     barrier(ctx)
     elapsed = time.perf_counter() - t0
     kernel_ms_total, launches = run.timing_collect()
@@ -298,7 +301,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
         n_audit, bad, worst = run.plan.audit()
         entry = {"value": P / (elapsed / steps), "unit": "pairs/s", "steps": steps, "warmup": warmup,
                  "ms_per_step": elapsed / steps * 1e3,
-                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8"}[int(info.kernel)],
+                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8"}[int(info.kernel)],
                  "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
                                         "leaf density %.2f, seed 0x%X" %
                                         (cfg["name"], n_samples, cfg["n_leaves"], B,
@@ -307,6 +310,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup):
                             "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (ctx.world, run.transport)},
                  "roofline": roofline_of(info, B, n_samples, run.n_slots, kernel_ms, launches, weighted,
                                          traffic_of(cfg["name"], ctx.world, info, weighted))}
+        entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region
         if n_audit:
             entry["audit"] = {"pairs": n_audit, "failed": bad, "worst_rel_err": worst}
         if ctx.world > 1:
@@ -416,11 +420,11 @@ def main():
         k, w = max(1, min(args.secondary_steps, args.steps)), 1
         if world == 1:
             sec.append(measure(ctx, cfg, nodes, True, "exact64", k, w))       # the reference-width figure
-            sec.append(measure(ctx, cfg, nodes, False, "fixed32", max(k, args.steps), w))  # int8 matrix cores
+            sec.append(measure(ctx, cfg, nodes, False, "fixed32", max(k, args.steps), w, event_every=8))  # int8 matrix cores
             del nodes
-            for wl, wtd, steps in (("C2", False, max(k, args.steps)), ("C4", True, k), ("C5", True, k)):
+            for wl, wtd, steps, every in (("C2", False, max(k, args.steps), 8), ("C4", True, k, 1), ("C5", True, k, 1)):
                 c2, n2 = make_problem(ctx, wl)
-                sec.append(measure(ctx, c2, n2, wtd, "fixed32", steps, w))
+                sec.append(measure(ctx, c2, n2, wtd, "fixed32", steps, w, event_every=every))
                 del n2
         else:
             del nodes

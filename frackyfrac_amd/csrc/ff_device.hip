@@ -46,6 +46,7 @@ using namespace ff::sched;
 #include "ff_kernels_pair_sad.hpp"
 #include "ff_kernels_finish_pair.hpp"
 #include "ff_kernels_mfma.hpp"
+#include "ff_kernels_mfma_small.hpp"
 #include "ff_kernels_stage_a.hpp"
 #include "ff_kernels_finish.hpp"
 
@@ -106,6 +107,9 @@ struct ff_plan {
     bool m_any_atomic = true;    // some item adds into num[] atomically: num[] has to be zero before a run
     bool m_fused = false;        // the kernels that hold a slot's final sum write its distance (no num[] round trip, no finish launch)
     int n_mitems = 0, n_mgroups = 0;
+    bool m_small = false;        // a shard smaller than one round: pair_common_small_kernel, one launch per pass
+    STile *d_stiles = nullptr;
+    int n_stiles = 0;
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -363,6 +367,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_partial);
     (void)hipFree(pl->d_ptiles);
     (void)hipFree(pl->d_ptile_ptr);
+    (void)hipFree(pl->d_stiles);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_len_rows);
@@ -702,10 +707,55 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_partial);
     free_and_null(pl->d_ptiles);
     free_and_null(pl->d_ptile_ptr);
+    free_and_null(pl->d_stiles);
     pl->n_ptiles = 0;
+    pl->m_small = false;
+    pl->n_stiles = 0;
+    pl->n_mitems = 0;
     const int64_t slabs = pl->m_ldb / M_KSLAB;
     const int G = inf.n_compute_units * M_WGS_PER_CU;  // one 8-wave workgroup per CU
     pl->n_mgroups = G;
+    {
+        // A shard with fewer 256 x 128 tiles than workgroups is all "remainder" for the persistent kernel --
+        // every tile cut into branch ranges that each pay its 10 us of prologue and write-out, plus a reduce
+        // launch.  Below S_MAX_WORK (32 x 32 tiles x k-steps; calibrated with tools/mfma_small_sweep.py) such a
+        // shard takes pair_common_small_kernel instead: one 32 x 32 tile per workgroup over all branches, the
+        // sum over the waves' ranges and the division inside the same launch.  FF_MFMA_SMALL=1 / 0 forces.
+        std::vector<STile> st;
+        for (int64_t i0 = inf.row_begin / S_TILE * S_TILE; i0 < inf.row_end; i0 += S_TILE) {
+            const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + S_TILE, inf.row_end) - 1, N);  // valid columns: j < w
+            for (int64_t j0 = 0; j0 < w; j0 += S_TILE) st.push_back({(int32_t)i0, (int32_t)j0});
+        }
+        int64_t big_tiles = 0;
+        for (int64_t i0 = inf.row_begin / M_TILE_I * M_TILE_I; i0 < inf.row_end; i0 += M_TILE_I)
+            big_tiles += (std::min<int64_t>(std::min<int64_t>(i0 + M_TILE_I, inf.row_end) - 1, N) + M_TILE_J - 1) / M_TILE_J;
+        const int force = env_int("FF_MFMA_SMALL", -1);
+        const bool fits = !st.empty() && pl->m_digits <= S_MAX_DIGITS && st.size() < ((size_t)1 << 30) &&
+                          pl->m_ldb * pl->m_digits <= S_TABLE_BYTES;  // (its digit planes live in LDS)
+        const bool small = fits && (force >= 0 ? force != 0
+                                               : big_tiles < G && (double)st.size() * 2.0 * (double)slabs <= S_MAX_WORK);
+        if (small) {
+            pl->m_small = true;
+            pl->n_stiles = (int)st.size();
+            FF_HIP(hipMalloc(&pl->d_stiles, sizeof(STile) * st.size()));
+            FF_HIP(hipMemcpy(pl->d_stiles, st.data(), sizeof(STile) * st.size(), hipMemcpyHostToDevice));
+            inf.kernel = FF_KERNEL_MFMA_I8_SMALL;
+            inf.n_tiles = inf.n_items = (int64_t)st.size();
+            inf.n_wave_slots = (int64_t)st.size() * S_WAVES;
+            inf.elements = (double)st.size() * S_TILE * S_TILE * (double)pl->m_ldb * pl->m_digits;
+            pl->m_all_private = false;
+            pl->m_any_atomic = false;
+            pl->m_fused = env_int("FF_MFMA_FUSED_FINISH", -1) != 0;  // every slot has one writer: it can write the distance
+#define FF_S_ATTR(ND)                                                                                                   \
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_small_kernel<ND>),                            \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+            FF_S_ATTR(1) FF_S_ATTR(2) FF_S_ATTR(3) FF_S_ATTR(4) FF_S_ATTR(5)
+#undef FF_S_ATTR
+            FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
+            return FF_OK;
+        }
+        inf.kernel = FF_KERNEL_MFMA_I8;
+    }
     std::vector<MItem> mi;
     std::vector<int32_t> mptr;
     std::vector<int32_t> ptiles, pptr;
@@ -1315,7 +1365,29 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (!fused && (!pl->mfma || pl->m_any_atomic))
             FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
-        if (pl->mfma) {
+        if (pl->mfma && pl->m_small) {
+            FinishArgs none = fin;
+            none.out = nullptr;  // null: integer sums into num[]
+            const dim3 grid((unsigned)pl->n_stiles), block(S_THREADS);
+            const uint4 *bits = reinterpret_cast<const uint4 *>(pl->d_Pbits);
+            const int n_slab_pairs = (int)(pl->m_ldb / (2 * M_KSLAB));
+#define FF_S_CASE(ND)                                                                                                  \
+    case ND:                                                                                                           \
+        pair_common_small_kernel<ND><<<grid, block, (size_t)(pl->m_ldb * ND + S_RED_BYTES), st>>>(bits, pl->m_n8, pl->d_Kd, pl->m_ldb, n_slab_pairs,        \
+                                                             pl->d_stiles, pl->d_W, pl->d_num, inf.row_begin,          \
+                                                             inf.row_end, inf.slot_begin, fused ? fin : none);         \
+        break;
+            switch (pl->m_digits) {
+                FF_S_CASE(1)
+                FF_S_CASE(2)
+                FF_S_CASE(3)
+                FF_S_CASE(4)
+                FF_S_CASE(5)
+            default: return ff::fail(FF_ERR_INTERNAL, err, errlen, "no small-shard kernel for %d digits", pl->m_digits);
+            }
+#undef FF_S_CASE
+            if (timed) FF_HIP(hipEventRecord(ev1, st));
+        } else if (pl->mfma) {
             auto kern = pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>;
 #ifdef FF_MFMA_DIAG  // ablations for timing only (wrong results): see the kernel's DIAG parameter
             switch (env_int("FF_MFMA_DIAG", 0)) {

@@ -184,8 +184,10 @@ typedef enum ff_kernel {
     FF_KERNEL_SAD_U32 = 0,   /* pair_sad_kernel: v_sad_u32 pair tiles (FIXED32)                    */
     FF_KERNEL_EXACT_F64 = 1, /* pair_exact64_kernel (EXACT64)                                      */
     FF_KERNEL_MFMA_I8 = 2,   /* pair_common_mfma_kernel: FIXED32 unweighted, int8 matrix cores     */
-    FF_KERNEL_SAD_U32_SPARSE = 3 /* pair_sad_sparse_kernel: as SAD_U32, skipping branch rows on which
-                                    none of a tile's 32 samples has a flat node (sparse tables)    */
+    FF_KERNEL_SAD_U32_SPARSE = 3, /* pair_sad_sparse_kernel: as SAD_U32, skipping branch rows on which
+                                     none of a tile's 32 samples has a flat node (sparse tables)   */
+    FF_KERNEL_MFMA_I8_SMALL = 4   /* pair_common_small_kernel: as MFMA_I8 for a shard smaller than one round
+                                     of it (few hundred samples): 32 x 32 tiles, one launch per pass     */
 } ff_kernel;
 
 /* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM

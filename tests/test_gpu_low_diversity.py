@@ -112,7 +112,7 @@ def test_fixed32_unweighted_few_distinct_lengths(mfma, monkeypatch):
     want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=4)
     plan = ff.Plan(nodes, False, precision="fixed32")
     assert plan.info.lengths_exact == 0
-    assert plan.info.kernel == (2 if mfma == "1" else 0)
+    assert plan.info.kernel == (4 if mfma == "1" else 0)  # (64 samples: the small-shard matrix-core kernel)
     got = plan.run_host()
     assert rel_err(got, want).max() <= WEIGHTED_RTOL
     n, bad, worst = plan.audit()
@@ -133,7 +133,7 @@ def test_fixed32_unweighted_inexact_lengths_keep_their_bits():
     nodes, ip, on, ft = both_sides(tree, ptr, idx, val, False)
     want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=4)
     plan = ff.Plan(nodes, False, precision="fixed32")
-    assert plan.info.lengths_exact == 0 and plan.info.kernel == 2 and plan.info.n_digits >= 3
+    assert plan.info.lengths_exact == 0 and plan.info.kernel in (2, 4) and plan.info.n_digits >= 3
     got = plan.run_host()
     assert rel_err(got, want).max() <= WEIGHTED_RTOL
     queued, cap = plan.refined_pairs()

@@ -20,6 +20,26 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 WEIGHTED_RTOL = 1e-6  # north_star: "within 1e-6 relative for weighted"
+# FIXED32's guarantee is statistical (hashed per-branch offset + refinement rule + audit sample): the full-size
+# tests therefore hold the WORST error over their 1 M sampled pairs to half the bar and log it, so that an
+# erosion of the headroom (bigger B, another hash, a staging change) shows up before it becomes a failure.
+WEIGHTED_MARGIN = 5e-7
+
+
+def record_margin(name, worst, pairs):
+    """Logs the worst relative error of a full-size sampled-parity test (stdout + gpurun_out/parity_margins.txt,
+    which gpurun merges back) and holds it to WEIGHTED_MARGIN."""
+    line = "%s: worst relative error over %d sampled pairs %.3e (bar %.0e, margin bar %.0e)" % (
+        name, pairs, worst, WEIGHTED_RTOL, WEIGHTED_MARGIN)
+    print("[margin] " + line)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_margins.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert worst <= WEIGHTED_MARGIN, line
 HOST_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))  # oracle threads (the checker only)
 
 
@@ -113,8 +133,10 @@ def test_cli_run_sh(tmp_path):
 
 # ---------------------------------------------------------------- synthetic, full comparison
 
-def test_c2_unweighted_bit_exact():
-    """BASELINE configs[1]: 512 samples x 2k-leaf tree, unweighted, every pair, both paths."""
+def test_c2_unweighted_bit_exact(monkeypatch):
+    """BASELINE configs[1]: 512 samples x 2k-leaf tree, unweighted, every pair, every path: the one-launch
+    small-shard matrix-core kernel the plan picks for it (136 tiles of 32 x 32, kernel 4), the persistent
+    matrix-core kernel, the vector-ALU kernel, EXACT64 and AUTO."""
     cfg = synth.CONFIGS["C2"]
     nodes, ip, on, ft = synth_problem(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
     want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=8)
@@ -123,7 +145,20 @@ def test_c2_unweighted_bit_exact():
         assert np.array_equal(got, want), precision
     plan = ff.Plan(nodes, False, precision="fixed32")
     assert plan.info.lengths_exact == 1 and plan.info.scale_log2 == 10
+    assert plan.info.kernel == 4 and plan.info.n_tiles == 136 and plan.info.n_wave_slots == 136 * 8
+    assert np.array_equal(plan.run_host(), want)
+    for r in range(3):  # re-targeted at shards: the same bits, slice by slice
+        plan.set_shard(r, 3)
+        a, b = ff.shard_slots(cfg["n_samples"], r, 3)
+        assert plan.info.kernel == 4 and np.array_equal(plan.run_host(), want[a:b])
     plan.close()
+    for env, kernel in (("FF_MFMA_SMALL", 2), ("FF_UNWEIGHTED_MFMA", 0)):
+        monkeypatch.setenv(env, "0")
+        plan = ff.Plan(nodes, False, precision="fixed32")
+        assert plan.info.kernel == kernel
+        assert np.array_equal(plan.run_host(), want), env
+        plan.close()
+        monkeypatch.delenv(env)
 
 
 def test_weighted_512_within_tolerance_and_exact64_bit_exact():
@@ -286,10 +321,16 @@ def test_bad_problems_are_rejected():
         ff.unifrac_dists(nodes, True, rank=3, world=2)
 
 
-def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch):
-    """FIXED32 unweighted: the int8 matrix-core contraction and the v_sad_u32 kernel work
-    on the same integers and must give the same bits (three base-128 digits here)."""
+MFMA_KERNEL = {"0": 2, "1": 4}  # FF_MFMA_SMALL -> ff_kernel: pair_common_mfma_kernel / pair_common_small_kernel
+
+
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch, small):
+    """FIXED32 unweighted: the int8 matrix-core contraction (either kernel: the persistent one, FF_MFMA_SMALL=0,
+    or the one-launch kernel for small shards) and the v_sad_u32 kernel work on the same integers and must
+    give the same bits (three base-128 digits here)."""
     import torch
+    monkeypatch.setenv("FF_MFMA_SMALL", small)
     tree, ptr, idx, val = synth.make(300, 700, 0.1, 91)
     rng = np.random.default_rng(5)
     tree.branch_len = rng.integers(1, 1 << 20, size=tree.n).astype(np.float64) / 64.0   # 20-bit integer lengths
@@ -303,7 +344,7 @@ def test_unweighted_mfma_and_vector_kernels_agree(monkeypatch):
     for flag in ("1", "0"):
         monkeypatch.setenv("FF_UNWEIGHTED_MFMA", flag)
         plan = ff.Plan(nodes, False, precision="fixed32")
-        assert plan.info.kernel == (2 if flag == "1" else 0) or (flag == "0" and plan.info.kernel == 3)
+        assert plan.info.kernel == (MFMA_KERNEL[small] if flag == "1" else 0) or (flag == "0" and plan.info.kernel == 3)
         assert plan.info.lengths_exact == 1
         if flag == "1":
             assert plan.info.n_digits == 3
@@ -381,8 +422,11 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
             monkeypatch.delenv(k)
 
 
-def test_unweighted_mfma_five_digits_and_long_lengths():
-    """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps)."""
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_unweighted_mfma_five_digits_and_long_lengths(monkeypatch, small):
+    """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps of the persistent kernel,
+    five accumulator tiles in the small-shard one)."""
+    monkeypatch.setenv("FF_MFMA_SMALL", small)
     tree, ptr, idx, val = synth.make(130, 20, 0.3, 93)
     rng = np.random.default_rng(6)
     tree.branch_len = rng.integers(1, 1 << 24, size=tree.n).astype(np.float64)
@@ -393,23 +437,30 @@ def test_unweighted_mfma_five_digits_and_long_lengths():
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     plan = ff.Plan(nodes, False, precision="fixed32")
-    assert plan.info.kernel == 2 and plan.info.n_digits == 5 and plan.info.lengths_exact == 1
+    assert plan.info.kernel == MFMA_KERNEL[small] and plan.info.n_digits == 5 and plan.info.lengths_exact == 1
     plan.close()
     assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
 
 
 @pytest.mark.parametrize("ns,nl,dens", [(130, 20000, 0.02), (700, 17000, 0.01), (257, 33, 0.5), (1, 10, 0.5), (2, 40000, 0.001),
                                         (300, 1000, 0.1)])  # 1000 leaves = 32 slabs: the deepest read past an item's end
-def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts(ns, nl, dens):
-    """The matrix-core kernel keeps 512 slabs of digits in LDS at a time (20000 leaves = 625 slabs:
-    two segments, the second of odd length), walks slabs in pairs with a tail, pads the sample
-    count to whole 256 x 128 tiles and cuts problems smaller than a round stream-K style: every
-    pair, bit-exact (dyadic lengths), against the oracle and against the vector-ALU kernel."""
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts(monkeypatch, ns, nl, dens, small):
+    """The persistent matrix-core kernel (FF_MFMA_SMALL=0) keeps 512 slabs of digits in LDS at a time (20000
+    leaves = 625 slabs: two segments, the second of odd length), walks slabs in pairs with a tail, pads the sample
+    count to whole 256 x 128 tiles and cuts problems smaller than a round stream-K style; the small-shard kernel
+    (=1) cuts the same slabs over the eight waves of a workgroup (157 pairs of slabs: uneven shares; 1 pair: seven
+    idle waves).  Every pair, bit-exact (dyadic lengths), against the oracle and against the vector-ALU kernel."""
+    monkeypatch.setenv("FF_MFMA_SMALL", small)
     nodes, ip, on, ft = synth_problem(ns, nl, dens, 4242 + ns)
     want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
     plan = ff.Plan(nodes, False, precision="fixed32")
     if ns > 1:
-        assert plan.info.kernel == 2 and plan.info.lengths_exact == 1
+        # (the small-shard kernel keeps all digit planes in 64 KiB of LDS: a tree too large for that takes the
+        # persistent kernel whatever FF_MFMA_SMALL says)
+        fits = plan.info.rows_padded * plan.info.n_digits <= 64 * 1024
+        assert plan.info.kernel == (MFMA_KERNEL[small] if fits else 2) and plan.info.lengths_exact == 1
+        assert fits == (nl < 17000)
     got = plan.run_host() if ns > 1 else np.zeros(0)
     plan.close()
     assert np.array_equal(got, want, equal_nan=True)
@@ -422,11 +473,13 @@ def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts
 
 @pytest.mark.parametrize("exact_lengths", [True, False])
 @pytest.mark.parametrize("ns", [300, 1200])
-def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch, exact_lengths, ns):
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch, exact_lengths, ns, small):
     """FF_MFMA_FUSED_FINISH: distances written by the pair kernel's epilogue / the partial reduction
     (no num[], no finish launch) or by finish_fixed32_kernel -- the same doubles either way, with the
     refinement queue in play when the lengths are off the binary grid (replicated samples), and the
     oracle's to 1e-6 (bit-exact for dyadic lengths)."""
+    monkeypatch.setenv("FF_MFMA_SMALL", small)
     tree, ptr, idx, val = synth.make(ns, 1500, 0.1, 31 + ns)
     if not exact_lengths:
         tree.branch_len[:] = np.random.default_rng(1).integers(1, 40, size=tree.n) / 10.0
@@ -444,7 +497,7 @@ def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch
     for fused in ("0", "1"):
         monkeypatch.setenv("FF_MFMA_FUSED_FINISH", fused)
         plan = ff.Plan(nodes, False, precision="fixed32")
-        assert plan.info.kernel == 2 and plan.info.lengths_exact == (1 if exact_lengths else 0)
+        assert plan.info.kernel == MFMA_KERNEL[small] and plan.info.lengths_exact == (1 if exact_lengths else 0)
         got[fused] = plan.run_host()
         if not exact_lengths:
             queued, cap = plan.refined_pairs()
@@ -698,7 +751,7 @@ def test_c4_c5_full_size_sampled_parity(name):
     del part
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
-    assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
+    record_margin(name, oracle_ranges_worst(d, ip, on, ft.dist, True, n), 1_000_000)
 
 
 def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
@@ -803,7 +856,8 @@ def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch,
         assert np.array_equal(a.abnd, b.abnd)
 
 
-@pytest.mark.parametrize("case", ["weighted-fixed32", "unweighted-mfma", "unweighted-sad", "weighted-exact64", "sparse"])
+@pytest.mark.parametrize("case", ["weighted-fixed32", "unweighted-mfma", "unweighted-mfma-persistent", "unweighted-sad",
+                                  "weighted-exact64", "sparse"])
 def test_one_staging_serves_every_shard(monkeypatch, case):
     """ff_plan_set_shard: the staged matrix stays, schedule and accumulators are rebuilt; every
     shard of 1, 2 and 7 reproduces its slice of the whole, in any order, back and forth."""
@@ -813,13 +867,15 @@ def test_one_staging_serves_every_shard(monkeypatch, case):
     prec = "exact64" if case.endswith("exact64") else "fixed32"
     if case == "unweighted-sad":
         monkeypatch.setenv("FF_UNWEIGHTED_MFMA", "0")
+    if case == "unweighted-mfma-persistent":
+        monkeypatch.setenv("FF_MFMA_SMALL", "0")
     if case == "sparse":
         nodes, ip, on, ft = synth_problem(330, 6000, 0.004, 12)
     else:
         nodes, ip, on, ft = synth_problem(330, 700, 0.2, 12)
     n = 330
     plan = ff.Plan(nodes, weighted, precision=prec)
-    assert plan.info.kernel == {"weighted-fixed32": 0, "unweighted-mfma": 2, "unweighted-sad": 0, "weighted-exact64": 1,
+    assert plan.info.kernel == {"weighted-fixed32": 0, "unweighted-mfma": 4, "unweighted-mfma-persistent": 2, "unweighted-sad": 0, "weighted-exact64": 1,
                                 "sparse": 3}[case]
     def run():
         out = torch.full((max(plan.n_slots, 1),), np.nan, dtype=torch.float64, device="cuda")
@@ -970,7 +1026,7 @@ def test_c3_full_size_properties_and_sampled_parity():
     # sampled parity against the oracle: 1 M pairs in 8 slot ranges spread over the triangle
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
-    assert oracle_ranges_worst(d, ip, on, ft.dist, True, n) <= WEIGHTED_RTOL
+    record_margin("C3", oracle_ranges_worst(d, ip, on, ft.dist, True, n), 1_000_000)
     # two shards of the same problem reproduce the single-device bits (checksum of checksums)
     parts = []
     for r in range(2):
@@ -985,15 +1041,62 @@ def test_c3_full_size_properties_and_sampled_parity():
 
 
 def test_c3_unweighted_full_size_bit_exact_on_ranges():
-    """Unweighted at headline size: integer path, so sampled ranges must match the
-    oracle exactly (dyadic lengths)."""
+    """Unweighted at headline size -- 4,096 samples, the launch shape bench.py's `secondary` reports (272 tiles on
+    256 workgroups: one whole round and a remainder): integer path, so sampled ranges must match the oracle
+    exactly (dyadic lengths), 1 M pairs in four ranges spread over the triangle."""
     cfg = synth.CONFIGS["C3"]
-    nodes, ip, on, ft = synth_problem(2048, cfg["n_leaves"], cfg["density"], cfg["seed"])
-    got = ff.unifrac_dists(nodes, False, precision="fixed32")
-    P = ff.num_pairs(2048)
-    for a in (0, P // 4, P // 2, P - 250_000):
+    n = cfg["n_samples"]
+    assert n == 4096
+    nodes, ip, on, ft = synth_problem(n, cfg["n_leaves"], cfg["density"], cfg["seed"])
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    assert plan.info.kernel == 2 and plan.info.n_tiles == 272 and plan.info.lengths_exact == 1
+    got = plan.run_host()
+    plan.close()
+    assert not np.isnan(got).any() and got.min() >= 0.0 and got.max() <= 1.0
+    P = ff.num_pairs(n)
+    for a in (0, P // 3, 2 * P // 3, P - 250_000):
         want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 250_000)
         assert np.array_equal(got[a:a + 250_000], want)
+
+
+@pytest.mark.parametrize("stride_kind", ["odd", "power_of_two"])
+def test_hashed_offset_on_arithmetic_progressions_of_branch_ids(stride_kind):
+    """Adversarial input for FIXED32's per-branch rounding offset (ff_dither.hpp: a hash of the branch id).  A star
+    tree of 100,000 leaves, every branch the same length, every count the same: all of a sample's values are equal,
+    so every term's rounding error is a function of the offset alone, and the leaves a sample holds are an
+    ARITHMETIC PROGRESSION of branch ids (start and stride per sample: consecutive ids, small odd strides or powers
+    of two) -- if the hash of a progression were not equidistributed the errors of U would add up linearly instead
+    of like sqrt(k).  (The samples use under a tenth of the tree, so the rows are compacted; the offset hashes the
+    original id.)  Every pair against the oracle, worst error logged and held to the margin."""
+    L_ = 100_000
+    n, m = 96, 3000
+    names = [""] + ["t%d" % k for k in range(1, L_ + 1)]
+    newick = "(" + ",".join("%s:0.37" % nm for nm in names[1:]) + ");"
+    T = ff.parse_newick(newick)
+    rng = np.random.default_rng(12)
+    rows = []
+    for s in range(n):
+        stride = [1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 31][s % 12] if stride_kind == "odd" else 1 << (s % 6)
+        start = int(rng.integers(1, L_ - m * stride))
+        rows.append(np.arange(start, start + m * stride, stride, dtype=np.int64))
+    ptr = np.arange(n + 1, dtype=np.int64) * m
+    idx = np.concatenate(rows)
+    val = np.full(n * m, 7.0)
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.precision == 1 and plan.info.n_rows < L_ // 2   # FIXED32, compacted rows
+    got = plan.run_host()
+    queued, cap = plan.refined_pairs()
+    checked, failed, worst_audit = plan.audit()
+    plan.close()
+    assert failed == 0 and queued <= cap
+    ft = O.FlatTree(names, np.array([0.0] + [0.37] * L_), np.array([L_ + 1] + [1] * L_, dtype=np.int64),
+                    np.array([-1] + [0] * L_, dtype=np.int64))
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    record_margin("star tree 100k leaves, progressions (%s strides), audit worst %.2e" % (stride_kind, worst_audit),
+                  rel_err(got, want), len(want))
 
 
 def test_remaining_schedule_and_audit_switches_are_bit_neutral(monkeypatch):

@@ -14,7 +14,7 @@ declare -A ARGS KERN
 ARGS[c3]="--no-cpu-baseline --no-secondary";                         KERN[c3]=pair_sad_kernel
 ARGS[c3_unweighted]="--unweighted --no-cpu-baseline --no-secondary --steps 50"; KERN[c3_unweighted]=pair_common_mfma
 ARGS[c3_exact64]="--precision exact64 --steps 5 --no-cpu-baseline --no-secondary"; KERN[c3_exact64]=pair_exact64
-ARGS[c2]="--workload C2 --unweighted --no-cpu-baseline --no-secondary --steps 50"; KERN[c2]=pair_common_mfma
+ARGS[c2]="--workload C2 --unweighted --no-cpu-baseline --no-secondary --steps 50"; KERN[c2]=pair_common_small
 ARGS[c4]="--workload C4 --steps 5 --no-cpu-baseline --no-secondary";  KERN[c4]=pair_sad_kernel
 ARGS[c5]="--workload C5 --steps 5 --no-cpu-baseline --no-secondary";  KERN[c5]=pair_sad_kernel
 list=("$@"); [ ${#list[@]} -eq 0 ] && list=(c3 c3_unweighted c3_exact64 c2 c4 c5)
