@@ -382,7 +382,9 @@ def main():
         n_override = int(round(int(args.workload.lower().split("x")[0]) * math.sqrt(world) / 32.0)) * 32
     cfg, nodes = make_problem(ctx, args.workload, n_override)
     weighted = cfg["weighted"] and not args.unweighted
-    primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup)
+    # (steps of a few microseconds -- the unweighted matrix-core kernels -- carry the event pair on every 8th launch)
+    primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup,
+                      event_every=1 if weighted or args.precision == "exact64" else 8)
 
     e2e = None
     if rank == 0 and world == 1 and args.end_to_end:
