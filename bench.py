@@ -191,7 +191,10 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     sec = max(kernel_ms, 1e-9) * 1e-3
     hbm = {"bound": "hbm", "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
-    common = {"kernel": KERNEL_NAMES[int(info.kernel)], "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
+    kname = KERNEL_NAMES[int(info.kernel)]
+    if info.kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
+        kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for many-round shards)
+    common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
     # the binding floor of THIS launch (one rank's shard): its algorithmic work at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
     common["floor_ms"] = (6.0 if info.kernel == 1 else 2.0) * B * shard_pairs / peak_ops * 1e3
