@@ -108,8 +108,8 @@ struct ff_plan {
     bool m_fused = false;        // the kernels that hold a slot's final sum write its distance (no num[] round trip, no finish launch)
     int n_mitems = 0, n_mgroups = 0;
     bool m_small = false;        // a shard smaller than one round: pair_common_small_kernel, one launch per pass
-    STile *d_stiles = nullptr;
-    int n_stiles = 0;
+    int n_stiles = 0;            // its 32 x 32 tiles (= workgroups)
+    int64_t stile_c0 = 0;        // position of the shard's first tile in the triangle of 32 x 32 blocks
     // EXACT64
     double *d_DT = nullptr;
     double *d_len = nullptr;
@@ -367,7 +367,6 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_partial);
     (void)hipFree(pl->d_ptiles);
     (void)hipFree(pl->d_ptile_ptr);
-    (void)hipFree(pl->d_stiles);
     (void)hipFree(pl->d_DT);
     (void)hipFree(pl->d_len);
     (void)hipFree(pl->d_len_rows);
@@ -707,7 +706,6 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_partial);
     free_and_null(pl->d_ptiles);
     free_and_null(pl->d_ptile_ptr);
-    free_and_null(pl->d_stiles);
     pl->n_ptiles = 0;
     pl->m_small = false;
     pl->n_stiles = 0;
@@ -721,28 +719,30 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
         // launch.  Below S_MAX_WORK (32 x 32 tiles x k-steps; calibrated with tools/mfma_small_sweep.py) such a
         // shard takes pair_common_small_kernel instead: one 32 x 32 tile per workgroup over all branches, the
         // sum over the waves' ranges and the division inside the same launch.  FF_MFMA_SMALL=1 / 0 forces.
-        std::vector<STile> st;
-        for (int64_t i0 = inf.row_begin / S_TILE * S_TILE; i0 < inf.row_end; i0 += S_TILE) {
+        // its tiles: row blocks of 32 in ascending order, block I with the column blocks 0 .. I (the kernel maps a
+        // tile's ordinal to (I, J) by itself: small_tile_of)
+        int64_t n_st = 0;
+        const int64_t ib0 = inf.row_begin / S_TILE;
+        for (int64_t i0 = ib0 * S_TILE; i0 < inf.row_end; i0 += S_TILE) {
             const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + S_TILE, inf.row_end) - 1, N);  // valid columns: j < w
-            for (int64_t j0 = 0; j0 < w; j0 += S_TILE) st.push_back({(int32_t)i0, (int32_t)j0});
+            n_st += (w + S_TILE - 1) / S_TILE;  // (= I + 1, or I for a last block of one row)
         }
         int64_t big_tiles = 0;
         for (int64_t i0 = inf.row_begin / M_TILE_I * M_TILE_I; i0 < inf.row_end; i0 += M_TILE_I)
             big_tiles += (std::min<int64_t>(std::min<int64_t>(i0 + M_TILE_I, inf.row_end) - 1, N) + M_TILE_J - 1) / M_TILE_J;
         const int force = env_int("FF_MFMA_SMALL", -1);
-        const bool fits = !st.empty() && pl->m_digits <= S_MAX_DIGITS && st.size() < ((size_t)1 << 30) &&
+        const bool fits = n_st > 0 && pl->m_digits <= S_MAX_DIGITS && n_st < ((int64_t)1 << 30) &&
                           pl->m_ldb * pl->m_digits <= S_TABLE_BYTES;  // (its digit planes live in LDS)
         const bool small = fits && (force >= 0 ? force != 0
-                                               : big_tiles < G && (double)st.size() * 2.0 * (double)slabs <= S_MAX_WORK);
+                                               : big_tiles < G && (double)n_st * 2.0 * (double)slabs <= S_MAX_WORK);
         if (small) {
             pl->m_small = true;
-            pl->n_stiles = (int)st.size();
-            FF_HIP(hipMalloc(&pl->d_stiles, sizeof(STile) * st.size()));
-            FF_HIP(hipMemcpy(pl->d_stiles, st.data(), sizeof(STile) * st.size(), hipMemcpyHostToDevice));
+            pl->n_stiles = (int)n_st;
+            pl->stile_c0 = ib0 * (ib0 + 1) / 2;
             inf.kernel = FF_KERNEL_MFMA_I8_SMALL;
-            inf.n_tiles = inf.n_items = (int64_t)st.size();
-            inf.n_wave_slots = (int64_t)st.size() * S_WAVES;
-            inf.elements = (double)st.size() * S_TILE * S_TILE * (double)pl->m_ldb * pl->m_digits;
+            inf.n_tiles = inf.n_items = n_st;
+            inf.n_wave_slots = n_st * S_WAVES;
+            inf.elements = (double)n_st * S_TILE * S_TILE * (double)pl->m_ldb * pl->m_digits;
             pl->m_all_private = false;
             pl->m_any_atomic = false;
             pl->m_fused = env_int("FF_MFMA_FUSED_FINISH", -1) != 0;  // every slot has one writer: it can write the distance
@@ -1374,7 +1374,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
 #define FF_S_CASE(ND)                                                                                                  \
     case ND:                                                                                                           \
         pair_common_small_kernel<ND><<<grid, block, (size_t)(pl->m_ldb * ND + S_RED_BYTES), st>>>(bits, pl->m_n8, pl->d_Kd, pl->m_ldb, n_slab_pairs,        \
-                                                             pl->d_stiles, pl->d_W, pl->d_num, inf.row_begin,          \
+                                                             pl->stile_c0, pl->d_W, pl->d_num, inf.row_begin,          \
                                                              inf.row_end, inf.slot_begin, fused ? fin : none);         \
         break;
             switch (pl->m_digits) {
@@ -1598,6 +1598,21 @@ int ff_debug_mfma_stamps(unsigned long long *host_out, int64_t n_workgroups)
     if (!host_out) {
         if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) return FF_ERR_DEVICE;
         return hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_stamps), &d, sizeof(d)) == hipSuccess ? FF_OK : FF_ERR_DEVICE;
+    }
+    if (!d) return FF_ERR_ARG;
+    return hipMemcpy(host_out, d, bytes, hipMemcpyDeviceToHost) == hipSuccess ? FF_OK : FF_ERR_DEVICE;
+}
+#endif
+
+#ifdef FF_MFMA_DIAG
+// Diagnostic build only: as ff_debug_mfma_stamps, for pair_common_small_kernel ([workgroup][8] 100 MHz ticks).
+int ff_debug_small_stamps(unsigned long long *host_out, int64_t n_workgroups)
+{
+    static unsigned long long *d = nullptr;
+    const size_t bytes = (size_t)n_workgroups * 8 * sizeof(unsigned long long);
+    if (!host_out) {
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) return FF_ERR_DEVICE;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &d, sizeof(d)) == hipSuccess ? FF_OK : FF_ERR_DEVICE;
     }
     if (!d) return FF_ERR_ARG;
     return hipMemcpy(host_out, d, bytes, hipMemcpyDeviceToHost) == hipSuccess ? FF_OK : FF_ERR_DEVICE;

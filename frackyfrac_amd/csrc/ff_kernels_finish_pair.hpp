@@ -27,10 +27,10 @@ struct FinishArgs {
     int scale_log2, weighted;
 };
 
-// Local slot t = pair (i, j), integer numerator u.
-__device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u)
+// Local slot t = pair (i, j), integer numerator u, w = W[i] + W[j] (the caller has loaded them).
+__device__ __forceinline__ void finish_pair_w(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u,
+                                              unsigned long long w)
 {
-    const unsigned long long w = f.W[i] + f.W[j];
     double d;
     if (u == w || !f.wex) {
         // u == w: no branch carries both samples (integer identity): exactly 1, or 0/0 = NaN
@@ -56,4 +56,10 @@ __device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int6
             if (at < f.refine_cap) f.refine_list[at] = (unsigned long long)t;
         }
     }
+}
+
+// Local slot t = pair (i, j), integer numerator u.
+__device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u)
+{
+    finish_pair_w(f, t, i, j, u, f.W[i] + f.W[j]);
 }

@@ -32,14 +32,33 @@ constexpr int S_RED_BYTES = S_WAVES * S_TILE * S_TILE * 4;
 constexpr int S_LDS_BYTES = S_TABLE_BYTES + S_RED_BYTES;  // the most a launch asks for
 static_assert(M_PAD_SLABS >= 2 * S_DEPTH, "pair_common_small_kernel requests S_DEPTH pairs of slabs behind a wave's range");
 
-struct STile {
-    int32_t i0, j0;
-};
+// Tile t of a shard whose first row block is ib0 (rows 32 ib0 ..): row blocks in ascending order, block I with its
+// I + 1 column blocks 0 .. I (the diagonal one last); t + c0 with c0 = ib0 (ib0 + 1) / 2 is the tile's position in
+// the triangle of 32 x 32 blocks, so (I, J) follow from a square root -- no table of tiles, no load before the
+// first operand request.  (A shard's last row block may lack its diagonal tile -- a single row whose pairs all lie
+// left of it: that tile is the last of the enumeration and is simply not launched.)
+__device__ __forceinline__ void small_tile_of(int64_t t, int64_t c0, int32_t *i0, int32_t *j0)
+{
+    const int64_t k = t + c0;
+    int64_t I = (int64_t)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > k) --I;
+    while ((I + 1) * (I + 2) / 2 <= k) ++I;
+    *i0 = (int32_t)(I * S_TILE);
+    *j0 = (int32_t)((k - I * (I + 1) / 2) * S_TILE);
+}
 
+#ifdef FF_MFMA_DIAG
+// Diagnostic build: thread 0 of every workgroup stamps the phases with the 100 MHz real-time clock
+// (tools/small_stamps.py): [workgroup][8].
+__device__ unsigned long long *g_small_stamps = nullptr;
+#define FF_SSTAMP(slot) if (g_small_stamps && tid == 0) g_small_stamps[(int64_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define FF_SSTAMP(slot)
+#endif
 template <int NDIG>
 __global__ __launch_bounds__(S_THREADS)
 void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const int8_t *__restrict__ Kd, int64_t ldb,
-                              int n_slab_pairs, const STile *__restrict__ tiles, const unsigned long long *__restrict__ W,
+                              int n_slab_pairs, int64_t tile_c0, const unsigned long long *__restrict__ W,
                               uint32_t *__restrict__ num, int64_t row_begin, int64_t row_end, int64_t slot_begin,
                               const FinishArgs fin)  // fin.out != null: distances; else integer sums into num[]
 {
@@ -49,7 +68,11 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, row = lane & 31;
-    const STile tile = tiles[blockIdx.x];
+    FF_SSTAMP(0);
+    struct {
+        int32_t i0, j0;
+    } tile;
+    small_tile_of(blockIdx.x, tile_c0, &tile.i0, &tile.j0);
     // this wave's share of the branch sweep: pairs of slabs [p0, p1)
     const int p0 = (int)((int64_t)n_slab_pairs * wave / S_WAVES), p1 = (int)((int64_t)n_slab_pairs * (wave + 1) / S_WAVES);
     const uint4 *pa = Pbits + (int64_t)p0 * n8 + tile.i0 + row;   // the presence words of i-row / j-row `row`
@@ -65,6 +88,11 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
     }
     pa += (int64_t)S_DEPTH * n8;
     pb += (int64_t)S_DEPTH * n8;
+    // W_i, W_j of the two pairs this thread finishes (elements tid and tid + 512 of the tile): requested now, used
+    // after the sweep (W has a zero entry for every padded sample)
+    const unsigned long long w_j = W[tile.j0 + (tid & 31)];
+    const unsigned long long w_i0 = W[tile.i0 + (tid >> 5)], w_i1 = W[tile.i0 + (tid >> 5) + S_THREADS / S_TILE];
+    static_assert(S_TILE * S_TILE == 2 * S_THREADS, "a thread finishes two pairs of the tile");
     // the digit planes -> LDS, 16 bytes per thread and trip: table[d * ldb + position]
     {
         const int pieces = (int)(ldb / 16);
@@ -74,6 +102,7 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
         }
     }
     __syncthreads();
+    FF_SSTAMP(1);
     // digits of (slab, k-step kt, half-wave): 16 bytes at slab * 64 + kt * 32 + half * 16 of the digit's plane
     const int8_t *pd = small_lds + (int64_t)p0 * (2 * M_KSLAB) + half * 16;
     mfma_v16i acc[NDIG];
@@ -122,6 +151,7 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
 #pragma unroll
     for (int q = 0; q < S_DEPTH - 1; ++q)  // the last p1 - p < S_DEPTH pairs (their words are here already)
         if (p + q < p1) pair_steps(wa[q], wb[q]);
+    FF_SSTAMP(2);
     // common = sum_d 128^d acc_d (modulo 2^32, like every sum here: the final U < 2^32) -> LDS, one tile per wave
     // D[r] of a lane: row (r & 3) + 8 (r >> 2) + 4 half, column lane & 31
     uint32_t *red = (uint32_t *)(small_lds + (int64_t)NDIG * ldb);  // [wave][32 x 32], behind the table (ldb is a multiple of 256)
@@ -133,6 +163,7 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
         red[wave * (S_TILE * S_TILE) + ((r & 3) + 8 * (r >> 2) + 4 * half) * S_TILE + row] = c;
     }
     __syncthreads();
+    FF_SSTAMP(3);
 #pragma unroll
     for (int e = tid; e < S_TILE * S_TILE; e += S_THREADS) {
         const int64_t i = tile.i0 + (e >> 5), j = tile.j0 + (e & 31);
@@ -140,9 +171,12 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
         uint32_t c = 0;
 #pragma unroll
         for (int w = 0; w < S_WAVES; ++w) c += red[w * (S_TILE * S_TILE) + e];
-        const uint32_t u = (uint32_t)W[i] + (uint32_t)W[j] - 2u * c;  // result = W_i + W_j - 2 common
+        const unsigned long long w_i = e < S_THREADS ? w_i0 : w_i1;
+        const uint32_t u = (uint32_t)w_i + (uint32_t)w_j - 2u * c;  // result = W_i + W_j - 2 common
         const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
-        if (fin.out) finish_pair(fin, slot, i, j, u);
+        if (fin.out) finish_pair_w(fin, slot, i, j, u, w_i + w_j);
         else num[slot] = u;
     }
+    FF_SSTAMP(4);
 }
+#undef FF_SSTAMP
