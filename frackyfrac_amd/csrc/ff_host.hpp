@@ -100,7 +100,7 @@ public:
 
 private:
     int fd_ = -1;
-    bool own_ = false, gz_ = false, seekable_ = false;
+    bool own_ = false, gz_ = false, zst_ = false, seekable_ = false;
     unsigned nt_ = 1;
     int64_t off_ = 0;
     std::string name_;

@@ -7,6 +7,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <mutex>
@@ -168,12 +169,178 @@ static bool has_suffix(const char *path, const char *suf)
     return n >= m && strcmp(path + n - m, suf) == 0;
 }
 
-// aio.Open (frcfrc.go:93): a path ending in ".gz" is decompressed on the fly (the
+// ---- zstd and bzip2 by suffix, like gzip --------------------------------------------------------
+// gostuff/aio (go.mod:7; its klauspost/compress dependency is go.mod:12) picks the codec by the file's suffix.
+// This image ships libzstd.so.1 and libbz2.so.1.0 without their headers, so the few entry points used are
+// declared here and bound with dlopen when a ".zst" / ".bz2" path first comes by; a host without the library
+// gets an error that says so.  (Parity unpinned: aio's source is not in the reference tree; ".zst" is read and
+// written, ".bz2" read only -- Go has no bzip2 writer.)
+namespace {
+struct ZstdBuf {  // ZSTD_inBuffer / ZSTD_outBuffer (same layout: pointer, size, position)
+    void *ptr;
+    size_t size, pos;
+};
+struct ZstdApi {
+    void *(*createDStream)();
+    size_t (*freeDStream)(void *);
+    size_t (*decompressStream)(void *, ZstdBuf *out, ZstdBuf *in);
+    unsigned (*isError)(size_t);
+    const char *(*getErrorName)(size_t);
+    size_t (*compressBound)(size_t);
+    size_t (*compress)(void *dst, size_t cap, const void *src, size_t n, int level);
+    bool ok = false;
+};
+const ZstdApi &zstd_api()
+{
+    static const ZstdApi api = [] {
+        ZstdApi a{};
+        void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.createDStream = (void *(*)())dlsym(h, "ZSTD_createDStream");
+        a.freeDStream = (size_t(*)(void *))dlsym(h, "ZSTD_freeDStream");
+        a.decompressStream = (size_t(*)(void *, ZstdBuf *, ZstdBuf *))dlsym(h, "ZSTD_decompressStream");
+        a.isError = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+        a.getErrorName = (const char *(*)(size_t))dlsym(h, "ZSTD_getErrorName");
+        a.compressBound = (size_t(*)(size_t))dlsym(h, "ZSTD_compressBound");
+        a.compress = (size_t(*)(void *, size_t, const void *, size_t, int))dlsym(h, "ZSTD_compress");
+        a.ok = a.createDStream && a.freeDStream && a.decompressStream && a.isError && a.getErrorName && a.compressBound &&
+               a.compress;
+        return a;
+    }();
+    return api;
+}
+struct BzStream {  // bz_stream of bzlib.h
+    char *next_in;
+    unsigned avail_in, total_in_lo32, total_in_hi32;
+    char *next_out;
+    unsigned avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int);
+    void (*bzfree)(void *, void *);
+    void *opaque;
+};
+struct Bz2Api {
+    int (*init)(BzStream *, int verbosity, int small);
+    int (*run)(BzStream *);
+    int (*end)(BzStream *);
+    bool ok = false;
+};
+const Bz2Api &bz2_api()
+{
+    static const Bz2Api api = [] {
+        Bz2Api a{};
+        void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.init = (int (*)(BzStream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+        a.run = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompress");
+        a.end = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompressEnd");
+        a.ok = a.init && a.run && a.end;
+        return a;
+    }();
+    return api;
+}
+
+// raw: the file's bytes; out: the decompressed text (concatenated frames / streams are one text)
+int unzstd(const std::string &raw, const char *path, std::string *out, char *err, size_t errlen)
+{
+    const ZstdApi &z = zstd_api();
+    if (!z.ok) return ff::fail(FF_ERR_IO, err, errlen, "read %s: zstd support needs libzstd.so.1, which could not be loaded", path);
+    void *ds = z.createDStream();
+    if (!ds) return ff::fail(FF_ERR_IO, err, errlen, "read %s: zstd: out of memory", path);
+    std::vector<char> buf(1 << 17);
+    ZstdBuf in{const_cast<char *>(raw.data()), raw.size(), 0};
+    size_t last = 0;
+    while (in.pos < in.size) {
+        ZstdBuf o{buf.data(), buf.size(), 0};
+        last = z.decompressStream(ds, &o, &in);
+        if (z.isError(last)) {
+            const std::string why = z.getErrorName(last);
+            z.freeDStream(ds);
+            return ff::fail(FF_ERR_IO, err, errlen, "read %s: zstd: %s", path, why.c_str());
+        }
+        out->append(buf.data(), o.pos);
+        if (o.pos == 0 && in.pos == in.size) break;
+    }
+    for (; last != 0;) {  // input consumed, the decoder may still hold output
+        ZstdBuf o{buf.data(), buf.size(), 0};
+        const size_t before = in.pos;
+        last = z.decompressStream(ds, &o, &in);
+        if (z.isError(last) || (o.pos == 0 && in.pos == before)) {
+            z.freeDStream(ds);
+            return ff::fail(FF_ERR_IO, err, errlen, "read %s: zstd: %s", path, z.isError(last) ? z.getErrorName(last) : "unexpected end of file");
+        }
+        out->append(buf.data(), o.pos);
+    }
+    z.freeDStream(ds);
+    return FF_OK;
+}
+
+int unbz2(const std::string &raw, const char *path, std::string *out, char *err, size_t errlen)
+{
+    const Bz2Api &b = bz2_api();
+    if (!b.ok) return ff::fail(FF_ERR_IO, err, errlen, "read %s: bzip2 support needs libbz2.so.1.0, which could not be loaded", path);
+    std::vector<char> buf(1 << 17);
+    size_t at = 0;
+    while (at < raw.size()) {  // a file may hold several streams back to back
+        BzStream st;
+        memset(&st, 0, sizeof st);
+        if (b.init(&st, 0, 0) != 0) return ff::fail(FF_ERR_IO, err, errlen, "read %s: bzip2: out of memory", path);
+        st.next_in = const_cast<char *>(raw.data()) + at;
+        st.avail_in = (unsigned)std::min<size_t>(raw.size() - at, 1u << 30);
+        int rc = 0;
+        for (;;) {
+            st.next_out = buf.data();
+            st.avail_out = (unsigned)buf.size();
+            const unsigned in_before = st.avail_in;
+            rc = b.run(&st);
+            out->append(buf.data(), buf.size() - st.avail_out);
+            if (rc == 4 /* BZ_STREAM_END */) break;
+            if (rc != 0 /* BZ_OK */ || (st.avail_in == 0 && in_before == 0 && st.avail_out == buf.size())) {
+                b.end(&st);
+                return ff::fail(FF_ERR_IO, err, errlen, "read %s: bzip2: %s", path, rc == 0 ? "unexpected end of file" : "data error");
+            }
+            if (st.avail_in == 0) {  // next slice of a very large file
+                const size_t used = (size_t)(st.next_in - raw.data());
+                st.avail_in = (unsigned)std::min<size_t>(raw.size() - used, 1u << 30);
+            }
+        }
+        at = (size_t)(st.next_in - raw.data());
+        b.end(&st);
+    }
+    return FF_OK;
+}
+
+// One buffer as a complete zstd frame (a file may be a sequence of frames, like gzip members).
+bool zstd_frame(const std::string &in, std::string *out)
+{
+    const ZstdApi &z = zstd_api();
+    if (!z.ok) return false;
+    out->resize(z.compressBound(in.size()));
+    const size_t n = z.compress(&(*out)[0], out->size(), in.data(), in.size(), 1);
+    if (z.isError(n)) return false;
+    out->resize(n);
+    return true;
+}
+}  // namespace
+
+// aio.Open (frcfrc.go:93): a path ending in ".gz" (".zst", ".bz2") is decompressed on the fly (the
 // reference's gostuff/aio picks the codec by suffix); anything else, and stdin, is read as is.
 int read_all(const char *path, std::string *out, char *err, size_t errlen)
 {
     out->clear();
     char buf[1 << 16];
+    if (path && (has_suffix(path, ".zst") || has_suffix(path, ".bz2"))) {
+        std::string raw;
+        FILE *f = fopen(path, "rb");
+        if (!f) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.append(buf, n);
+        const bool bad = ferror(f);
+        fclose(f);
+        if (bad) return fail(FF_ERR_IO, err, errlen, "read %s: %s", path, strerror(errno));
+        return has_suffix(path, ".zst") ? unzstd(raw, path, out, err, errlen) : unbz2(raw, path, out, err, errlen);
+    }
     if (path && has_suffix(path, ".gz")) {
         gzFile g = gzopen(path, "rb");
         if (!g) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
@@ -264,8 +431,13 @@ DistWriter::~DistWriter()
 
 int DistWriter::open(const char *path, int threads, char *err, size_t errlen)
 {
-    // aio.Create (frcfrc.go:102): ".gz" output is compressed, by suffix
-    gz_ = path && has_suffix(path, ".gz");
+    // aio.Create (frcfrc.go:102): ".gz" / ".zst" output is compressed, by suffix
+    zst_ = path && has_suffix(path, ".zst");
+    if (zst_ && !zstd_api().ok)
+        return fail(FF_ERR_IO, err, errlen, "open %s: zstd support needs libzstd.so.1, which could not be loaded", path);
+    if (path && has_suffix(path, ".bz2"))
+        return fail(FF_ERR_IO, err, errlen, "open %s: bzip2 output is not supported (the reference's aio cannot write it either)", path);
+    gz_ = (path && has_suffix(path, ".gz")) || zst_;  // (gz_: the parts are compressed, each a member / frame of its own)
     name_ = path ? path : "stdout";
     fd_ = 1;
     own_ = false;
@@ -304,12 +476,12 @@ int DistWriter::write(const double *d, int64_t n, char *err, size_t errlen)
                 *o++ = '\n';
             }
             s.resize((size_t)(o - s.data()));
-            if (gz_) ok[t] = gzip_member(s, &zbufs_[t]) ? 1 : 0;
+            if (gz_) ok[t] = (zst_ ? zstd_frame(s, &zbufs_[t]) : gzip_member(s, &zbufs_[t])) ? 1 : 0;
         });
         std::vector<std::string> &outb = gz_ ? zbufs_ : bufs_;
         if (gz_)
             for (unsigned t = 0; t < nt; ++t)
-                if (!ok[t]) return fail(FF_ERR_IO, err, errlen, "write %s: gzip error", name_.c_str());
+                if (!ok[t]) return fail(FF_ERR_IO, err, errlen, "write %s: %s error", name_.c_str(), zst_ ? "zstd" : "gzip");
         if (seekable_ && nt > 1) {
             std::vector<int64_t> off(nt + 1, off_);
             for (unsigned t = 0; t < nt; ++t) off[t + 1] = off[t] + (int64_t)outb[t].size();

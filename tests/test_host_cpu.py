@@ -1,6 +1,7 @@
 """Host side of the product (C++ behind the C ABI) against the oracle: Newick reader,
 table loaders, species validation, stage A, Go float formatting, sharding, output
 writer.  No GPU needed."""
+import ctypes
 import math
 import os
 import subprocess
@@ -10,6 +11,7 @@ import pytest
 
 import frackyfrac_amd as ff
 from conftest import read_golden
+from frackyfrac_amd import _lib as L
 from frackyfrac_amd import synth
 from oracle import oracle as O
 
@@ -311,6 +313,88 @@ def test_gzip_io_by_suffix(tmp_path):
     with pytest.raises(ff.FFError) as e:
         ff.Tree.read_file(str(bad))
     assert e.value.code == 5
+
+
+def _zstd():
+    """libzstd through ctypes: the test's own compressor / decompressor (python has no zstd module here)."""
+    import ctypes
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    z.ZSTD_findFrameCompressedSize.restype = ctypes.c_size_t
+    z.ZSTD_findFrameCompressedSize.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+
+    def compress(data: bytes) -> bytes:
+        buf = ctypes.create_string_buffer(z.ZSTD_compressBound(len(data)))
+        n = z.ZSTD_compress(buf, len(buf), data, len(data), 3)
+        assert not z.ZSTD_isError(n)
+        return buf.raw[:n]
+
+    def decompress_frames(data: bytes, cap: int) -> bytes:
+        out, at = b"", 0
+        while at < len(data):
+            fsz = z.ZSTD_findFrameCompressedSize(data[at:], len(data) - at)
+            assert not z.ZSTD_isError(fsz)
+            buf = ctypes.create_string_buffer(cap)
+            n = z.ZSTD_decompress(buf, cap, data[at:at + fsz], fsz)
+            assert not z.ZSTD_isError(n)
+            out += buf.raw[:n]
+            at += fsz
+        return out
+
+    return compress, decompress_frames
+
+
+def test_zstd_and_bzip2_io_by_suffix(tmp_path):
+    """The other codecs gostuff/aio picks by suffix (frcfrc.go:93,102; go.mod:7,12): ".zst" on input and output,
+    ".bz2" on input (Go has no bzip2 writer).  The libraries are bound with dlopen (the image ships them without
+    headers).  Parity unpinned: aio's source is not in the reference tree."""
+    import bz2
+    compress, decompress_frames = _zstd()
+    tree_text, table_text = read_golden("uwtd2.tree"), read_golden("uwtd2.dense")
+    names = ff.parse_newick(tree_text).names
+    maps = ff.parse_abundance(table_text).to_maps()
+    # input: zstd (one frame, and two frames back to back), bzip2 (one stream, and two)
+    for suffix, blobs in ((".zst", [compress(tree_text.encode()), compress(tree_text[:9].encode()) + compress(tree_text[9:].encode())]),
+                          (".bz2", [bz2.compress(tree_text.encode()), bz2.compress(tree_text[:9].encode()) + bz2.compress(tree_text[9:].encode())])):
+        for k, blob in enumerate(blobs):
+            p = tmp_path / ("t%d.tree%s" % (k, suffix))
+            p.write_bytes(blob)
+            assert ff.Tree.read_file(str(p)).names == names
+    for suffix, blob in ((".zst", compress(table_text.encode())), (".bz2", bz2.compress(table_text.encode()))):
+        p = tmp_path / ("t.dense" + suffix)
+        p.write_bytes(blob)
+        h, err = ctypes.c_void_p(), L.errbuf()
+        L.check(L.lib().ff_table_read_file(str(p).encode(), 0, ctypes.byref(h), err, L.ERRLEN), err)
+        assert ff.Table(h).to_maps() == maps
+    # a large text: many decoder rounds
+    big = ("%.17g\n" * 200000 % tuple(np.random.default_rng(5).random(200000))).encode()
+    (tmp_path / "big.zst").write_bytes(compress(big))
+    (tmp_path / "big.bz2").write_bytes(bz2.compress(big))
+    for name in ("big.zst", "big.bz2"):
+        with pytest.raises(ff.FFError) as e:   # (it is not a tree: but the whole text must have been decoded to say so)
+            ff.Tree.read_file(str(tmp_path / name))
+        assert e.value.code == 2
+    # output: ".zst" = one frame per part, decodable as one text; ".bz2" is refused
+    d = np.random.default_rng(12).random(50000)
+    out = tmp_path / "out.txt.zst"
+    ff.write_distances(str(out), d, 3)
+    assert decompress_frames(out.read_bytes(), 1 << 22).decode() == O.format_output(d)
+    with pytest.raises(ff.FFError) as e:
+        ff.write_distances(str(tmp_path / "out.txt.bz2"), d, 1)
+    assert e.value.code == 5 and "bzip2 output is not supported" in str(e.value)
+    # corrupt input is an I/O error, not a crash
+    for name, blob in (("bad.tree.zst", b"\x28\xb5\x2f\xfdgarbage"), ("bad.tree.bz2", b"BZh9garbage-not-bzip2"),
+                       ("cut.tree.zst", compress(big)[:1000]), ("cut.tree.bz2", bz2.compress(big)[:1000])):
+        (tmp_path / name).write_bytes(blob)
+        with pytest.raises(ff.FFError) as e:
+            ff.Tree.read_file(str(tmp_path / name))
+        assert e.value.code == 5, name
 
 
 def test_iter_pairs_and_slots():
