@@ -43,3 +43,19 @@ def test_struct_layouts():
 def test_frcfrc_binary_links_the_library():
     out = subprocess.run(["ldd", L.FRCFRC_PATH], capture_output=True, text=True).stdout
     assert "libfrackyfrac_amd.so" in out and "not found" not in out
+
+
+def test_lib_path_switch_selects_another_build(tmp_path):
+    """FF_LIB_PATH: the Python layer loads the library from there (the diagnostic build of tools/*_stamps.py)."""
+    import shutil
+    import sys
+
+    other = tmp_path / "libother.so"
+    shutil.copy(L.LIB_PATH, other)
+    code = "import frackyfrac_amd as ff, frackyfrac_amd._lib as L; L.lib(); print(L.LIB_PATH)"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, FF_LIB_PATH=str(other)))
+    assert r.returncode == 0 and r.stdout.strip() == str(other), r.stderr
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, FF_LIB_PATH=str(tmp_path / "missing.so")))
+    assert r.returncode != 0 and "there is no fallback path" in r.stderr

@@ -39,9 +39,11 @@ def _worker(rank, world, port, n_samples, transport, q):
     tree, ptr, idx, val = synth.make(n_samples, 300, 0.15, 1234)
     T = ff.parse_newick(tree.newick())
     nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
-    run = ShardedRun(nodes, True, rank, world, precision="fixed32", device=0, transport=transport)
-    if transport == "auto":  # fault injected on one rank: every rank must have taken the fallback
-        q.put((rank, run.transport))
+    run = ShardedRun(nodes, True, rank, world, precision="fixed32", device=0,
+                     transport=None if transport == "env" else transport)
+    if transport in ("auto", "env"):  # fault injected on one rank / switches from the environment: what did every rank take?
+        a, b = ff.shard_slots(n_samples, rank, world)
+        q.put((rank, run.transport, run.transport_note, run.chunks, run.n_slots == b - a))
         dist.barrier()
         run.close()
         dist.destroy_process_group()
@@ -92,5 +94,34 @@ def test_ipc_failure_on_one_rank_makes_every_rank_fall_back(monkeypatch):
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    got = sorted(q.get(timeout=5) for _ in range(3))
+    got = sorted(q.get(timeout=5)[:2] for _ in range(3))
     assert got == [(0, "nccl"), (1, "nccl"), (2, "nccl")]
+
+
+@pytest.mark.parametrize("env,want_transport,want_chunks,note", [
+    ({"FF_GATHER": "ipc"}, "ipc", 1, ""),
+    ({"FF_GATHER": "nccl"}, "nccl", 1, ""),
+    ({"FF_GATHER_MIN_GBPS": "1e9"}, "nccl", 1, "too slow"),      # a mapping that crawls must not beat RCCL to the job
+    ({"FF_GATHER_CHUNKS": "3"}, "nccl", 3, ""),                   # sub-shards are the RCCL path's pipelining
+])
+def test_gather_switches_from_the_environment(monkeypatch, env, want_transport, want_chunks, note):
+    """FF_GATHER / FF_GATHER_MIN_GBPS / FF_GATHER_CHUNKS as a launcher would set them: every rank takes the same
+    transport, says why ipc was not used, and its sub-shard plans tile its shard.  (2,000 samples: slices of 8 MB,
+    large enough for the bandwidth probe to count.)"""
+    import torch.multiprocessing as mp
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 2000, "env", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    for rank, transport, why, chunks, tiles in got:
+        assert transport == want_transport and chunks == want_chunks and tiles
+        assert note in why
