@@ -32,6 +32,12 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
 // an MI355X's 8 XCDs; 0 = rounds that ignore the XCDs).  Default 2: measured at C3, fabric
 // traffic 6.6 -> 2.2 GB per launch at the same kernel time (4 and 8 move no fewer bytes and
 // cost 0.2 % and 1.5 %: more, shorter items).
+bool xcd_slices_forced()
+{
+    const auto e = ff::tuning("FF_XCD_SLICES");
+    return e && !e->empty();
+}
+
 int xcd_slices()
 {
     const auto e = ff::tuning("FF_XCD_SLICES");
@@ -50,21 +56,30 @@ int waves_per_wg()
 
 // Balances tiles over U persistent waves.
 //
-//  * Main rounds (full-width tiles only).  Each tile is cut into S equal branch ranges,
-//    S = ceil(U / T) (1 when there are at least U tiles), and U/S tiles are handed out per
-//    round, one range per wave.  All waves of a round then sweep the branches in step on
-//    S fronts, so the rows they read are shared through L2 (each XCD's 256 waves read the
-//    same few rows; measured: without this alignment 88 % of the loads miss L2).
-//  * Remainder.  The last < U/S full tiles and all half-width tiles are cut stream-K
-//    style into U ranges of equal cost (a half-width row costs half) so that every wave
-//    ends at the same time.
+//  * Rounds (full-width tiles only).  Each tile of a round is cut into S equal branch ranges and `pr` <= U/S tiles are
+//    handed out per round, one range per wave.  All waves of a round then sweep the branches in step on S fronts, so
+//    the rows they read are shared through L2 (each XCD's 256 waves read the same few rows; measured: without this
+//    alignment 88 % of the loads miss L2).  S is chosen by estimated makespan (below).  What the first level's whole
+//    rounds leave over -- fewer than pr tiles -- gets rounds of its own with its own, deeper split (second level),
+//    as long as that is estimated to beat cutting it stream-K style.
+//  * Remainder.  What is left then, and all half-width tiles, is cut stream-K style into ranges of cost -- not equal
+//    ranges: a wave that the rounds left idle (a round rarely has work for every wave) takes remainder first, and
+//    the shares are such that every wave ends at the same time (a remainder row costs 1.30 main-round rows).
 //
-// Ranges that share a tile add their partial sums atomically; the sums are integers, so
-// the result does not depend on the order.
+// Ranges that share a tile store into planes of their own (rounds, when there are planes enough) or add their partial
+// sums atomically; the sums are integers, so the result does not depend on the order.
+//
+// The makespan estimate (unit: one full tile on one wave), fitted to measured kernel times over sample counts and
+// splits (round 3, profiles/r03_sched_split_sweep.txt: within 3 % of the measurement): a round takes 1/S plus about
+// 120 rows' worth of start-up and epilogue per item; stream-K remainder runs 1.30x slower per term (its waves are not
+// on common rows, its sums meet in atomics).  Round 2's estimate (48 rows, 1.15) and its rule "XCD-sliced rounds
+// whenever they apply" left shapes between the round sizes up to 13 % behind (5,632 samples: 0.75 of the roofline
+// where 4,096 and 8,192 reach 0.86; 0.82 now -- tools/shape_sweep.py, profiles/r03_shape_sweep_*.txt).
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                     std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw,
                     int max_planes)
 {
+    constexpr double ITEM_ROWS = 120.0, REM_COST = 1.30;
     std::vector<Tile> wide, rest;
     for (const Tile &t : all_tiles) (t.narrow ? rest : wide).push_back(t);
     // Column-segment major: the 8 consecutive tiles a workgroup gets then share their 256 columns
@@ -86,22 +101,77 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
         per[(size_t)u].push_back(it);
     };
     if (rows > 0) {
-        int64_t done = 0;  // full-width tiles scheduled in main rounds
+        int64_t done = 0;  // full-width tiles scheduled in rounds
         const int64_t n_wg = U / wpw;
-        if (xcds > 1 && 8 % xcds == 0 && n_wg % 8 == 0 && T >= n_wg / xcds * wpw &&
-            rows >= (int64_t)xcds * 8 * KSTEP) {
+        const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
+        // best split for `left` tiles (the narrow tiles and what these rounds leave go to the remainder)
+        auto choose = [&](int64_t left, int64_t *S_out, int64_t *pr_out) {
+            double best = 1e300;
+            *S_out = 1;
+            *pr_out = 0;
+            for (int64_t cand = 1; left > 0 && cand <= std::min<int64_t>(256, max_split); ++cand) {
+                const int64_t pr = std::min<int64_t>(U / cand, left) / wpw * wpw;  // a multiple of the workgroup size: the waves
+                if (pr <= 0) continue;                                            // of a workgroup hold equally long items
+                const int64_t rounds = left / pr, rem = left - rounds * pr;
+                const double est = (double)rounds / (double)cand + (double)rounds * ITEM_ROWS / (double)rows +
+                                   REM_COST * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
+                if (est < best - 1e-9) {
+                    best = est;
+                    *S_out = cand;
+                    *pr_out = pr;
+                }
+            }
+            return best;
+        };
+        // rounds of `pr` tiles in S ranges each, from tile `done` on; `level`: waves barrier together only on items all
+        // eight of a workgroup hold at the same position of their lists (pr is a multiple of the workgroup size)
+        auto plain_rounds = [&](int64_t S, int64_t pr, int64_t rounds) {
+            const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
+            for (int64_t r = 0; r < rounds; ++r)
+                for (int64_t q = 0; q < pr; ++q) {
+                    const Tile &t = wide[(size_t)(done + r * pr + q)];
+                    for (int64_t sidx = 0; sidx < S; ++sidx) {
+                        // the S ranges of a tile go to waves pr apart: neighbouring waves keep
+                        // neighbouring tiles (same columns -> one shared vector row per branch)
+                        const int u = (int)(sidx * pr + q);
+                        const size_t before = per[(size_t)u].size();
+                        push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
+                        if (per[(size_t)u].size() > before) {
+                            uint32_t &fl = per[(size_t)u].back().flags;
+                            fl |= 2u;
+                            if (S > 1 && S <= max_planes) fl = (fl & ~1u) | ((uint32_t)sidx << 3);
+                        }
+                    }
+                }
+            done += rounds * pr;
+        };
+        int64_t S = 1, per_round = 0;
+        const double best = choose(T, &S, &per_round);
+        // The XCD-sliced rounds are rounds with S = xcds whose slices are pinned to groups of XCDs: the same time as
+        // the plain S = xcds rounds, a third of the fabric traffic.  They are taken when no other split is estimated
+        // more than 1 % faster -- or whenever they apply, if FF_XCD_SLICES asks for them by name.
+        const bool xcd_ok = xcds > 1 && 8 % xcds == 0 && n_wg % 8 == 0 && T >= n_wg / xcds * wpw &&
+                            rows >= (int64_t)xcds * 8 * KSTEP;
+        bool xcd_take = false;
+        if (xcd_ok) {
+            const int64_t pr = n_wg / xcds * wpw, rounds = T / pr, rem = T - rounds * pr;
+            const double est = (double)rounds / (double)xcds + (double)rounds * ITEM_ROWS / (double)rows +
+                               REM_COST * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
+            xcd_take = xcd_slices_forced() || est <= best * 1.01;
+        }
+        if (xcd_take) {
             // Branch slices pinned to XCDs.  Workgroup g runs on XCD g mod 8 (round-robin
             // dispatch); every tile is cut into `xcds` (2, 4 or 8) equal branch ranges and range x
             // always goes to a workgroup of XCD group x (8/xcds XCDs), so each XCD's L2 only ever
             // sees 1/xcds of the staged rows and all its waves sweep that slice together.  A round
             // = 8 consecutive tiles per workgroup of ONE group's share, i.e. n_wg/xcds * 8 tiles.
             const int64_t gsz = 8 / xcds;  // XCDs per group
-            const int64_t per_round = n_wg / xcds * wpw;
+            const int64_t pr = n_wg / xcds * wpw;
             const int64_t part = round_up((rows + xcds - 1) / xcds, 2 * KSTEP);
-            const int64_t rounds = T / per_round;
+            const int64_t rounds = T / pr;
             for (int64_t r = 0; r < rounds; ++r)
-                for (int64_t q = 0; q < per_round; ++q) {
-                    const Tile &t = wide[(size_t)(r * per_round + q)];
+                for (int64_t q = 0; q < pr; ++q) {
+                    const Tile &t = wide[(size_t)(r * pr + q)];
                     const int64_t m = q / wpw, w = q % wpw;
                     for (int64_t x = 0; x < xcds; ++x) {
                         const int64_t wg = 8 * (m / gsz) + x * gsz + (m % gsz);  // m-th workgroup of group x
@@ -117,49 +187,18 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                         }
                     }
                 }
-            done = rounds * per_round;
-        } else if (T > 0) {
-            // Choose the split S by estimated makespan (unit: one full tile on one wave):
-            // rounds of `pr` tiles take 1/S each; what is left over is cut stream-K style and
-            // runs about 15 % slower per term (its waves are not on common rows).  pr is a
-            // multiple of the workgroup size, so the 8 waves of a workgroup hold the same range
-            // index and hence equally long items (they may then barrier together); a round may
-            // leave slots idle when the shard has fewer than U/S tiles.
-            const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
-            int64_t S = 1, per_round = 0;
-            double best = 1e300;
-            for (int64_t cand = 1; cand <= std::min<int64_t>(256, max_split); ++cand) {
-                const int64_t pr = std::min<int64_t>(U / cand, T) / wpw * wpw;
-                if (pr <= 0) continue;
-                const int64_t rounds = T / pr, rem = T - rounds * pr;
-                // (an item also costs about 48 rows' worth of start-up and epilogue whatever its
-                // length, which is what keeps the split from growing without bound)
-                const double est = (double)rounds / (double)cand + (double)rounds * 48.0 / (double)rows +
-                                   1.15 * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
-                if (est < best - 1e-9) {
-                    best = est;
-                    S = cand;
-                    per_round = pr;
-                }
-            }
-            const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
-            const int64_t rounds = per_round > 0 ? T / per_round : 0;
-            for (int64_t r = 0; r < rounds; ++r)
-                for (int64_t q = 0; q < per_round; ++q) {
-                    const Tile &t = wide[(size_t)(r * per_round + q)];
-                    for (int64_t sidx = 0; sidx < S; ++sidx) {
-                        // the S ranges of a tile go to waves per_round apart: neighbouring waves keep
-                        // neighbouring tiles (same columns -> one shared vector row per branch)
-                        const int u = (int)(sidx * per_round + q);
-                        push(u, t, std::min(rows, sidx * part), std::min(rows, (sidx + 1) * part));
-                        if (!per[(size_t)u].empty() && (int64_t)per[(size_t)u].size() == r + 1) {
-                            uint32_t &fl = per[(size_t)u].back().flags;
-                            fl |= 2u;
-                            if (S > 1 && S <= max_planes) fl = (fl & ~1u) | ((uint32_t)sidx << 3);
-                        }
-                    }
-                }
-            done = rounds * per_round;
+            done = rounds * pr;
+        } else if (T > 0 && per_round > 0) {
+            plain_rounds(S, per_round, T / per_round);
+        }
+        // Second level: the tiles the whole rounds left over, in rounds with a split of their own, if that is
+        // estimated to finish sooner than cutting them stream-K style with the half-width tiles.
+        if (T - done >= wpw) {
+            const int64_t left = T - done;
+            int64_t S2 = 1, pr2 = 0;
+            const double with_rounds = choose(left, &S2, &pr2);
+            const double stream_only = REM_COST * ((double)left + 0.5 * (double)rest.size()) / (double)U;
+            if (pr2 > 0 && with_rounds < stream_only - 1e-9) plain_rounds(S2, pr2, left / pr2);
         }
         rest.insert(rest.begin(), wide.begin() + done, wide.end());  // leftover full tiles first
         if (!rest.empty()) {
@@ -167,11 +206,42 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
             std::vector<int64_t> start(rest.size() + 1, 0);
             for (size_t t = 0; t < rest.size(); ++t) start[t + 1] = start[t] + rows * (rest[t].narrow ? 1 : 2);
             const int64_t total = start.back();
-            const int64_t share = round_up((total + U - 1) / U, 4 * KSTEP);  // 32 units: 16 wide or 32 narrow rows
-            size_t t = 0;
+            // Shares: wave u holds load[u] units of round work; with the level L at which every wave ends, it takes
+            // (L - load[u]) / REM_COST units of remainder (none if it is above the level).  L by bisection; shares
+            // are whole multiples of 32 units (16 wide or 32 narrow rows), what rounding leaves goes round-robin.
+            std::vector<double> load((size_t)U, 0.0);
+            double lo = 0, hi = 0;
             for (int u = 0; u < U; ++u) {
-                int64_t a = (int64_t)u * share;
-                const int64_t b = std::min(total, a + share);
+                for (const Item &it : per[(size_t)u]) load[(size_t)u] += 2.0 * (double)(it.k1 - it.k0) + 2.0 * ITEM_ROWS;
+                hi = std::max(hi, load[(size_t)u]);
+            }
+            hi += REM_COST * (double)total;
+            for (int iter = 0; iter < 60; ++iter) {
+                const double L = 0.5 * (lo + hi);
+                double got = 0;
+                for (int u = 0; u < U; ++u) got += std::max(0.0, L - load[(size_t)u]) / REM_COST;
+                (got >= (double)total ? hi : lo) = L;
+            }
+            const int64_t q32 = 4 * KSTEP;
+            std::vector<int64_t> share((size_t)U, 0);
+            int64_t sum = 0;
+            for (int u = 0; u < U; ++u) {
+                share[(size_t)u] = (int64_t)(std::max(0.0, hi - load[(size_t)u]) / REM_COST / (double)q32) * q32;
+                sum += share[(size_t)u];
+            }
+            // (rounded down above: a few 32-unit steps are missing; they go to waves at or below the level)
+            for (int u = 0, skipped = 0; sum < total; u = (u + 1) % U)
+                if (share[(size_t)u] > 0 || load[(size_t)u] <= lo || skipped >= U) {
+                    share[(size_t)u] += q32;
+                    sum += q32;
+                    skipped = 0;
+                } else {
+                    ++skipped;
+                }
+            size_t t = 0;
+            int64_t a = 0;
+            for (int u = 0; u < U && a < total; ++u) {
+                const int64_t b = std::min(total, a + share[(size_t)u]);
                 while (a < b) {
                     while (start[t + 1] <= a) ++t;
                     const int64_t unit = rest[t].narrow ? 1 : 2;

@@ -104,6 +104,7 @@ struct Tile {
 };
 
 int xcd_slices();
+bool xcd_slices_forced();  // FF_XCD_SLICES is set: the XCD-sliced rounds wherever they apply
 void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles);
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std::vector<Item> *items,
                     std::vector<int32_t> *item_ptr, double *elements, int xcds = 0, int wpw = WAVES_PER_WG,
