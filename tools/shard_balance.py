@@ -7,9 +7,12 @@ import numpy as np, torch
 import frackyfrac_amd as ff
 from frackyfrac_amd import synth
 
-cfg = synth.CONFIGS["C3"]
-for G in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-    n = cfg["n_samples"] if G == 1 else int(round(cfg["n_samples"] * math.sqrt(G) / 32.0)) * 32
+# (--strong C4 | C5: the stated size of that configuration, row shards over G ranks)
+strong = sys.argv[sys.argv.index("--strong") + 1] if "--strong" in sys.argv else None
+cfg = synth.CONFIGS[strong or "C3"]
+args = [a for a in sys.argv[1:] if a not in ("--strong", strong)]
+for G in [int(a) for a in args] or [1, 2, 4, 8]:
+    n = cfg["n_samples"] if (G == 1 or strong) else int(round(cfg["n_samples"] * math.sqrt(G) / 32.0)) * 32
     tree, ptr, idx, val = synth.make(n, cfg["n_leaves"], cfg["density"], cfg["seed"])
     T = ff.parse_newick(tree.newick())
     nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
