@@ -889,12 +889,36 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         // vector ALU: the lowest tile that still keeps them all resident (C2: 1.31 ms with 16 rows, 0.84 with 8,
         // 0.56 with 4; 2 rows and 16 two-value scalar loads per trip are slower again: 0.75).
         const int64_t resident = (int64_t)inf.n_compute_units * 4 * 8;
+        bool small = false;
         for (int cand : {4, 8}) {
             std::vector<Tile> count;
             build_tiles(inf.n_samples, inf.row_begin, inf.row_end, cand, X_TILE_J, false, &count);
             if ((int64_t)count.size() <= resident) {
                 h = cand;
+                small = true;
                 break;
+            }
+        }
+        // Larger shards are bound by the vector ALU, every SIMD working through the tiles it is dealt one after the
+        // other (interleaved): a SIMD gets floor or ceil of tiles / SIMDs of them, and the kernel ends with the SIMDs
+        // that got the ceiling -- so the height decides how much of the last "tile per SIMD" is idle.  With
+        // avg = tiles(h) / SIMDs the efficiency is avg / ceil(avg), times what the height itself is worth (scalar
+        // operands per trip, waves per SIMD; from the sweep's largest sizes).  This ranks the five heights as
+        // measured at every size of tools/exact64_sweep.py (round 3; the fixed 12 rows of round 2 lost 6 % at 3,072
+        // samples, 4 % at 2,048 and 3,584); 4,096 samples keep their 12 rows.
+        if (!small) {
+            const double simds = (double)inf.n_compute_units * 4.0;
+            double best_score = 0;
+            for (int cand : {8, 10, 12, 14, 16}) {
+                std::vector<Tile> count;
+                build_tiles(inf.n_samples, inf.row_begin, inf.row_end, cand, X_TILE_J, false, &count);
+                const double avg = (double)count.size() / simds;
+                const double worth = cand == 8 ? 0.95 : cand == 10 ? 0.97 : cand == 16 ? 0.985 : 1.0;
+                const double score = worth * avg / std::ceil(avg);
+                if (score > best_score + 1e-12) {
+                    best_score = score;
+                    h = cand;
+                }
             }
         }
         for (int cand : X_TILE_HEIGHTS)
