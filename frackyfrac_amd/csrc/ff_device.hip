@@ -645,16 +645,25 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     std::vector<Tile> tiles;
     build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, true, &tiles);
     inf.n_tiles = (int64_t)tiles.size();
-    // 8 waves per workgroup (two per SIMD) for pair_sad_kernel and the sparse-aware kernel, 12 (three
-    // per SIMD, paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12
-    // forces one; otherwise the 12-wave variant takes shards that fill its 12 x CUs wave slots for at
-    // least two whole rounds and whose matrix is small enough for four rows of prefetch -- measured:
-    // 16384 x 10k leaves (1.3 GB, 5.4 rounds) 80.3 -> 77.3 ms; one round or less (4096 samples; an
-    // eighth of 16384) and the 3.3 GB matrix of 8192 x 50k leaves lose 1-2 % with it.
+    // 8 waves per workgroup (two per SIMD) for pair_sad_kernel and the sparse-aware kernel, 12 (three per SIMD,
+    // paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12 forces one; otherwise
+    // the 12-wave variant takes every shard whose full-width tiles fill a round of ITS two XCD-sliced halves (1,536
+    // tiles on 256 CUs: about 5,000 samples up, or a row shard of that many pairs).  (Round 2 kept it for shards of
+    // two or more such rounds under 2 GB staged: with that round's schedule it lost 1-2 % on the 3.3 GB matrix of
+    // 8,192 x 50k leaves.  With the round-3 schedule it wins wherever its sliced rounds apply -- tools/shape_sweep.py
+    // with either value: 5,120 samples 7.96 -> 7.58 ms, 8,192 19.9 -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9 -- and
+    // by 1-4 % from 3,072 samples up with plain thirds; but on two of the eight row shards of an 11,584-sample
+    // problem those plain thirds ran 7 and 15 % SLOWER than the 8-wave kernel's sliced halves, some XCDs far behind
+    // the others (tools/experiments/xcd_variants.py), so below its own sliced rounds the 8-wave kernel stays.)
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() &&
-        inf.n_tiles >= 2 * (int64_t)pl->n_workgroups * L_WAVES_PER_WG && inf.staged_bytes <= 2.0e9)
-        pl->waves_per_wg = L_WAVES_PER_WG;
+    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value()) {
+        int64_t wide = 0;
+        for (const Tile &t : tiles) wide += t.narrow ? 0 : 1;
+        // (and only shards that begin at row 0 -- whole problems, a first shard: on the trapezoid of a later row
+        // shard the 12-wave kernel gains nothing on average and has outliers, 10.43 against 10.03 ms on shard 6 of 8 of
+        // 16,384 samples, so the ranks of a multi-GPU run, whose slowest one sets the time, keep the 8-wave kernel)
+        if (wide >= (int64_t)pl->n_workgroups / 2 * L_WAVES_PER_WG && inf.row_begin == 0) pl->waves_per_wg = L_WAVES_PER_WG;
+    }
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     const int U = pl->n_workgroups * pl->waves_per_wg;
     inf.n_wave_slots = U;

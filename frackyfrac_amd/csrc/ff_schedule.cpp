@@ -89,7 +89,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
     // at C3, kernel times unchanged.
     std::stable_sort(wide.begin(), wide.end(), [](const Tile &a, const Tile &b) { return a.j0 < b.j0; });
     const int64_t T = (int64_t)wide.size();
-    std::vector<std::vector<Item>> per((size_t)U);
+    const std::vector<Tile> narrow_tiles = rest;  // (an attempt appends the full tiles its rounds leave over to its own copy)
+    std::vector<std::vector<Item>> per;            // the schedule being built by the current attempt
     auto push = [&](int u, const Tile &t, int64_t k0, int64_t k1) {
         if (k1 <= k0) return;
         Item it{};
@@ -100,9 +101,15 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
         it.flags = ((k0 == 0 && k1 == rows) ? 0u : 1u) | (t.narrow ? 4u : 0u);
         per[(size_t)u].push_back(it);
     };
-    if (rows > 0) {
+    // One attempt: first-level rounds of the given kind (x > 0: XCD-sliced with x slices; else plain rounds with split
+    // S0 and pr0 tiles per round), second-level rounds, levelled remainder.  Returns the estimated makespan in cost
+    // units (the load of the busiest wave: 2 per main-round row, 2 * ITEM_ROWS per item, REM_COST per remainder unit).
+    const int64_t n_wg = U / wpw;
+    auto attempt = [&](int x, int64_t S0, int64_t pr0) -> double {
+        per.assign((size_t)U, std::vector<Item>());
+        rest = narrow_tiles;
+        double makespan = 0;
         int64_t done = 0;  // full-width tiles scheduled in rounds
-        const int64_t n_wg = U / wpw;
         const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));  // ranges of >= 64 rows
         // best split for `left` tiles (the narrow tiles and what these rounds leave go to the remainder)
         auto choose = [&](int64_t left, int64_t *S_out, int64_t *pr_out) {
@@ -125,7 +132,15 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
         };
         // rounds of `pr` tiles in S ranges each, from tile `done` on; `level`: waves barrier together only on items all
         // eight of a workgroup hold at the same position of their lists (pr is a multiple of the workgroup size)
-        auto plain_rounds = [&](int64_t S, int64_t pr, int64_t rounds) {
+        int64_t planes_used = 1;  // accumulator planes the first level's ranges own (the finish kernel reads every plane of every slot)
+        auto plain_rounds = [&](int64_t S, int64_t pr, int64_t rounds, bool first_level) {
+            // (the finish kernel reads every plane of every slot, about 8,192 slots a tile: a second level adds planes
+            // of its own while reading them stays under a quarter of a gigabyte -- 2,560 samples with a twelve-fold
+            // second level: 2.03 ms with planes, 2.11 adding atomically -- beyond that its ranges add atomically, like
+            // the remainder's)
+            const bool planes = S > 1 && S <= max_planes &&
+                                (first_level || S <= planes_used || (double)all_tiles.size() * 8192.0 * 4.0 * (double)S <= 268435456.0);
+            if (first_level && planes) planes_used = S;
             const int64_t part = round_up((rows + S - 1) / S, 2 * KSTEP);
             for (int64_t r = 0; r < rounds; ++r)
                 for (int64_t q = 0; q < pr; ++q) {
@@ -139,27 +154,14 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                         if (per[(size_t)u].size() > before) {
                             uint32_t &fl = per[(size_t)u].back().flags;
                             fl |= 2u;
-                            if (S > 1 && S <= max_planes) fl = (fl & ~1u) | ((uint32_t)sidx << 3);
+                            if (planes) fl = (fl & ~1u) | ((uint32_t)sidx << 3);
                         }
                     }
                 }
             done += rounds * pr;
         };
-        int64_t S = 1, per_round = 0;
-        const double best = choose(T, &S, &per_round);
-        // The XCD-sliced rounds are rounds with S = xcds whose slices are pinned to groups of XCDs: the same time as
-        // the plain S = xcds rounds, a third of the fabric traffic.  They are taken when no other split is estimated
-        // more than 1 % faster -- or whenever they apply, if FF_XCD_SLICES asks for them by name.
-        const bool xcd_ok = xcds > 1 && 8 % xcds == 0 && n_wg % 8 == 0 && T >= n_wg / xcds * wpw &&
-                            rows >= (int64_t)xcds * 8 * KSTEP;
-        bool xcd_take = false;
-        if (xcd_ok) {
-            const int64_t pr = n_wg / xcds * wpw, rounds = T / pr, rem = T - rounds * pr;
-            const double est = (double)rounds / (double)xcds + (double)rounds * ITEM_ROWS / (double)rows +
-                               REM_COST * ((double)rem + 0.5 * (double)rest.size()) / (double)U;
-            xcd_take = xcd_slices_forced() || est <= best * 1.01;
-        }
-        if (xcd_take) {
+        if (x > 0) {
+            const int xcds = x;
             // Branch slices pinned to XCDs.  Workgroup g runs on XCD g mod 8 (round-robin
             // dispatch); every tile is cut into `xcds` (2, 4 or 8) equal branch ranges and range x
             // always goes to a workgroup of XCD group x (8/xcds XCDs), so each XCD's L2 only ever
@@ -183,13 +185,16 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                             fl |= 2u;
                             // one plane of accumulators per range: each stores its sums plainly
                             // into its own plane instead of adding atomically
-                            if (xcds <= max_planes && part < rows) fl = (fl & ~1u) | ((uint32_t)x << 3);
+                            if (xcds <= max_planes && part < rows) {
+                                fl = (fl & ~1u) | ((uint32_t)x << 3);
+                                planes_used = xcds;
+                            }
                         }
                     }
                 }
             done = rounds * pr;
-        } else if (T > 0 && per_round > 0) {
-            plain_rounds(S, per_round, T / per_round);
+        } else if (T > 0 && pr0 > 0) {
+            plain_rounds(S0, pr0, T / pr0, true);
         }
         // Second level: the tiles the whole rounds left over, in rounds with a split of their own, if that is
         // estimated to finish sooner than cutting them stream-K style with the half-width tiles.
@@ -198,7 +203,8 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
             int64_t S2 = 1, pr2 = 0;
             const double with_rounds = choose(left, &S2, &pr2);
             const double stream_only = REM_COST * ((double)left + 0.5 * (double)rest.size()) / (double)U;
-            if (pr2 > 0 && with_rounds < stream_only - 1e-9) plain_rounds(S2, pr2, left / pr2);
+            // (its ranges own planes only if the first level has as many: a deeper split adds atomically, like the remainder)
+            if (pr2 > 0 && with_rounds < stream_only - 1e-9) plain_rounds(S2, pr2, left / pr2, false);
         }
         rest.insert(rest.begin(), wide.begin() + done, wide.end());  // leftover full tiles first
         if (!rest.empty()) {
@@ -222,6 +228,7 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                 for (int u = 0; u < U; ++u) got += std::max(0.0, L - load[(size_t)u]) / REM_COST;
                 (got >= (double)total ? hi : lo) = L;
             }
+            makespan = hi;
             const int64_t q32 = 4 * KSTEP;
             std::vector<int64_t> share((size_t)U, 0);
             int64_t sum = 0;
@@ -252,6 +259,69 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                 }
             }
         }
+        for (int u = 0; u < U; ++u) {  // (no remainder: the busiest wave of the rounds)
+            double l = 0;
+            for (const Item &it : per[(size_t)u])
+                l += ((it.flags & 2u) ? 2.0 : REM_COST * ((it.flags & 4u) ? 1.0 : 2.0)) * (double)(it.k1 - it.k0) + 2.0 * ITEM_ROWS;
+            makespan = std::max(makespan, l);
+        }
+        return makespan;
+    };
+    if (rows > 0) {
+        // Candidates for the first level: the plain rounds with the best estimated split, and the XCD-sliced rounds --
+        // rounds with S = 2, 4 or 8 whose slices are pinned to groups of XCDs, so that an XCD's L2 sees one front of
+        // the sweep instead of all of them.  Every candidate is built, its makespan estimated from the loads of its
+        // waves, and the best is kept; an XCD-sliced candidate is preferred unless the plain rounds are estimated more
+        // than 3 % faster: slicing costs about half a percent where it is not needed (4,096 samples: 4.92 -> 4.94 ms)
+        // and is worth 7-12 % on some row shards of a multi-GPU run, whose plain rounds run far slower on some XCDs
+        // than on others (round 3: shards 3 and 4 of 8 of 11,584 samples, 5.67 / 5.23 ms with plain thirds, 5.02 /
+        // 4.86 with four slices, the other six shards within 1 % either way; tools/experiments/xcd_variants.py --
+        // the estimate cannot tell those shards from the others, so the preference is general).
+        // FF_XCD_SLICES = 0 forbids the sliced rounds, 2 / 4 / 8 asks for that slicing wherever it applies.
+        struct Cand {
+            int x;
+            int64_t S, pr;
+            double est;
+        };
+        std::vector<Cand> cands;
+        {
+            per.assign((size_t)U, std::vector<Item>());
+            const int64_t max_split = std::max<int64_t>(1, rows / (8 * KSTEP));
+            double best = 1e300;
+            Cand g{0, 1, 0, 0};
+            for (int64_t cand = 1; T > 0 && cand <= std::min<int64_t>(256, max_split); ++cand) {
+                const int64_t pr = std::min<int64_t>(U / cand, T) / wpw * wpw;
+                if (pr <= 0) continue;
+                const int64_t rounds = T / pr, rem = T - rounds * pr;
+                const double est = (double)rounds / (double)cand + (double)rounds * ITEM_ROWS / (double)rows +
+                                   REM_COST * ((double)rem + 0.5 * (double)narrow_tiles.size()) / (double)U;
+                if (est < best - 1e-9) {
+                    best = est;
+                    g.S = cand;
+                    g.pr = pr;
+                }
+            }
+            cands.push_back(g);
+        }
+        const bool forced = xcd_slices_forced();
+        for (int x : {2, 4, 8}) {
+            if (xcds <= 0 || (forced && x != xcds)) continue;
+            if (n_wg % 8 == 0 && T >= n_wg / x * wpw && rows >= (int64_t)x * 8 * KSTEP) cands.push_back({x, 0, 0, 0});
+        }
+        if (forced && cands.size() > 1) cands.erase(cands.begin());  // (asked for by name: the sliced rounds, where they apply)
+        size_t pick = 0;
+        double pick_score = 1e300;
+        for (size_t c = 0; c < cands.size(); ++c) {
+            cands[c].est = attempt(cands[c].x, cands[c].S, cands[c].pr);
+            const double score = cands[c].est * (cands[c].x > 0 ? 0.97 : 1.0);
+            if (score < pick_score - 1e-9) {
+                pick_score = score;
+                pick = c;
+            }
+        }
+        if (pick + 1 != cands.size() || cands.empty()) attempt(cands[pick].x, cands[pick].S, cands[pick].pr);  // (rebuild the one kept)
+    } else {
+        per.assign((size_t)U, std::vector<Item>());
     }
     items->clear();
     item_ptr->assign((size_t)U + 1, 0);

@@ -773,9 +773,13 @@ def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
 
 
 def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
-    """A shard with at least two rounds of 12 x CUs pair tiles (and a staged matrix under 2 GB) is
-    scheduled on the 12-wave register kernel without any switch being set; the choice is
-    bit-neutral: forcing the 8-wave kernel gives the same distances."""
+    """A shard whose full-width pair tiles fill a round of the 12-wave kernel's two XCD-sliced halves (6 tiles per CU:
+    about 5,000 samples up on 256 CUs) is scheduled on that kernel without any switch being set, a smaller one on the
+    8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same distances."""
+    small, *_ = synth_problem(4096, 150, 0.2, 79)
+    plan = ff.Plan(small, True, precision="fixed32")
+    assert plan.info.n_tiles < 6 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
+    plan.close()
     nodes, ip, on, ft = synth_problem(10240, 150, 0.2, 78)
     plan = ff.Plan(nodes, True, precision="fixed32")
     cus = plan.info.n_compute_units
