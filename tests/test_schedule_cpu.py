@@ -10,12 +10,12 @@ import frackyfrac_amd as ff
 from frackyfrac_amd import _lib as L
 
 
-def schedule(kernel, n, rows, rb, re, n_cu, digits=2, narrow=1):
+def schedule(kernel, n, rows, rb, re, n_cu, digits=2, narrow=1, wpw=8):
     fn = L.lib().ff_debug_schedule
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
-    slots = n_cu * 8 if kernel == 0 else n_cu  # SAD: 8 waves per CU; MFMA: one workgroup per CU
+    slots = n_cu * wpw if kernel == 0 else n_cu  # SAD: 8 (or 12) waves per CU; MFMA: one workgroup per CU
     cap = 1 << 20
     items = np.zeros((cap, 8), dtype=np.int32)
     ptr = np.zeros(slots + 1, dtype=np.int32)
@@ -36,10 +36,15 @@ def pair_cover(n, rb, re):
                                          (4096, 20000, 256), (700, 64, 256), (5000, 100000, 256)])
 @pytest.mark.parametrize("world", [1, 3])
 @pytest.mark.parametrize("narrow", [0, 1])
-def test_sad_schedule_covers_pairs_and_rows_once(n, rows, n_cu, world, narrow):
+@pytest.mark.parametrize("wpw", [8, 12])
+def test_sad_schedule_covers_pairs_and_rows_once(monkeypatch, n, rows, n_cu, world, narrow, wpw):
+    """Whatever the first level turns out to be (plain rounds, XCD-sliced rounds), with or without a second level,
+    for the 8- and the 12-wave kernel: every pair of the shard in exactly one tile, every tile's branch rows covered
+    once, atomics exactly on ranges that share accumulators, barrier items matched within a workgroup, loads level."""
+    monkeypatch.setenv("FF_WAVES_PER_WG", str(wpw))
     for rank in range(world):
         rb, re = ff.shard_rows(n, rank, world)
-        items, ptr, n_tiles = schedule(0, n, rows, rb, re, n_cu, narrow=narrow)
+        items, ptr, n_tiles = schedule(0, n, rows, rb, re, n_cu, narrow=narrow, wpw=wpw)
         assert ptr[0] == 0 and ptr[-1] == len(items) and np.all(np.diff(ptr) >= 0)
         tiles = {}
         for i0, j0, k0, k1, flags, *_ in items:
@@ -62,13 +67,13 @@ def test_sad_schedule_covers_pairs_and_rows_once(n, rows, n_cu, world, narrow):
             want = pair_cover(n, rb, re)
             assert np.all(cover[want == 1] == 1)          # every pair of the shard in exactly one tile
         # items flagged for the in-workgroup barrier: same position, same length on all 8 waves
-        for wg in range(len(ptr) // 8):
-            lists = [items[ptr[8 * wg + w]:ptr[8 * wg + w + 1]] for w in range(8)]
+        for wg in range(len(ptr) // wpw):
+            lists = [items[ptr[wpw * wg + w]:ptr[wpw * wg + w + 1]] for w in range(wpw)]
             depth = max(len(x) for x in lists)
             for pos in range(depth):
                 flagged = [x[pos] for x in lists if len(x) > pos and (x[pos][4] & 2)]
                 if flagged:
-                    assert len(flagged) == 8 and len({int(f[3] - f[2]) for f in flagged}) == 1
+                    assert len(flagged) == wpw and len({int(f[3] - f[2]) for f in flagged}) == 1
         # balance: no wave carries more than its share plus one range
         if len(items) and rows >= 1024:   # (with a handful of rows a tile cannot be cut)
             cost = np.array([(it[3] - it[2]) * (1 if (it[4] & 4) else 2) for it in items], dtype=np.int64)
@@ -99,7 +104,8 @@ def test_xcd_sliced_rounds_pin_branch_slices_to_xcds(monkeypatch):
     for ranges in cover.values():
         ranges.sort()
         assert ranges[0][0] == 0 and ranges[-1][1] == rows and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-    test_sad_schedule_covers_pairs_and_rows_once(1000, 20000, 256, 3, 1)
+    test_sad_schedule_covers_pairs_and_rows_once(monkeypatch, 1000, 20000, 256, 3, 1, 8)
+    monkeypatch.setenv("FF_XCD_SLICES", "8")
 
 
 @pytest.mark.parametrize("n,slabs,n_cu,digits", [(5, 3, 8, 1), (300, 60, 8, 2), (1000, 313, 256, 3), (4096, 313, 256, 2),
