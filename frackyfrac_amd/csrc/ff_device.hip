@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ff_dither.hpp"
@@ -170,6 +171,13 @@ int env_int(const char *name, int dflt)
     return atoi(v->c_str());
 }
 
+// Host threads for a pass over `work` flat nodes: one per 2 M, at most 8 (and never more than the machine has).
+unsigned host_threads(int64_t work)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, hw), work / 2000000));
+}
+
 int validate_problem(const ff_problem *p, char *err, size_t errlen)
 {
     if (!p) return ff::fail(FF_ERR_ARG, err, errlen, "null problem");
@@ -182,20 +190,39 @@ int validate_problem(const ff_problem *p, char *err, size_t errlen)
         return ff::fail(FF_ERR_ARG, err, errlen, "too many samples (%lld)", (long long)p->n_samples);
     if (p->n_samples == 0) return FF_OK;
     if (p->indptr[0] != 0) return ff::fail(FF_ERR_ARG, err, errlen, "indptr[0] != 0");
-    for (int64_t s = 0; s < p->n_samples; ++s) {
-        int64_t b = p->indptr[s], e = p->indptr[s + 1];
-        if (e < b) return ff::fail(FF_ERR_ARG, err, errlen, "indptr not monotone at sample %lld", (long long)s);
-        for (int64_t t = b; t < e; ++t) {
-            int32_t id = p->branch_id[t];
-            if (id < 0 || id >= p->n_branches)
-                return ff::fail(FF_ERR_ARG, err, errlen, "sample %lld: branch id %d out of range", (long long)s, id);
-            if (t > b && id <= p->branch_id[t - 1])
-                return ff::fail(FF_ERR_ARG, err, errlen,
-                                "sample %lld: branch ids not strictly ascending", (long long)s);
-            if (!(p->abnd[t] > 0) || !std::isfinite(p->abnd[t]))
-                return ff::fail(FF_ERR_ARG, err, errlen,
-                                "sample %lld: abundance must be finite and > 0", (long long)s);
+    for (int64_t s = 0; s < p->n_samples; ++s)
+        if (p->indptr[s + 1] < p->indptr[s])
+            return ff::fail(FF_ERR_ARG, err, errlen, "indptr not monotone at sample %lld", (long long)s);
+    // the flat nodes themselves: 21 M of them at C3 -- on a few host threads (this pass and the weights below were
+    // 40 of the 50 ms of a one-shot ff_unifrac_dists there); the first offending sample in sample order is reported
+    const unsigned nt = host_threads(p->indptr[p->n_samples]);
+    std::vector<int64_t> bad_sample(nt, -1);
+    std::vector<int> bad_kind(nt, 0);
+    std::vector<int32_t> bad_id(nt, 0);
+    ff::parallel_for(p->n_samples, nt, [&](unsigned th, int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1 && bad_sample[th] < 0; ++s) {
+            const int64_t b = p->indptr[s], e = p->indptr[s + 1];
+            for (int64_t t = b; t < e; ++t) {
+                const int32_t id = p->branch_id[t];
+                int kind = 0;
+                if (id < 0 || id >= p->n_branches) kind = 1;
+                else if (t > b && id <= p->branch_id[t - 1]) kind = 2;
+                else if (!(p->abnd[t] > 0) || !std::isfinite(p->abnd[t])) kind = 3;
+                if (kind) {
+                    bad_sample[th] = s;
+                    bad_kind[th] = kind;
+                    bad_id[th] = id;
+                    break;
+                }
+            }
         }
+    });
+    for (unsigned th = 0; th < nt; ++th) {  // (threads hold ascending sample ranges)
+        if (bad_sample[th] < 0) continue;
+        const long long s = (long long)bad_sample[th];
+        if (bad_kind[th] == 1) return ff::fail(FF_ERR_ARG, err, errlen, "sample %lld: branch id %d out of range", s, bad_id[th]);
+        if (bad_kind[th] == 2) return ff::fail(FF_ERR_ARG, err, errlen, "sample %lld: branch ids not strictly ascending", s);
+        return ff::fail(FF_ERR_ARG, err, errlen, "sample %lld: abundance must be finite and > 0", s);
     }
     return FF_OK;
 }
@@ -421,11 +448,13 @@ int csr_from_host(const ff_problem *p, DeviceCsr *c, char *err, size_t errlen)
     if (N > 0) memcpy(c->h_indptr.data(), p->indptr, sizeof(int64_t) * (size_t)(N + 1));
     c->h_len.assign(p->branch_len, p->branch_len + B);
     c->h_weight.assign((size_t)N, 0.0);
-    for (int64_t s = 0; s < N; ++s) {
-        double w = 0;
-        for (int64_t t = p->indptr[s]; t < p->indptr[s + 1]; ++t) w += p->branch_len[p->branch_id[t]] * p->abnd[t];
-        c->h_weight[(size_t)s] = w;
-    }
+    ff::parallel_for(N, host_threads(c->nnz), [&](unsigned, int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s) {
+            double w = 0;
+            for (int64_t t = p->indptr[s]; t < p->indptr[s + 1]; ++t) w += p->branch_len[p->branch_id[t]] * p->abnd[t];
+            c->h_weight[(size_t)s] = w;
+        }
+    });
     FF_HIP(hipMalloc(&c->d_indptr, sizeof(int64_t) * (size_t)(N + 1)));
     FF_HIP(hipMalloc(&c->d_ids, sizeof(int32_t) * (size_t)std::max<int64_t>(c->nnz, 1)));
     FF_HIP(hipMalloc(&c->d_abnd, sizeof(double) * (size_t)std::max<int64_t>(c->nnz, 1)));
