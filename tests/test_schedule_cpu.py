@@ -314,3 +314,27 @@ def test_exact64_operands_past_the_last_row_are_padded():
             ld = (n + 63) // 64 * 64
             i0_max = (n - 1) // h * h          # build_tiles: i0 = multiples of h below the shard's end
             assert i0_max + h - 1 < ld + lay["X_VALUES_PAD"]
+
+
+def test_row_shards_of_a_multi_gpu_run_take_xcd_sliced_rounds(monkeypatch):
+    """Regression guard for round 3's finding: on shards 3 and 4 of 8 of an 11,584-sample problem the
+    12-wave kernel's PLAIN thirds ran 15 and 7 % slower than sliced rounds (some XCDs far behind the others); the
+    schedule therefore keeps an XCD-sliced first level unless plain rounds are estimated more than 3 % faster.  These
+    shards hold 1,008 full-width tiles -- too few for a round of two sliced halves (1,024 with 8 waves per workgroup,
+    1,536 with 12) -- so the first level is four sliced quarters either way, never plain halves or thirds."""
+    n, rows = 11584, 20000
+    for wpw, want_parts in ((8, 4), (12, 4)):
+        monkeypatch.setenv("FF_WAVES_PER_WG", str(wpw))
+        for rank in (3, 4):
+            rb, re = ff.shard_rows(n, rank, 8)
+            items, ptr, n_tiles = schedule(0, n, rows, rb, re, 256, wpw=wpw)
+            first = [items[ptr[u]] for u in range(256 * wpw) if ptr[u + 1] > ptr[u] and (items[ptr[u]][4] & 2)]
+            lengths = {int(it[3] - it[2]) for it in first}
+            part = ((rows + want_parts - 1) // want_parts + 15) // 16 * 16
+            assert lengths <= {part, rows - (want_parts - 1) * part}, (wpw, rank, lengths)
+            # pinned: workgroup g (XCD g mod 8) only ever sweeps the slice of its XCD group
+            gsz = 8 // want_parts
+            for u in range(256 * wpw):
+                if ptr[u + 1] > ptr[u] and (items[ptr[u]][4] & 2):
+                    x = ((u // wpw) % 8) // gsz
+                    assert int(items[ptr[u]][2]) == x * part
