@@ -16,7 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 tree, ptr, idx, val = synth.make(n, leaves, 0.1, synth.CONFIGS["C3"]["seed"])
 rng = np.random.default_rng(5)
-for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e-3 u), u uniform"):
+for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e-3 u), u uniform",
+              "log-normal lengths (sigma 1.5), as in a real phylogeny"):
     nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
     plan = ff.Plan(nodes, False, precision="fixed32")
     out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
@@ -33,4 +34,11 @@ for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e
     ms, k = plan.timing_collect()
     print("%-44s digits %d  items %d  pair kernel %.4f ms  pass %.4f ms" % (
         label, plan.info.n_digits, plan.info.n_items, ms / k, e0.elapsed_time(e1) / 20), flush=True)
-    tree.branch_len = tree.branch_len * (1.0 + 1e-3 * rng.random(tree.branch_len.shape[0]))
+    q, cap = plan.refined_pairs()
+    print("%-44s    scale 2^%d, pairs sent to the binary64 walk %d" % ("", plan.info.scale_log2, q), flush=True)
+    if label.startswith("generator"):
+        tree.branch_len = tree.branch_len * (1.0 + 1e-3 * rng.random(tree.branch_len.shape[0]))
+    else:
+        bl = rng.lognormal(-3.0, 1.5, tree.branch_len.shape[0])
+        bl[0] = 0.0
+        tree.branch_len = bl
