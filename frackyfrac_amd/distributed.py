@@ -506,7 +506,9 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
                 failure = e
             worst = status_all(2 if failure is not None else 0, group, run.device) if world > 1 else (2 if failure else 0)
             if worst:
-                run.close(collective=world > 1 and failure is None)
+                # (every rank has drained its device above, so no copy into the root's array is in flight: nobody
+                # needs to wait for anybody before unmapping / freeing)
+                run.close(collective=False)
                 raise failure if failure is not None else RuntimeError("frackyfrac_amd: another rank's step failed")
             try:
                 run.wait()
