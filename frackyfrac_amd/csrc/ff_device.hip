@@ -676,23 +676,20 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     inf.n_tiles = (int64_t)tiles.size();
     // 8 waves per workgroup (two per SIMD) for pair_sad_kernel and the sparse-aware kernel, 12 (three per SIMD,
     // paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12 forces one; otherwise
-    // the 12-wave variant takes every shard whose full-width tiles fill a round of ITS two XCD-sliced halves (1,536
-    // tiles on 256 CUs: about 5,000 samples up, or a row shard of that many pairs).  (Round 2 kept it for shards of
-    // two or more such rounds under 2 GB staged: with that round's schedule it lost 1-2 % on the 3.3 GB matrix of
-    // 8,192 x 50k leaves.  With the round-3 schedule it wins wherever its sliced rounds apply -- tools/shape_sweep.py
-    // with either value: 5,120 samples 7.96 -> 7.58 ms, 8,192 19.9 -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9 -- and
-    // by 1-4 % from 3,072 samples up with plain thirds; but on two of the eight row shards of an 11,584-sample
-    // problem those plain thirds ran 7 and 15 % SLOWER than the 8-wave kernel's sliced halves, some XCDs far behind
-    // the others (tools/experiments/xcd_variants.py), so below its own sliced rounds the 8-wave kernel stays.)
+    // the 12-wave variant takes every shard that BEGINS AT ROW 0 -- a whole problem, a first shard: a triangle --
+    // and holds more than 2.25 tiles per workgroup (3,072 samples up on 256 CUs).  (Round 2 kept it for shards of two
+    // or more rounds of its slots under 2 GB staged: with that round's schedule it lost 1-2 % at 4,096 samples and
+    // on the 3.3 GB matrix of 8,192 x 50k leaves.  With the round-3 schedule it wins on triangles from 3,072 samples
+    // up -- tools/shape_sweep.py with either value: 4,096 samples 4.98 -> 4.91 ms, 5,120 7.96 -> 7.56, 8,192 19.9
+    // -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9; it ties at 2,560 and loses below 2,048.  On the TRAPEZOID of a
+    // later row shard it gains nothing on average and has outliers -- shards 3 and 4 of 8 of 11,584 samples 15 and
+    // 7 % slower with its plain thirds, shard 6 of 8 of 16,384 samples 10.43 against 10.03 ms with sliced halves
+    // (tools/experiments/xcd_variants.py) -- so the ranks of a multi-GPU run, whose slowest sets the
+    // time, keep the 8-wave kernel.)
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value()) {
-        int64_t wide = 0;
-        for (const Tile &t : tiles) wide += t.narrow ? 0 : 1;
-        // (and only shards that begin at row 0 -- whole problems, a first shard: on the trapezoid of a later row
-        // shard the 12-wave kernel gains nothing on average and has outliers, 10.43 against 10.03 ms on shard 6 of 8 of
-        // 16,384 samples, so the ranks of a multi-GPU run, whose slowest one sets the time, keep the 8-wave kernel)
-        if (wide >= (int64_t)pl->n_workgroups / 2 * L_WAVES_PER_WG && inf.row_begin == 0) pl->waves_per_wg = L_WAVES_PER_WG;
-    }
+    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() && inf.row_begin == 0 &&
+        inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 9)
+        pl->waves_per_wg = L_WAVES_PER_WG;
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     const int U = pl->n_workgroups * pl->waves_per_wg;
     inf.n_wave_slots = U;
@@ -702,7 +699,7 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     int max_planes = std::min(255, std::max(1, env_int("FF_PLANES", 255)));
     while (max_planes > 1 && (double)max_planes * 4.0 * (double)std::max<int64_t>(n_slots, 1) > 1073741824.0) --max_planes;
     build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg,
-                   max_planes > 1 ? max_planes : 0);
+                   max_planes > 1 ? max_planes : 0, inf.row_begin > 0);
     inf.n_items = (int64_t)items.size();
     pl->n_planes = 1;
     for (const Item &it : items) pl->n_planes = std::max(pl->n_planes, (int)((it.flags >> 3) & 255u) + 1);

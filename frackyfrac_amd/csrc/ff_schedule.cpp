@@ -77,7 +77,7 @@ int waves_per_wg()
 // where 4,096 and 8,192 reach 0.86; 0.82 now -- tools/shape_sweep.py, profiles/r03_shape_sweep_*.txt).
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
                     std::vector<Item> *items, std::vector<int32_t> *item_ptr, double *elements, int xcds, int wpw,
-                    int max_planes)
+                    int max_planes, bool prefer_sliced)
 {
     constexpr double ITEM_ROWS = 120.0, REM_COST = 1.30;
     std::vector<Tile> wide, rest;
@@ -272,11 +272,13 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
         // rounds with S = 2, 4 or 8 whose slices are pinned to groups of XCDs, so that an XCD's L2 sees one front of
         // the sweep instead of all of them.  Every candidate is built, its makespan estimated from the loads of its
         // waves, and the best is kept; an XCD-sliced candidate is preferred unless the plain rounds are estimated more
-        // than 3 % faster: slicing costs about half a percent where it is not needed (4,096 samples: 4.92 -> 4.94 ms)
-        // and is worth 7-12 % on some row shards of a multi-GPU run, whose plain rounds run far slower on some XCDs
-        // than on others (round 3: shards 3 and 4 of 8 of 11,584 samples, 5.67 / 5.23 ms with plain thirds, 5.02 /
-        // 4.86 with four slices, the other six shards within 1 % either way; tools/experiments/xcd_variants.py --
-        // the estimate cannot tell those shards from the others, so the preference is general).
+        // than 1 % faster -- 3 % for a shard that does not begin at row 0 (prefer_sliced): slicing costs about half a
+        // percent where it is not needed (4,096 samples: 4.92 -> 4.94 ms) and is worth 7-12 % on some later row
+        // shards of a multi-GPU run, whose plain rounds run far slower on some XCDs than on others (round 3: shards
+        // 3 and 4 of 8 of 11,584 samples, 5.67 / 5.23 ms with plain thirds, 5.02 / 4.86 with four slices, the other
+        // six shards within 1 % either way; tools/experiments/xcd_variants.py -- the estimate cannot tell those
+        // shards from the others, so the preference covers every later shard; whole problems and first shards --
+        // triangles -- showed no such outlier at any of fifteen sizes).
         // FF_XCD_SLICES = 0 forbids the sliced rounds, 2 / 4 / 8 asks for that slicing wherever it applies.
         struct Cand {
             int x;
@@ -313,7 +315,7 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
         double pick_score = 1e300;
         for (size_t c = 0; c < cands.size(); ++c) {
             cands[c].est = attempt(cands[c].x, cands[c].S, cands[c].pr);
-            const double score = cands[c].est * (cands[c].x > 0 ? 0.97 : 1.0);
+            const double score = cands[c].est * (cands[c].x > 0 ? (prefer_sliced ? 0.97 : 0.99) : 1.0);
             if (score < pick_score - 1e-9) {
                 pick_score = score;
                 pick = c;
@@ -567,7 +569,8 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
         std::vector<Item> items;
         double elements = 0;
-        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg(), 0);
+        build_schedule(tiles, rows, n_cu * waves_per_wg(), &items, &ptr, &elements, xcd_slices(), waves_per_wg(), 0,
+                       row_begin > 0);
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(Item) * (size_t)n);

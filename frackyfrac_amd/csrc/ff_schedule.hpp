@@ -108,7 +108,7 @@ bool xcd_slices_forced();  // FF_XCD_SLICES is set: the XCD-sliced rounds wherev
 void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_narrow, std::vector<Tile> *tiles);
 void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U, std::vector<Item> *items,
                     std::vector<int32_t> *item_ptr, double *elements, int xcds = 0, int wpw = WAVES_PER_WG,
-                    int max_planes = 0);
+                    int max_planes = 0, bool prefer_sliced = false);
 int waves_per_wg();
 // Returns the number of 256 x 128 tiles; items/item_ptr get one list per workgroup.
 // partial_tiles / partial_ptr (may be null): filled when the ranges get private partial tiles

@@ -773,12 +773,13 @@ def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
 
 
 def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
-    """A shard whose full-width pair tiles fill a round of the 12-wave kernel's two XCD-sliced halves (6 tiles per CU:
-    about 5,000 samples up on 256 CUs) is scheduled on that kernel without any switch being set, a smaller one on the
-    8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same distances."""
-    small, *_ = synth_problem(4096, 150, 0.2, 79)
+    """A shard that begins at row 0 and holds more than 2.25 pair tiles per workgroup (3,072 samples up on 256 CUs)
+    is scheduled on the 12-wave kernel without any switch being set; a smaller one, and any later row shard (the ranks
+    of a multi-GPU run), on the 8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same
+    distances."""
+    small, *_ = synth_problem(2048, 150, 0.2, 79)
     plan = ff.Plan(small, True, precision="fixed32")
-    assert plan.info.n_tiles < 6 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
+    assert plan.info.n_tiles * 4 < 9 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
     plan.close()
     nodes, ip, on, ft = synth_problem(10240, 150, 0.2, 78)
     plan = ff.Plan(nodes, True, precision="fixed32")
@@ -792,6 +793,11 @@ def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
     want = plan.run_host()
     plan.close()
     assert np.array_equal(got, want)
+    monkeypatch.delenv("FF_WAVES_PER_WG")
+    plan = ff.Plan(nodes, True, precision="fixed32", rank=1, world=2)   # a later row shard: the 8-wave kernel
+    a, b = ff.shard_slots(10240, 1, 2)
+    assert plan.info.row_begin > 0 and plan.info.n_wave_slots == 8 * cus and np.array_equal(plan.run_host(), got[a:b])
+    plan.close()
     # a sample of pairs against the oracle
     rng = np.random.default_rng(3)
     for slot in rng.integers(0, len(got), size=50):
