@@ -193,7 +193,7 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
     kname = KERNEL_NAMES[int(info.kernel)]
     if info.kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
-        kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for many-round shards)
+        kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,072 samples)
     common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
     # the binding floor of THIS launch (one rank's shard): its algorithmic work at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
