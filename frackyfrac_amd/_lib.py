@@ -48,7 +48,8 @@ class ff_plan_info(ctypes.Structure):
                 ("row_end", c_int64), ("slot_begin", c_int64), ("slot_end", c_int64),
                 ("n_tiles", c_int64), ("n_items", c_int64), ("n_wave_slots", c_int64),
                 ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32),
-                ("n_rows", c_int64)]
+                ("n_rows", c_int64), ("n_sweeps", c_int32), ("planes_per_sweep", c_int32),
+                ("rows_three_planes", c_int64)]
 
 # ff_dists_fn: int (*)(void *user, int64_t slot_begin, const double *dists, int64_t n)
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)

@@ -97,6 +97,7 @@ struct ff_plan {
     bool mfma = false;
     unsigned long long *d_Pbits = nullptr;  // presence, one 64-bit word per (64-branch slab, sample), slab-major
     int8_t *d_Kd = nullptr;                 // base-128 digits of the integer branch lengths, [digit][row]
+    int8_t *d_Kt = nullptr;                 // graded staging: three signed digit planes of the rows (stage_for_mfma), or null
     int64_t m_ldb = 0, m_n8 = 0;
     int m_digits = 0;
     MItem *d_mitems = nullptr;
@@ -108,6 +109,8 @@ struct ff_plan {
     bool m_any_atomic = true;    // some item adds into num[] atomically: num[] has to be zero before a run
     bool m_fused = false;        // the kernels that hold a slot's final sum write its distance (no num[] round trip, no finish launch)
     int n_mitems = 0, n_mgroups = 0;
+    bool m_graded = false;       // the rows are staged graded (stage_for_mfma): sorted by length, three signed planes in d_Kt
+    int m_duo_from_slab = 0;     //   the first slab from which two of them do
     bool m_small = false;        // a shard smaller than one round: pair_common_small_kernel, one launch per pass
     int n_stiles = 0;            // its 32 x 32 tiles (= workgroups)
     int64_t stile_c0 = 0;        // position of the shard's first tile in the triangle of 32 x 32 blocks
@@ -352,17 +355,19 @@ Quant choose_quant(const DeviceCsr &c, bool weighted, const int64_t *d_indptr, c
         q.e = e_exact;
         q.lengths_exact = 1;
     } else {
-        // every sample's sum (each length rounded up by less than 1) below 2^31, every length below 2^28:
-        // four base-128 digits = two sweeps of the matrix-core kernel, which three digits cost as well
-        int ex, ex2;
+        // every sample's sum (each length rounded up by less than 1) below 2^31.  (Until round 3 every length was
+        // also kept below 2^28 -- four base-128 digits, two sweeps of the matrix-core kernel -- which cost a tree
+        // with a few very long branches most of its resolution: log-normal lengths of sigma 2.5 sent four pairs in
+        // five to the binary64 walk.  Graded staging, stage_for_mfma, multiplies a long branch as several rows.)
+        int ex;
         std::frexp((LIMIT - (double)nnz_max - 2.0) / wl, &ex);
-        std::frexp((268435456.0 - 2.0) / lmax, &ex2);
-        q.e = std::min(ex, ex2) - 1;
+        q.e = ex - 1;
         q.lengths_exact = 0;
     }
-    // the branch's shared rounding offset (ff_dither.hpp); an exact length is its own integer
+    // the branch's shared rounding offset (ff_dither.hpp); an exact length is its own integer.  (A branch no
+    // sample has a flat node on may be longer than any sample's sum: its integer is never used, only kept in range.)
     for (int64_t b = 0; b < B; ++b)
-        q.klen[(size_t)b] = (uint32_t)(int64_t)std::floor(std::ldexp(c.h_len[(size_t)b], q.e) + ff::branch_dither(b));
+        q.klen[(size_t)b] = (uint32_t)(int64_t)std::min(LIMIT, std::floor(std::ldexp(c.h_len[(size_t)b], q.e) + ff::branch_dither(b)));
     q.fixed_ok = true;
     return q;
 }
@@ -389,6 +394,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_audit_exact);
     (void)hipFree(pl->d_Pbits);
     (void)hipFree(pl->d_Kd);
+    (void)hipFree(pl->d_Kt);
     (void)hipFree(pl->d_mitems);
     (void)hipFree(pl->d_mitem_ptr);
     (void)hipFree(pl->d_partial);
@@ -775,6 +781,9 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
             pl->n_stiles = (int)n_st;
             pl->stile_c0 = ib0 * (ib0 + 1) / 2;
             inf.kernel = FF_KERNEL_MFMA_I8_SMALL;
+            inf.n_sweeps = 1;  // (every digit plane in its one pass)
+            inf.planes_per_sweep = pl->m_digits;
+            inf.rows_three_planes = 0;
             inf.n_tiles = inf.n_items = n_st;
             inf.n_wave_slots = n_st * S_WAVES;
             inf.elements = (double)n_st * S_TILE * S_TILE * (double)pl->m_ldb * pl->m_digits;
@@ -791,6 +800,13 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
         }
         inf.kernel = FF_KERNEL_MFMA_I8;
     }
+    // graded rows: ONE sweep, three planes up to m_duo_from_slab and two from there on (one digit group per tile,
+    // cut by cost); else base-128 digits, two planes per sweep
+    const int sched_digits = pl->m_graded ? 2 : pl->m_digits;
+    const int64_t duo_from_quad = pl->m_graded ? (pl->m_duo_from_slab + M_QUAD_SLABS - 1) / M_QUAD_SLABS : -1;
+    inf.n_sweeps = (sched_digits + M_ND - 1) / M_ND;
+    inf.planes_per_sweep = pl->m_graded ? 3 : std::min(pl->m_digits, M_ND);
+    inf.rows_three_planes = pl->m_graded ? std::min<int64_t>((int64_t)pl->m_duo_from_slab * M_KSLAB, pl->m_ldb) : 0;
     std::vector<MItem> mi;
     std::vector<int32_t> mptr;
     std::vector<int32_t> ptiles, pptr;
@@ -802,8 +818,9 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     int64_t private_tiles = (int64_t)env_int("FF_MFMA_PRIVATE_MB", 2048) * (1 << 20) / (M_TILE_I * M_TILE_J * 4);
     int64_t n_mtiles = 0;
     for (;;) {
-        n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, pl->m_digits, G, &mi, &mptr,
-                                       want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr, private_tiles);
+        n_mtiles = build_mfma_schedule(N, inf.row_begin, inf.row_end, slabs, sched_digits, G, &mi, &mptr,
+                                       want_partials ? &ptiles : nullptr, want_partials ? &pptr : nullptr, private_tiles,
+                                       duo_from_quad);
         if (pptr.empty()) break;
         if (hipMalloc(&pl->d_partial, sizeof(uint32_t) * (size_t)pptr.back() * M_TILE_I * M_TILE_J) == hipSuccess) break;
         (void)hipGetLastError();  // (the device is short of memory: only the remainder's ranges get private tiles)
@@ -824,7 +841,10 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     inf.n_tiles = n_mtiles;
     inf.n_items = (int64_t)mi.size();
     inf.n_wave_slots = (int64_t)G * (M_THREADS / 64);
-    inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J * (double)pl->m_ldb * pl->m_digits;
+    inf.elements = (double)n_mtiles * M_TILE_I * M_TILE_J *
+                   (pl->m_graded ? 3.0 * std::min<double>(pl->m_duo_from_slab * M_KSLAB, pl->m_ldb) +
+                                       2.0 * std::max<double>(0.0, (double)pl->m_ldb - pl->m_duo_from_slab * M_KSLAB)
+                                 : (double)pl->m_ldb * pl->m_digits);
     FF_HIP(hipMalloc(&pl->d_mitems, sizeof(MItem) * std::max<size_t>(mi.size(), 1)));
     FF_HIP(hipMalloc(&pl->d_mitem_ptr, sizeof(int32_t) * mptr.size()));
     if (!mi.empty()) FF_HIP(hipMemcpy(pl->d_mitems, mi.data(), sizeof(MItem) * mi.size(), hipMemcpyHostToDevice));
@@ -847,6 +867,10 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false, 0, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<true, 0, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     FF_ALLOC(pl->d_num, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1), "the pair accumulators");
     return FF_OK;
@@ -1123,52 +1147,134 @@ int compact_branches(StageCtx &x, char *err, size_t errlen)
 int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
-    // presence bits (64-bit words, pairs of slabs major) and per-branch digits, zero padded to whole tiles and quads of slabs
+    // presence bits (64-bit words, pairs of slabs major) and per-row digits, zero padded to whole tiles and quads of slabs
     pl->mfma = true;
     inf.kernel = FF_KERNEL_MFMA_I8;
     inf.lengths_exact = q.lengths_exact;
     inf.scale_log2 = q.e;
     uint32_t kmax = 0;
     for (uint32_t k : q.klen) kmax = std::max(kmax, k);
-    int digits = 1;
-    while (digits < 5 && (kmax >> (7 * digits)) != 0) ++digits;
+    auto digits_of = [](uint32_t k) {
+        int d = 1;
+        while (d < 5 && (k >> (7 * d)) != 0) ++d;
+        return d;
+    };
+    int digits = digits_of(kmax);
+    // The staged rows: (branch, integer length of the row).  Up to two base-128 digits -- short binary fractions,
+    // C3's generator -- a row is a branch in use, in ascending order, and a sweep multiplies both digit planes.
+    // Longer lengths (any real phylogeny: the integers then take the 31-bit budget of a sample's sum) are staged
+    // GRADED: three signed digits d0 + 128 d1 + 32768 d2 cover a length up to TRI_KMAX in one sweep of three
+    // MFMAs per block (pair_common_mfma_kernel<.., GRADED>), two of them one up to DUO_KMAX; common(i, j) is
+    // linear in the lengths, so a longer branch becomes several rows with the same presence bits whose lengths
+    // add up to its own, and the order of the rows is free, so they are sorted by length, longest first: the
+    // sweep multiplies three planes up to the first slab without a third digit and two from there on.  With
+    // lengths spread over orders of magnitude most rows are of the second kind.  FF_MFMA_GRADED=0: base-128
+    // digits in branch order, two planes per sweep, as many sweeps as it takes.
+    struct StagedRow {
+        int32_t branch;
+        uint32_t k;
+    };
+    std::vector<StagedRow> rows;
+    bool graded = false;
+    if (digits > 2 && env_int("FF_MFMA_GRADED", 1) != 0) {
+        int64_t pieces = 0;
+        for (int64_t r = 0; r < R; ++r) {
+            const int64_t k = q.klen[(size_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r])];
+            pieces += std::max<int64_t>(1, (k + TRI_KMAX - 1) / TRI_KMAX);
+        }
+        // (a few long branches, not a tree of them: three planes over x times the rows against two sweeps of two
+        // planes, or three sweeps from five base-128 digits)
+        if (pieces <= (digits < 5 ? R + R / 4 : R + R * 4 / 5) + 1024 && pieces < ((int64_t)1 << 30)) {
+            graded = true;
+            rows.reserve((size_t)pieces);
+            for (int64_t r = 0; r < R; ++r) {
+                const int32_t b = (int32_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r]);
+                const int64_t k = q.klen[(size_t)b], n = std::max<int64_t>(1, (k + TRI_KMAX - 1) / TRI_KMAX);
+                for (int64_t j = 0; j < n; ++j) rows.push_back({b, (uint32_t)(k / n + (j < k % n ? 1 : 0))});
+            }
+            std::stable_sort(rows.begin(), rows.end(), [](const StagedRow &u, const StagedRow &v) { return u.k > v.k; });
+            digits = digits_of(rows.empty() ? 0u : rows[0].k);  // (of the rows: what the small-shard kernel multiplies)
+        }
+    }
+    if (!graded) {
+        rows.reserve((size_t)R);
+        for (int64_t r = 0; r < R; ++r) {
+            const int32_t b = (int32_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r]);
+            rows.push_back({b, q.klen[(size_t)b]});
+        }
+    }
+    const int64_t Rs = (int64_t)rows.size();  // staged rows
     pl->m_digits = digits;
+    pl->m_graded = graded;
     inf.n_digits = digits;
     const int64_t n8 = round_up(N, M_TILE_I);
-    const int64_t n_slabs = mfma_staged_slabs(R);  // whole quads of slabs
+    const int64_t n_slabs = mfma_staged_slabs(Rs);  // whole quads of slabs
     const int64_t ldb = n_slabs * M_KSLAB;
     pl->m_ldb = ldb;
     pl->m_n8 = n8;
     inf.ld = n8;
     inf.rows_padded = ldb;
-    // (+ M_PAD_SLABS slabs of zeros behind both arrays: the kernel's prefetches run past an item's end)
-    const size_t bits_bytes = sizeof(unsigned long long) * (size_t)mfma_alloc_slabs(R) * (size_t)n8;
-    const size_t digit_bytes = (size_t)(mfma_alloc_slabs(R) * M_KSLAB) * (size_t)(digits + 1);  // (+1: a single-digit item reads its plane twice)
-    inf.staged_bytes = (double)bits_bytes + (double)digit_bytes;
+    // (+ M_PAD_SLABS slabs of zeros behind the arrays: the kernel's prefetches run past an item's end)
+    const size_t bits_bytes = sizeof(unsigned long long) * (size_t)mfma_alloc_slabs(Rs) * (size_t)n8;
+    const size_t plane_alloc = (size_t)(mfma_alloc_slabs(Rs) * M_KSLAB);
+    const size_t digit_bytes = plane_alloc * (size_t)(digits + 1);  // (+1: a single-digit item reads its plane twice)
+    inf.staged_bytes = (double)bits_bytes + (double)digit_bytes + (graded ? 3.0 * (double)plane_alloc : 0.0);
     FF_ALLOC(pl->d_Pbits, bits_bytes, "the presence bits");
     FF_HIP(hipMalloc(&pl->d_Kd, digit_bytes));
     FF_HIP(hipMemset(pl->d_Pbits, 0, bits_bytes));
     FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)n8));
     FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)n8));
     {
-        // digits in the kernel's order of the 64 branches of a slab: chunk C, dword kk, byte q holds
-        // branch 32 * (C >> 1) + 8 * q + 4 * (C & 1) + kk (ff_kernels_mfma.hpp)
-        std::vector<int8_t> kd(digit_bytes, 0);
-        for (int64_t r = 0; r < R; ++r) {
-            const uint32_t k = q.klen[(size_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r])];
+        // digits in the kernel's order of the 64 rows of a slab: chunk C, dword kk, byte q holds
+        // row 32 * (C >> 1) + 8 * q + 4 * (C & 1) + kk (ff_kernels_mfma.hpp)
+        auto pos_of = [](int64_t r) {
             const int64_t slab = r / M_KSLAB, w = r % M_KSLAB;  // w = 32 * h + 8 * q + 4 * c1 + kk
             const int64_t h = w >> 5, qq = (w >> 3) & 3, c1 = (w >> 2) & 1, kk = w & 3;
-            const int64_t pos = slab * M_KSLAB + (2 * h + c1) * 16 + kk * 4 + qq;
-            for (int d = 0; d < digits; ++d) kd[(size_t)d * (size_t)ldb + (size_t)pos] = (int8_t)((k >> (7 * d)) & 127u);
+            return (size_t)(slab * M_KSLAB + (2 * h + c1) * 16 + kk * 4 + qq);
+        };
+        std::vector<int8_t> kd(digit_bytes, 0);
+        for (int64_t r = 0; r < Rs; ++r) {
+            const uint32_t k = rows[(size_t)r].k;
+            const size_t pos = pos_of(r);
+            for (int d = 0; d < digits; ++d) kd[(size_t)d * (size_t)ldb + pos] = (int8_t)((k >> (7 * d)) & 127u);
         }
         FF_HIP(hipMemcpy(pl->d_Kd, kd.data(), digit_bytes, hipMemcpyHostToDevice));
+        pl->m_duo_from_slab = 0;
+        if (graded) {
+            std::vector<int8_t> kt(plane_alloc * 3, 0);
+            int64_t first_duo = Rs;  // the first row whose length (and every later one's) needs no third digit
+            for (int64_t r = 0; r < Rs; ++r) {
+                int8_t d[3];
+                tri_digits((int64_t)rows[(size_t)r].k, d);
+                const size_t pos = pos_of(r);
+                kt[pos] = d[0];
+                kt[(size_t)ldb + pos] = d[1];
+                kt[2 * (size_t)ldb + pos] = d[2];
+                if ((int64_t)rows[(size_t)r].k > DUO_KMAX) first_duo = r + 1;
+            }
+            pl->m_duo_from_slab = (int)((std::min(first_duo, Rs) + M_KSLAB - 1) / M_KSLAB);
+            FF_HIP(hipMalloc(&pl->d_Kt, kt.size()));
+            FF_HIP(hipMemcpy(pl->d_Kt, kt.data(), kt.size(), hipMemcpyHostToDevice));
+        }
     }
     Scratch<uint32_t> klen;
+    Scratch<int32_t> row_ptr, row_list;  // graded: the rows of a branch (it may have several)
     FF_HIP(klen.alloc((size_t)B));
     FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
+    if (graded) {
+        std::vector<int32_t> ptr((size_t)B + 1, 0), list((size_t)std::max<int64_t>(Rs, 1));
+        for (const StagedRow &sr : rows) ++ptr[(size_t)sr.branch + 1];
+        for (int64_t b = 0; b < B; ++b) ptr[(size_t)b + 1] += ptr[(size_t)b];
+        std::vector<int32_t> at(ptr.begin(), ptr.end() - 1);
+        for (int64_t r = 0; r < Rs; ++r) list[(size_t)at[(size_t)rows[(size_t)r].branch]++] = (int32_t)r;
+        FF_HIP(row_ptr.alloc(ptr.size()));
+        FF_HIP(row_list.alloc(list.size()));
+        FF_HIP(hipMemcpy(row_ptr.p, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
+        FF_HIP(hipMemcpy(row_list.p, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
+    }
     if (nnz > 0)
-        stage_mfma_bits_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, row_of.p, pl->d_Pbits, n8,
-                                                                  n_slabs, pl->d_W);
+        stage_mfma_bits_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, klen.p, graded ? nullptr : row_of.p,
+                                                                  row_ptr.p, row_list.p, pl->d_Pbits, n8, n_slabs, pl->d_W);
     FF_HIP(hipGetLastError());
     FF_HIP(hipDeviceSynchronize());
     klen.release();
@@ -1447,7 +1553,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
 #undef FF_S_CASE
             if (timed) FF_HIP(hipEventRecord(ev1, st));
         } else if (pl->mfma) {
-            auto kern = pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>;
+            auto kern = pl->m_graded ? (pl->m_all_private ? pair_common_mfma_kernel<true, 0, true> : pair_common_mfma_kernel<false, 0, true>)
+                                     : (pl->m_all_private ? pair_common_mfma_kernel<true> : pair_common_mfma_kernel<false>);
 #ifdef FF_MFMA_DIAG  // ablations for timing only (wrong results): see the kernel's DIAG parameter
             switch (env_int("FF_MFMA_DIAG", 0)) {
             case 2: kern = pair_common_mfma_kernel<false, 2>; break;
@@ -1464,8 +1571,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             none.out = nullptr;  // null: the kernels leave integer sums in num[]
             if (pl->n_mitems > 0)
                 kern<<<dim3((unsigned)pl->n_mgroups), dim3(M_THREADS), pl->lds_bytes, st>>>(
-                    reinterpret_cast<const uint4 *>(pl->d_Pbits), pl->m_n8, pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
-                    pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, fused ? fin : none);
+                    reinterpret_cast<const uint4 *>(pl->d_Pbits), pl->m_n8, pl->m_graded ? pl->d_Kt : pl->d_Kd, pl->m_ldb, pl->d_mitems, pl->d_mitem_ptr, pl->d_W, pl->d_num,
+                    pl->d_partial, inf.row_begin, inf.row_end, inf.slot_begin, pl->m_duo_from_slab, fused ? fin : none);
             if (pl->n_ptiles > 0 && pl->m_all_private)
                 reduce_private_kernel<<<dim3(M_REDUCE_BLOCKS, (unsigned)pl->n_ptiles), dim3(M_REDUCE_THREADS), 0, st>>>(
                     pl->d_partial, pl->d_ptiles, pl->d_ptile_ptr, pl->d_W, pl->d_num, inf.row_begin, inf.row_end,

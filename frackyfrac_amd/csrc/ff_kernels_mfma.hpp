@@ -61,9 +61,12 @@ constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time (12
 __global__ __launch_bounds__(256)
 void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
                             const uint32_t *__restrict__ klen, const int32_t *__restrict__ row_of,
+                            const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list,
                             unsigned long long *__restrict__ Pbits, int64_t n8, int64_t n_slabs,
                             unsigned long long *__restrict__ W)
 {
+    // a branch's staged rows: row_list[row_ptr[b] .. row_ptr[b + 1]) (graded staging: one or more, anywhere), else
+    // the one row row_of[b], else row b
     __shared__ uint32_t bm[2048];
     const int64_t s = blockIdx.x;
     const int64_t t0 = indptr[s], t1 = indptr[s + 1];
@@ -73,6 +76,14 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
         __syncthreads();
         for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
             const int32_t b0 = branch_id[t];
+            if (row_ptr) {
+                for (int32_t p = row_ptr[b0]; p < row_ptr[b0 + 1]; ++p) {
+                    const int64_t r = row_list[p];
+                    if ((r >> 16) == win) atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
+                }
+                if (win == 0) w += klen[b0];
+                continue;
+            }
             const int64_t r = row_of ? row_of[b0] : b0;
             if ((r >> 16) == win) {
                 atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
@@ -134,15 +145,17 @@ __device__ unsigned long long *g_mfma_stamps = nullptr;
 #define FF_STAMP(slot)
 #define FF_STAMP_CLOCK(slot)
 #endif
-template <bool ALL_PRIVATE, int DIAG = 0>
+template <bool ALL_PRIVATE, int DIAG = 0, bool GRADED = false>
 __global__ __launch_bounds__(M_THREADS, 1)
 void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                              const int8_t *__restrict__ Kd, int64_t ldb, const MItem *__restrict__ items,
                              const int32_t *__restrict__ item_ptr, const unsigned long long *__restrict__ W,
                              uint32_t *__restrict__ num, uint32_t *__restrict__ partial, int64_t row_begin,
                              int64_t row_end, int64_t slot_begin,
+                             int duo_from_slab,     // GRADED: from this slab on no length needs the third plane
                              const FinishArgs fin)  // fin.out != null: a tile's only item writes distances, not sums
 {
+    constexpr bool TRI = GRADED;  // (the graded sweep's first kind of k-step: three planes)
     extern __shared__ __attribute__((aligned(16))) int8_t mfma_lds[];  // [slab of the segment][plane][64 digits]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,8 +173,10 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         const int wlane = M_DIRECT_WORDS ? (lane & 31) : lane;
         const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + wlane;
         const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + wlane;
-        const int8_t *dig_src[2] = {Kd + (int64_t)item.d0 * ldb + item.k0,
-                                    Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0};
+        constexpr int NPL = TRI ? 3 : 2;  // digit planes of a slab in the LDS table
+        const int8_t *dig_src[3] = {Kd + (int64_t)item.d0 * ldb + item.k0,
+                                    Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0,
+                                    Kd + (int64_t)(TRI ? 2 : 0) * ldb + item.k0};  // (TRI: Kd = the three signed planes, d0 = 0)
         // An item with a single digit plane (the last group of an odd number of digits) runs without the
         // second plane's MFMAs, digit reads and masks.  The whole item -- accumulators, loop, way out -- is
         // instantiated once per case: a branch inside the loop nest would join the two cases' accumulators,
@@ -199,24 +214,25 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 }
                 // the segment's digits -> LDS: table[(slab * 2 + plane) * 64 + position]
                 __syncthreads();  // (every wave is done with the previous table)
-                for (int c0 = tid; c0 < nseg * 8; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
-                    mfma_v4i piece16[4];                                  // four loads in flight per thread
+                for (int c0 = tid; c0 < nseg * 4 * NPL; c0 += 4 * M_THREADS) {  // 16-byte pieces: 4 per (slab, plane);
+                    mfma_v4i piece16[4];                                        // four loads in flight per thread
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = c0 + u * M_THREADS, sp = c >> 2, piece = c & 3;
-                        if (c < nseg * 8)
-                            piece16[u] = *(const mfma_v4i *)(dig_src[sp & 1] + (int64_t)(seg + (sp >> 1)) * M_KSLAB + piece * 16);
+                        if (c < nseg * 4 * NPL)
+                            piece16[u] = *(const mfma_v4i *)(dig_src[sp % NPL] + (int64_t)(seg + sp / NPL) * M_KSLAB + piece * 16);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = c0 + u * M_THREADS;
-                        if (c < nseg * 8) *(mfma_v4i *)(mfma_lds + (c >> 2) * 64 + (c & 3) * 16) = piece16[u];
+                        if (c < nseg * 4 * NPL) *(mfma_v4i *)(mfma_lds + (c >> 2) * 64 + (c & 3) * 16) = piece16[u];
                     }
                 }
                 __syncthreads();
                 const int8_t *tab = mfma_lds + half * 16;
                 mfma_v4i fa[2][4], fb0[2][2], fb1[2][2];  // [set][row block]
                 mfma_v4i dg0[2], dg1[2];                   // digits for the k-step set [s] is (being) built for
+                mfma_v4i fb2[2][2], dg2, a128[2];          // TRI: the third plane, and the A fragments of two row blocks times -128
                 uint32_t swx[4], swy[2];                   // the k-step being built: words of row blocks m / n, swapped
                 uint32_t t[8];                             // its B masks in the making
                 uint32_t shk[4];                           // shift of dword kk for this half-wave: 4 * half + kk
@@ -265,7 +281,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 };
 #define FF_MM(d, m, n, A, B)                                                                           \
         if constexpr ((d) == 0 || TWO) {                                                                   \
-            if constexpr (!(DIAG & 16))                                                                    \
+            if constexpr (!(DIAG & 16))                                                               \
                 asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[d][m][n]) : "v"(A), "v"(B)); \
             else acc[d][m][n][0] += A[0] ^ B[0];                                                           \
         }                                                                                                  \
@@ -302,11 +318,125 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                     FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_OP(fa[nxt][2][3] &= 0x01010101); FF_OP(fa[nxt][3][0] &= 0x01010101); FF_OP(fa[nxt][3][1] &= 0x01010101); FF_OP(fa[nxt][3][2] &= 0x01010101); FF_OP(fa[nxt][3][3] &= 0x01010101); FF_END_PIECE();
                     FF_MM(1, 3, 1, fa[cur][3], fb1[cur][1]); take_words(bp2, bkt2); FF_END_PIECE();
                 };
+                // TRI: three digit planes in one sweep, into the same two accumulator sets.  With signed digits
+                // k = d0 + 128 d1 + 32768 d2 (d0 in [-64, 63], d1 in [-127, 128], d2 in [0, 127]; plane 1 holds -d1):
+                //   X += A . (d0 & mask),  X += (A << 7) . (-d1 & mask)   -- the bytes 0x80 of A << 7 are -128 --
+                //   Y += A . (d2 & mask),  common = X + (Y << 15),
+                // 24 MFMAs per k-step behind 96 vector instructions (4.0 per MFMA).  The scaled A fragments of row
+                // block m live in a128[m & 1] from four MFMAs before their use to their use; the digits are
+                // single-buffered (read at the top of the k-step that masks them, eight MFMAs before the first
+                // mask).  The two updates of an X tile are four MFMAs apart.
+                auto read_digits3 = [&](int kstep) {  // kstep = 2 * slab + kt, within the segment; slab stride 192 bytes
+                    const int8_t *at = tab + kstep * 32 + (kstep >> 1) * 128;
+                    dg0[0] = *(const mfma_v4i *)at;
+                    dg1[0] = *(const mfma_v4i *)(at + 64);
+                    dg2 = *(const mfma_v4i *)(at + 128);
+                };
+#define FF_T_SH(i) FF_OP(t[i] = swy[(i) >> 2] >> shk[(i) & 3])
+#define FF_T_AND(i) FF_OP(t[i] &= 0x01010101u)
+#define FF_T_BM(i) FF_OP(t[i] = ff_bytemask(t[i]))
+#define FF_B0(n, kk) FF_OP(fb0[nxt][n][kk] = (int)((uint32_t)dg0[0][kk] & t[4 * (n) + (kk)]))
+#define FF_B1(n, kk) FF_OP(fb1[nxt][n][kk] = (int)((uint32_t)dg1[0][kk] & t[4 * (n) + (kk)]))
+#define FF_B2(n, kk) FF_OP(fb2[nxt][n][kk] = (int)((uint32_t)dg2[kk] & t[4 * (n) + (kk)]))
+#define FF_A_SH(m) FF_OP(fa[nxt][m][0] = (int)(swx[m] >> shk[0])); FF_OP(fa[nxt][m][1] = (int)(swx[m] >> shk[1])); FF_OP(fa[nxt][m][2] = (int)(swx[m] >> shk[2])); FF_OP(fa[nxt][m][3] = (int)(swx[m] >> shk[3]))
+#define FF_A_AND(m) FF_OP(fa[nxt][m][0] &= 0x01010101); FF_OP(fa[nxt][m][1] &= 0x01010101); FF_OP(fa[nxt][m][2] &= 0x01010101); FF_OP(fa[nxt][m][3] &= 0x01010101)
+#define FF_A128(s, m) FF_OP(a128[s][0] = (int)((uint32_t)fa[cur][m][0] << 7)); FF_OP(a128[s][1] = (int)((uint32_t)fa[cur][m][1] << 7)); FF_OP(a128[s][2] = (int)((uint32_t)fa[cur][m][2] << 7)); FF_OP(a128[s][3] = (int)((uint32_t)fa[cur][m][3] << 7))
+                auto kstep3 = [&](int u, int sl) {
+                    constexpr bool TWO = true;
+                    const int cur = u & 1, nxt = cur ^ 1;
+                    const int bp2 = ((u + 2) >> 2) & 3, bkt2 = (u + 2) & 3;  // buffer and component of k-step u + 2
+                    read_digits3(2 * sl + u + 1);  // of the k-step whose fragments (set `nxt`) this one builds
+                    __builtin_amdgcn_sched_barrier(0);
+                    FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_A128(0, 0); FF_END_PIECE();
+                    FF_MM(1, 0, 0, fa[cur][0], fb2[cur][0]); FF_T_SH(0); FF_T_SH(1); FF_T_SH(2); FF_T_SH(3); FF_END_PIECE();
+                    FF_MM(0, 0, 1, fa[cur][0], fb0[cur][1]); FF_T_SH(4); FF_T_SH(5); FF_T_SH(6); FF_T_SH(7); FF_END_PIECE();
+                    FF_MM(1, 0, 1, fa[cur][0], fb2[cur][1]); FF_T_AND(0); FF_T_AND(1); FF_T_AND(2); FF_T_AND(3); FF_END_PIECE();
+                    FF_MM(0, 0, 0, a128[0], fb1[cur][0]); FF_A128(1, 1); FF_END_PIECE();
+                    FF_MM(0, 0, 1, a128[0], fb1[cur][1]); FF_T_AND(4); FF_T_AND(5); FF_T_AND(6); FF_T_AND(7); FF_END_PIECE();
+                    FF_MM(0, 1, 0, fa[cur][1], fb0[cur][0]); FF_T_BM(0); FF_T_BM(1); FF_T_BM(2); FF_T_BM(3); FF_END_PIECE();
+                    FF_MM(1, 1, 0, fa[cur][1], fb2[cur][0]); FF_T_BM(4); FF_T_BM(5); FF_T_BM(6); FF_T_BM(7); FF_END_PIECE();
+                    FF_MM(0, 1, 1, fa[cur][1], fb0[cur][1]); FF_B0(0, 0); FF_B1(0, 0); FF_B2(0, 0); FF_B0(0, 1); FF_END_PIECE();
+                    FF_MM(1, 1, 1, fa[cur][1], fb2[cur][1]); FF_B1(0, 1); FF_B2(0, 1); FF_B0(0, 2); FF_B1(0, 2); FF_END_PIECE();
+                    FF_MM(0, 1, 0, a128[1], fb1[cur][0]); FF_A128(0, 2); FF_END_PIECE();
+                    FF_MM(0, 1, 1, a128[1], fb1[cur][1]); FF_B2(0, 2); FF_B0(0, 3); FF_B1(0, 3); FF_B2(0, 3); FF_END_PIECE();
+                    FF_MM(0, 2, 0, fa[cur][2], fb0[cur][0]); FF_B0(1, 0); FF_B1(1, 0); FF_B2(1, 0); FF_B0(1, 1); FF_END_PIECE();
+                    FF_MM(1, 2, 0, fa[cur][2], fb2[cur][0]); FF_B1(1, 1); FF_B2(1, 1); FF_B0(1, 2); FF_B1(1, 2); FF_END_PIECE();
+                    FF_MM(0, 2, 1, fa[cur][2], fb0[cur][1]); FF_B2(1, 2); FF_B0(1, 3); FF_B1(1, 3); FF_B2(1, 3); FF_END_PIECE();
+                    FF_MM(1, 2, 1, fa[cur][2], fb2[cur][1]); FF_A_SH(0); FF_END_PIECE();
+                    FF_MM(0, 2, 0, a128[0], fb1[cur][0]); FF_A128(1, 3); FF_END_PIECE();
+                    FF_MM(0, 2, 1, a128[0], fb1[cur][1]); FF_A_SH(1); FF_END_PIECE();
+                    FF_MM(0, 3, 0, fa[cur][3], fb0[cur][0]); FF_A_SH(2); FF_END_PIECE();
+                    FF_MM(1, 3, 0, fa[cur][3], fb2[cur][0]); FF_A_SH(3); FF_END_PIECE();
+                    FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_A_AND(0); FF_END_PIECE();
+                    FF_MM(1, 3, 1, fa[cur][3], fb2[cur][1]); FF_A_AND(1); FF_END_PIECE();
+                    FF_MM(0, 3, 0, a128[1], fb1[cur][0]); FF_A_AND(2); FF_END_PIECE();
+                    FF_MM(0, 3, 1, a128[1], fb1[cur][1]); FF_A_AND(3); take_words(bp2, bkt2); FF_END_PIECE();
+                };
+#define FF_A_SH1(m, kk) FF_OP(fa[nxt][m][kk] = (int)(swx[m] >> shk[kk]))
+#define FF_A_AND1(m, kk) FF_OP(fa[nxt][m][kk] &= 0x01010101)
+                // DUO: the same without the third plane, for the slabs whose lengths all fit d0 + 128 d1 (the rows
+                // are staged in descending order of length): 16 MFMAs into X alone behind 88 vector instructions.
+                // It builds fb0 / fb1 only; a DUO k-step never comes before a TRI one.
+                auto kstep2 = [&](int u, int sl) {
+                    constexpr bool TWO = true;
+                    const int cur = u & 1, nxt = cur ^ 1;
+                    const int bp2 = ((u + 2) >> 2) & 3, bkt2 = (u + 2) & 3;
+                    {
+                        const int8_t *at = tab + (2 * sl + u + 1) * 32 + ((2 * sl + u + 1) >> 1) * 128;
+                        dg0[0] = *(const mfma_v4i *)at;
+                        dg1[0] = *(const mfma_v4i *)(at + 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    FF_MM(0, 0, 0, fa[cur][0], fb0[cur][0]); FF_A128(0, 0); FF_T_SH(0); FF_T_SH(1); FF_END_PIECE();
+                    FF_MM(0, 0, 1, fa[cur][0], fb0[cur][1]); FF_A128(1, 1); FF_T_SH(2); FF_T_SH(3); FF_END_PIECE();
+                    FF_MM(0, 1, 0, fa[cur][1], fb0[cur][0]); FF_T_SH(4); FF_T_SH(5); FF_T_SH(6); FF_T_SH(7); FF_T_AND(0); FF_T_AND(1); FF_END_PIECE();
+                    FF_MM(0, 1, 1, fa[cur][1], fb0[cur][1]); FF_T_AND(2); FF_T_AND(3); FF_T_AND(4); FF_T_AND(5); FF_T_AND(6); FF_T_AND(7); FF_END_PIECE();
+                    FF_MM(0, 0, 0, a128[0], fb1[cur][0]); FF_T_BM(0); FF_T_BM(1); FF_T_BM(2); FF_T_BM(3); FF_T_BM(4); FF_T_BM(5); FF_END_PIECE();
+                    FF_MM(0, 0, 1, a128[0], fb1[cur][1]); FF_T_BM(6); FF_T_BM(7); FF_B0(0, 0); FF_B1(0, 0); FF_B0(0, 1); FF_B1(0, 1); FF_END_PIECE();
+                    FF_MM(0, 1, 0, a128[1], fb1[cur][0]); FF_B0(0, 2); FF_B1(0, 2); FF_B0(0, 3); FF_B1(0, 3); FF_B0(1, 0); FF_B1(1, 0); FF_END_PIECE();
+                    FF_MM(0, 1, 1, a128[1], fb1[cur][1]); FF_B0(1, 1); FF_B1(1, 1); FF_B0(1, 2); FF_B1(1, 2); FF_B0(1, 3); FF_B1(1, 3); FF_END_PIECE();
+                    FF_MM(0, 2, 0, fa[cur][2], fb0[cur][0]); FF_A128(0, 2); FF_A_SH1(0, 0); FF_END_PIECE();
+                    FF_MM(0, 2, 1, fa[cur][2], fb0[cur][1]); FF_A128(1, 3); FF_A_SH1(0, 1); FF_END_PIECE();
+                    FF_MM(0, 3, 0, fa[cur][3], fb0[cur][0]); FF_A_SH1(0, 2); FF_A_SH1(0, 3); FF_A_SH1(1, 0); FF_A_SH1(1, 1); FF_A_SH1(1, 2); FF_END_PIECE();
+                    FF_MM(0, 3, 1, fa[cur][3], fb0[cur][1]); FF_A_SH1(1, 3); FF_A_SH1(2, 0); FF_A_SH1(2, 1); FF_A_SH1(2, 2); FF_A_SH1(2, 3); FF_END_PIECE();
+                    FF_MM(0, 2, 0, a128[0], fb1[cur][0]); FF_A_SH1(3, 0); FF_A_SH1(3, 1); FF_A_SH1(3, 2); FF_A_SH1(3, 3); FF_A_AND1(0, 0); FF_END_PIECE();
+                    FF_MM(0, 2, 1, a128[0], fb1[cur][1]); FF_A_AND1(0, 1); FF_A_AND1(0, 2); FF_A_AND1(0, 3); FF_A_AND1(1, 0); FF_A_AND1(1, 1); FF_END_PIECE();
+                    FF_MM(0, 3, 0, a128[1], fb1[cur][0]); FF_A_AND1(1, 2); FF_A_AND1(1, 3); FF_A_AND1(2, 0); FF_A_AND1(2, 1); FF_A_AND1(2, 2); FF_END_PIECE();
+                    FF_MM(0, 3, 1, a128[1], fb1[cur][1]); FF_A_AND1(2, 3); FF_A_AND1(3, 0); FF_A_AND1(3, 1); FF_A_AND1(3, 2); FF_A_AND1(3, 3); take_words(bp2, bkt2); FF_END_PIECE();
+                };
+#undef FF_A_SH1
+#undef FF_A_AND1
+#undef FF_T_SH
+#undef FF_T_AND
+#undef FF_T_BM
+#undef FF_B0
+#undef FF_B1
+#undef FF_B2
+#undef FF_A_SH
+#undef FF_A_AND
+#undef FF_A128
                 // prologue: digits of k-steps 0 and 1, fragment set 0 for k-step 0, the words of k-step 1
-                read_digits(std::true_type{}, 0, 0);
-                read_digits(std::true_type{}, 1, 1);
+                if constexpr (TRI) {
+                    read_digits3(0);
+                } else {
+                    read_digits(std::true_type{}, 0, 0);
+                    read_digits(std::true_type{}, 1, 1);
+                }
                 take_words(0, 0);
-                if constexpr (!(DIAG & 4)) {
+                if constexpr (TRI) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const uint32_t mask = ff_bytemask((swy[n] >> shk[kk]) & 0x01010101u);
+                            fb0[0][n][kk] = (int)((uint32_t)dg0[0][kk] & mask);
+                            fb1[0][n][kk] = (int)((uint32_t)dg1[0][kk] & mask);
+                            fb2[0][n][kk] = (int)((uint32_t)dg2[kk] & mask);
+                        }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) fa[0][m][kk] = (int)((swx[m] >> shk[kk]) & 0x01010101u);
+                    }
+                } else if constexpr (!(DIAG & 4)) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -338,6 +468,45 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 // and a 16-byte load costs the wave's instruction stream what an 8-byte one does.
                 auto sweep = [&](auto two_planes) {
                     int sl = 0;
+                    if constexpr (GRADED) {
+                        // groups of eight slabs from the segment's start: three planes while a group begins before
+                        // duo_from_slab (what it multiplies beyond is zero digits), two from there on
+                        const int tri_until = duo_from_slab - (item.k0 / M_KSLAB + seg);
+                        for (; sl + 7 < nseg && sl < tri_until; sl += 8) {
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                kstep3(4 * p, sl);
+                                kstep3(4 * p + 1, sl);
+                                kstep3(4 * p + 2, sl);
+                                kstep3(4 * p + 3, sl);
+                                load_words(p);
+                            }
+                        }
+                        if (sl + 7 < nseg) {
+                            // two planes from here on: their k-steps do not build the third plane's fragments, which
+                            // are all zero in this part of the sweep -- and wanted as such by the last quad below
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) fb2[0][n] = fb2[1][n] = mfma_v4i{0, 0, 0, 0};
+                        }
+                        for (; sl + 7 < nseg; sl += 8) {
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                kstep2(4 * p, sl);
+                                kstep2(4 * p + 1, sl);
+                                kstep2(4 * p + 2, sl);
+                                kstep2(4 * p + 3, sl);
+                                load_words(p);
+                            }
+                        }
+                        // a last quad of slabs, always with three planes (a third digit that is zero adds nothing).  An
+                        // if / else here -- two bodies that both write the accumulators and meet again -- makes the
+                        // register allocator give the 256 values new homes and copy them through private memory.
+                        if (sl < nseg) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) kstep3(u, sl);
+                        }
+                        return;
+                    }
                     for (; sl + 7 < nseg; sl += 8) {
 #pragma unroll
                         for (int p = 0; p < 4; ++p) {
@@ -377,7 +546,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 // stores, a contiguous KiB per instruction -- without a detour through LDS, and W_i + W_j is the
                 // reduce kernel's business.
                 uint32_t *pt = partial + (int64_t)(item.pad - 1) * (M_TILE_I * M_TILE_J) + wave * (M_TILE_I * M_TILE_J / 4) + lane * 4;
-                const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+                const int s0 = 7 * item.d0, s1 = TRI ? 15 : 7 * (item.d0 + 1);
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -400,7 +569,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 __syncthreads();  // every wave is done with the digit table
                 {
                     uint32_t *tile = (uint32_t *)mfma_lds + (wi * 128 + 4 * half) * M_TILE_J + wj * 64 + (lane & 31);
-                    const int s0 = 7 * item.d0, s1 = 7 * (item.d0 + 1);
+                    const int s0 = 7 * item.d0, s1 = TRI ? 15 : 7 * (item.d0 + 1);
         #pragma unroll
                     for (int m = 0; m < 4; ++m)
         #pragma unroll
@@ -483,7 +652,8 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                 }
             }
         };
-        if (nd > 1) run_item(std::true_type{});
+        if constexpr (TRI) run_item(std::true_type{});  // (its schedule has one digit group per tile, nd = 2)
+        else if (nd > 1) run_item(std::true_type{});
         else run_item(std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores and atomics of this item
         FF_STAMP(4);

@@ -342,7 +342,7 @@ void build_schedule(const std::vector<Tile> &all_tiles, int64_t rows, int U,
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
                             std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr,
-                            int64_t max_private_tiles)
+                            int64_t max_private_tiles, int64_t duo_from_quad)
 {
     // 256 x 128 tiles of the shard's part of the lower triangle, ordered so that 32
     // consecutive tiles form a compact block of 4 x 8 tiles (1024 x 1024 samples): the
@@ -372,13 +372,26 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     // turns quads back into branches.
     const int64_t true_slabs = slabs;
     slabs = (slabs + M_QUAD_SLABS - 1) / M_QUAD_SLABS;
+    // A graded sweep's quads do not cost the same: the cuts below are made on an axis of COST -- G_TRI per quad
+    // with three planes, G_DUO per quad with two, G_UNIT times the unit in which a quad of a base-128 two-plane
+    // sweep costs 4 (measured at C3's shape, tools/mfma_digits.py: 0.346 and 0.2625 ms against 0.244) -- and
+    // real_quad() turns a position on it back into the quad boundary at or after it.  Else the axis is quads.
+    constexpr int64_t G_UNIT = 2, G_TRI = 12, G_DUO = 9;
+    const bool graded = duo_from_quad >= 0;
+    const int64_t real_quads = slabs, tri_quads = graded ? std::min(duo_from_quad, slabs) : 0;
+    if (graded) slabs = G_TRI * tri_quads + G_DUO * (real_quads - tri_quads);
+    auto real_quad = [&](int64_t s) {
+        if (!graded) return s;
+        const int64_t q = s <= G_TRI * tri_quads ? (s + G_TRI - 1) / G_TRI : tri_quads + (s - G_TRI * tri_quads + G_DUO - 1) / G_DUO;
+        return std::min(q, real_quads);
+    };
     auto make_item = [&](int64_t unit, int64_t s0, int64_t s1) {
         const int64_t grp = unit / (int64_t)tiles.size(), t = unit % (int64_t)tiles.size();
         MItem itm{};
         itm.i0 = tiles[(size_t)t].i0;
         itm.j0 = tiles[(size_t)t].j0;
-        itm.k0 = (int32_t)(s0 * M_QUAD_SLABS * M_KSLAB);
-        itm.k1 = (int32_t)(std::min(true_slabs, s1 * M_QUAD_SLABS) * M_KSLAB);
+        itm.k0 = (int32_t)(real_quad(s0) * M_QUAD_SLABS * M_KSLAB);
+        itm.k1 = (int32_t)(std::min(true_slabs, real_quad(s1) * M_QUAD_SLABS) * M_KSLAB);
         itm.d0 = (int32_t)(M_ND * grp);
         itm.nd = std::min(M_ND, digits - M_ND * (int)grp);
         itm.first = (grp == 0 && s0 == 0) ? 1 : 0;
@@ -425,6 +438,7 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
     if (partial_ptr) partial_ptr->clear();
     auto add_range = [&](int g, int64_t unit, int64_t s0, int64_t s1) {
         MItem itm = make_item(unit, s0, s1);
+        if (itm.k0 >= itm.k1) return;  // (graded: a sliver of cost inside one quad, which its neighbour carries)
         if (private_remainder) itm.pad = 1;
         per[(size_t)g].push_back(itm);
         per_tile[(size_t)g].push_back((int32_t)(unit % T));
@@ -437,7 +451,10 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
         // workgroups in proportion to its cost, which cut it evenly; nothing straddles, but ranges
         // come out unequal where the proportions do not divide.  The cut whose slowest workgroup
         // finishes first is taken.
-        auto quad_cost = [&](int64_t unit) { return (int64_t)(std::min(M_ND, digits - M_ND * (int)(unit / T)) > 1 ? 4 : 3); };
+        auto quad_cost = [&](int64_t unit) {
+            if (graded) return (int64_t)1;  // (the axis is cost already)
+            return (int64_t)(std::min(M_ND, digits - M_ND * (int)(unit / T)) > 1 ? 4 : 3);
+        };
         std::vector<int64_t> start((size_t)rem_units + 1, 0);  // cost position at which unit k begins
         for (int64_t k = 0; k < rem_units; ++k) start[(size_t)k + 1] = start[(size_t)k] + slabs * quad_cost(rem[(size_t)k]);
         const int64_t total = start[(size_t)rem_units];
@@ -455,7 +472,7 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
                 if (s0 < s1) emit(k, s0, s1);
             }
         };
-        const int64_t overhead = M_ITEM_OVERHEAD_SLABS / M_QUAD_SLABS * 4;
+        const int64_t overhead = M_ITEM_OVERHEAD_SLABS / M_QUAD_SLABS * 4 * (graded ? G_UNIT : 1);
         int64_t cost_stream = 0;
         for (int g = 0; g < G; ++g) {
             int64_t c = 0, n_items = 0;
@@ -591,4 +608,31 @@ extern "C" void ff_debug_layout(int64_t R, int64_t *out)
                            M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
                            mfma_staged_slabs(R), mfma_alloc_slabs(R)};
     memcpy(out, v, sizeof v);
+}
+
+// Diagnostics / tests: the three signed digit planes of pair_common_mfma_kernel's TRI sweep for n lengths
+// (out[3 * q .. 3 * q + 2] = {d0, -d1, d2} of k[q]); returns TRI_KMAX.
+extern "C" int64_t ff_debug_tri_digits(const uint32_t *k, int64_t n, int8_t *out)
+{
+    for (int64_t q = 0; q < n; ++q) ff::sched::tri_digits((int64_t)k[q], out + 3 * q);
+    return ff::sched::TRI_KMAX;
+}
+
+// Diagnostics / tests: the schedule of a GRADED matrix-core sweep (build_mfma_schedule with duo_from_quad): items
+// as ff_debug_schedule returns them for FF_KERNEL_MFMA_I8.
+extern "C" int64_t ff_debug_graded_schedule(int64_t n_samples, int64_t slabs, int64_t row_begin, int64_t row_end, int n_cu,
+                                            int64_t duo_from_quad, int32_t *items_out, int64_t max_items,
+                                            int32_t *item_ptr_out, int64_t *n_tiles_out)
+{
+    using namespace ff::sched;
+    std::vector<int32_t> ptr;
+    std::vector<MItem> items;
+    const int64_t nt = build_mfma_schedule(n_samples, row_begin, row_end, slabs, 2, n_cu * M_WGS_PER_CU, &items, &ptr, nullptr,
+                                           nullptr, 0, duo_from_quad);
+    if (n_tiles_out) *n_tiles_out = nt;
+    const int64_t n = (int64_t)items.size();
+    if (n > max_items) return -n;
+    if (n) memcpy(items_out, items.data(), sizeof(MItem) * (size_t)n);
+    memcpy(item_ptr_out, ptr.data(), sizeof(int32_t) * ptr.size());
+    return n;
 }

@@ -78,6 +78,21 @@ static_assert(M_PAD_SLABS >= M_SLABS_AHEAD && M_PAD_SLABS % 2 == 0, "the prefetc
 inline int64_t mfma_staged_slabs(int64_t R) { return round_up(R > 0 ? R : 1, (int64_t)M_KSLAB * M_QUAD_SLABS) / M_KSLAB; }
 inline int64_t mfma_alloc_slabs(int64_t R) { return mfma_staged_slabs(R) + M_PAD_SLABS; }
 constexpr int M_ND = 2;        // digit planes multiplied per sweep of the presence operand
+// pair_common_mfma_kernel<.., GRADED>: three SIGNED digit planes in one sweep, k = d0 + 128 d1 + 32768 d2 with
+// d0 in [-64, 63], d1 in [-127, 128], d2 in [0, 127]; where every d2 is zero the sweep multiplies two planes.
+// (An accumulator may wrap on the way: v_mfma_i32 adds in two's complement -- tools/microbench/mfma_i8_wrap.hip --
+// and the sum it is part of, common(i, j) < 2^31, comes out modulo 2^32.)
+constexpr int64_t TRI_KMAX = 63 + 128 * (128 + 256 * 127);      // 4,177,983: the largest such k
+constexpr int64_t DUO_KMAX = 63 + 128 * 128;                    // 16,447: the largest with d2 = 0
+// the three planes of k <= TRI_KMAX as the kernel multiplies them: {d0, -d1, d2}
+inline void tri_digits(int64_t k, int8_t out[3])
+{
+    const int64_t d0 = ((k + 64) & 127) - 64, q1 = (k - d0) >> 7;  // k - d0: a multiple of 128, never negative
+    const int64_t r1 = q1 & 255, d1 = r1 <= 128 ? r1 : r1 - 256;
+    out[0] = (int8_t)d0;
+    out[1] = (int8_t)(-d1);
+    out[2] = (int8_t)((q1 - d1) >> 8);
+}
 constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB, ff_kernels_mfma.hpp
                                                       // M_TABLE_SLABS), then the epilogue's 256 x 128 tile of 32-bit sums
 // what one more item costs a workgroup of pair_common_mfma_kernel, in slabs of its loop (measured:
@@ -119,7 +134,10 @@ int waves_per_wg();
 int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64_t slabs, int digits, int G,
                             std::vector<MItem> *items, std::vector<int32_t> *item_ptr,
                             std::vector<int32_t> *partial_tiles, std::vector<int32_t> *partial_ptr,
-                            int64_t max_private_tiles = 0);
+                            int64_t max_private_tiles = 0, int64_t duo_from_quad = -1);
+//   duo_from_quad >= 0: a graded sweep (pair_common_mfma_kernel<.., GRADED>; `digits` = 2: one group per tile) whose
+//   quads of slabs cost 12 up to that quad and 9 from there on (a quad of a base-128 two-plane sweep: 8); ranges are
+//   cut by cost.
 
 }  // namespace sched
 }  // namespace ff

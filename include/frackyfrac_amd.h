@@ -178,6 +178,13 @@ typedef struct ff_plan_info {
     int32_t n_digits;         /* FF_KERNEL_MFMA_I8: base-128 digits of the integer lengths    */
     int64_t n_rows;           /* branches staged: n_branches, or only those some sample has a
                                  flat node on when that drops a tenth of them (compaction)    */
+    int32_t n_sweeps;         /* FF_KERNEL_MFMA_I8: passes over the branch range per pair tile */
+    int32_t planes_per_sweep; /* FF_KERNEL_MFMA_I8: digit planes multiplied per pass: 1 or 2
+                                 base-128 digits, or 3 signed digits (graded rows, below)      */
+    int64_t rows_three_planes;/* FF_KERNEL_MFMA_I8, graded rows (lengths of more than two base-128
+                                 digits: rows sorted by length, longest first, a branch longer than
+                                 three signed digits hold as several rows): the leading rows of
+                                 rows_padded whose blocks take three planes; the rest take two  */
 } ff_plan_info;
 
 typedef enum ff_kernel {

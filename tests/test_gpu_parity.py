@@ -388,10 +388,60 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
     want, info = run({"FF_UNWEIGHTED_MFMA": "0"})
     assert info.kernel in (0, 3)
     for env in ({}, {"FF_MFMA_PRIVATE_MB": "0"}, {"FF_MFMA_FUSED_FINISH": "0"},
-                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_FUSED_FINISH": "0"}):
+                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_FUSED_FINISH": "0"}, {"FF_MFMA_GRADED": "0"},
+                {"FF_MFMA_GRADED": "0", "FF_MFMA_PRIVATE_MB": "0"}):
         got, info = run(env)
         assert info.kernel == 2 and info.n_digits == (3 if digits3 else 2) and info.n_tiles == 342
+        # three digits: ONE graded sweep of signed planes unless FF_MFMA_GRADED=0 (then two sweeps of base-128 digits)
+        tri = digits3 and env.get("FF_MFMA_GRADED") != "0"
+        assert (info.n_sweeps, info.planes_per_sweep) == ((1, 3) if tri else (2, 2) if digits3 else (1, 2)), env
         assert np.array_equal(got, want), env
+
+
+@pytest.mark.parametrize("tail", ["short", "long"])
+def test_unweighted_mfma_graded_planes_at_the_ends_of_their_ranges(monkeypatch, tail):
+    """Lengths of more than two base-128 digits are staged graded (ff_device.hip stage_for_mfma): rows sorted by
+    length, signed digits d0 + 128 d1 + 32768 d2, three planes per block where some row has a third digit and two
+    behind, and a branch longer than 4,177,983 (ff_schedule.hpp TRI_KMAX) as several rows.  Lengths at every digit's
+    ends, one past the three-digit range and one of 2^27 (33 rows), against the oracle, bit for bit
+    (unifrac.go:144-171), on the persistent kernel (FF_MFMA_SMALL=0).  "short": most lengths below 2^12, so most
+    slabs take the two-plane k-steps; "long": most need the third digit."""
+    import torch
+    monkeypatch.setenv("FF_MFMA_SMALL", "0")
+    tree, ptr, idx, val = synth.make(300, 2100, 0.05, 23)
+    rng = np.random.default_rng(11)
+    kmax = 63 + 128 * (128 + 256 * 127)
+    ends = np.array([1, 63, 64, 65, 127, 128, 8191, 8192, 16383, 16384, 16446, 16447, 16448, 16449, 32767, 32768, 32769,
+                     49151, 49152, 49153, 65535, 65536, 4161535, 4161536, 4161537, kmax - 1, kmax, kmax + 1, kmax - 128,
+                     kmax - 16384, 2 ** 21, 2 ** 21 - 1, 2 ** 21 + 1, 2 * kmax, 2 * kmax + 1, 2 ** 27], dtype=np.int64)
+    k = rng.integers(1, 1 << (12 if tail == "short" else 19), size=tree.n).astype(np.int64)
+    at = rng.choice(np.arange(1, tree.n), size=ends.size * 3, replace=False)
+    k[at] = np.tile(ends, 3)
+    tree.branch_len = k.astype(np.float64)
+    tree.branch_len[0] = 0.0
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, False)
+    outs = {}
+    for graded in ("1", "0"):
+        monkeypatch.setenv("FF_MFMA_GRADED", graded)
+        plan = ff.Plan(nodes, False, precision="fixed32")
+        info = plan.info
+        assert info.kernel == 2 and info.lengths_exact == 1 and info.scale_log2 == 0
+        if graded == "1":
+            # 3 x (1 + 1 + 32) more rows than branches in use; the rows' lengths need 22 bits = 4 base-128 digits
+            assert (info.n_sweeps, info.planes_per_sweep, info.n_digits) == (1, 3, 4)
+            assert info.rows_padded >= info.n_rows + 3 * 34
+        else:
+            assert (info.n_sweeps, info.planes_per_sweep, info.n_digits) == (2, 2, 4)
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        outs[graded] = out.cpu().numpy()
+        plan.close()
+    assert np.array_equal(outs["1"], want)
+    assert np.array_equal(outs["0"], want)
 
 
 @pytest.mark.parametrize("weighted", [True, False])
@@ -423,10 +473,14 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
 
 
 @pytest.mark.parametrize("small", ["0", "1"])
-def test_unweighted_mfma_five_digits_and_long_lengths(monkeypatch, small):
-    """Integer branch lengths up to 2^29 need five base-128 digit planes (three sweeps of the persistent kernel,
-    five accumulator tiles in the small-shard one)."""
+@pytest.mark.parametrize("graded", ["1", "0"])
+def test_unweighted_mfma_five_digits_and_long_lengths(monkeypatch, small, graded):
+    """Integer branch lengths up to 2^29.  Base-128 digits in branch order (FF_MFMA_GRADED=0): five digit planes,
+    three sweeps of the persistent kernel, five accumulator tiles in the small-shard one.  Graded (the default):
+    every branch here is longer than three signed digits hold (4,177,983) and becomes up to 129 rows of at most that
+    -- four base-128 digits for the small-shard kernel, one sweep of three signed planes for the persistent one."""
     monkeypatch.setenv("FF_MFMA_SMALL", small)
+    monkeypatch.setenv("FF_MFMA_GRADED", graded)
     tree, ptr, idx, val = synth.make(130, 20, 0.3, 93)
     rng = np.random.default_rng(6)
     tree.branch_len = rng.integers(1, 1 << 24, size=tree.n).astype(np.float64)
@@ -437,7 +491,10 @@ def test_unweighted_mfma_five_digits_and_long_lengths(monkeypatch, small):
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     plan = ff.Plan(nodes, False, precision="fixed32")
-    assert plan.info.kernel == MFMA_KERNEL[small] and plan.info.n_digits == 5 and plan.info.lengths_exact == 1
+    assert plan.info.kernel == MFMA_KERNEL[small] and plan.info.lengths_exact == 1
+    assert plan.info.n_digits == (4 if graded == "1" else 5)
+    if small == "0":
+        assert (plan.info.n_sweeps, plan.info.planes_per_sweep) == ((1, 3) if graded == "1" else (3, 2))
     plan.close()
     assert np.array_equal(ff.unifrac_dists(nodes, False, precision="fixed32"), O.unifrac_dists(ip, on, ft.dist, False))
 

@@ -338,3 +338,80 @@ def test_row_shards_of_a_multi_gpu_run_take_xcd_sliced_rounds(monkeypatch):
                 if ptr[u + 1] > ptr[u] and (items[ptr[u]][4] & 2):
                     x = ((u // wpw) % 8) // gsz
                     assert int(items[ptr[u]][2]) == x * part
+
+
+def test_tri_digits_cover_every_length_of_their_range():
+    """pair_common_mfma_kernel's three-planes-in-one-sweep variant multiplies SIGNED digits: k = d0 + 128 d1 +
+    32768 d2, d0 in [-64, 63], d1 in [-127, 128] (stored negated, the A operand carries -128), d2 in [0, 127]
+    (ff_schedule.hpp tri_digits).  Every k of 0 .. TRI_KMAX must come back from its planes, every plane fit int8,
+    and TRI_KMAX + 1 must not (the plan then keeps two sweeps of base-128 digits)."""
+    fn = L.lib().ff_debug_tri_digits
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    kmax = fn(None, 0, None)
+    assert kmax == 63 + 128 * (128 + 256 * 127)
+    k = np.arange(0, kmax + 2, dtype=np.uint32)
+    out = np.zeros((k.size, 3), dtype=np.int8)
+    fn(k.ctypes.data, k.size, out.ctypes.data)
+    d0, nd1, d2 = (out[:, c].astype(np.int64) for c in range(3))
+    back = d0 + (-128) * nd1 + 32768 * d2
+    assert np.array_equal(back[:-1], k[:-1].astype(np.int64))
+    assert back[-1] != kmax + 1                               # (d2 = 128 does not fit a signed byte)
+    assert d0.min() == -64 and d0.max() == 63
+    assert nd1[:-1].min() == -128 and nd1[:-1].max() == 127   # -d1, d1 in [-127, 128]
+    assert d2[:-1].min() == 0 and d2[:-1].max() == 127
+    # what an accumulator adds per branch stays within the bound TRI_MAX_ROWS is derived from
+    assert np.abs(d0 - 128 * nd1)[:-1].max() <= 64 + 128 * 128
+
+
+def graded_schedule(n, slabs, rb, re, n_cu, duo_from_quad):
+    fn = L.lib().ff_debug_graded_schedule
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    cap = 1 << 20
+    items = np.zeros((cap, 8), dtype=np.int32)
+    ptr = np.zeros(n_cu + 1, dtype=np.int32)
+    nt = ctypes.c_int64()
+    k = fn(n, slabs, rb, re, n_cu, duo_from_quad, items.ctypes.data, cap, ptr.ctypes.data, ctypes.byref(nt))
+    assert k >= 0
+    return items[:k], ptr, nt.value
+
+
+@pytest.mark.parametrize("n,slabs,n_cu,duo_from", [(5, 3, 8, 0), (300, 60, 8, 4), (300, 60, 8, 15), (300, 60, 8, 99),
+                                                    (1000, 313, 256, 30), (4096, 316, 256, 9), (4096, 316, 256, 70),
+                                                    (4600, 20, 256, 2), (777, 1200, 256, 100)])
+@pytest.mark.parametrize("world", [1, 2])
+def test_graded_mfma_schedule_covers_every_slab_once_and_cuts_by_cost(n, slabs, n_cu, duo_from, world):
+    """A graded sweep (rows staged by descending length: three digit planes per block up to a slab, two from there
+    on) has ONE digit group per tile; its remainder is cut on an axis of cost, 12 per quad of slabs with three
+    planes and 9 with two.  Coverage as for any matrix-core schedule; the workgroups' costs agree to within an item's
+    granularity; and every item's reach stays inside the staged arrays."""
+    lay = layout(slabs * 64)
+    assert lay["mfma_staged_slabs"] >= slabs
+    quads = (slabs + 3) // 4
+    tri_quads = min(duo_from, quads)
+    for rank in range(world):
+        rb, re = ff.shard_rows(n, rank, world)
+        items, ptr, n_tiles = graded_schedule(n, slabs, rb, re, n_cu, duo_from)
+        assert ptr[-1] == len(items)
+        units, cost = {}, np.zeros(n_cu)
+        for g in range(n_cu):
+            for i0, j0, k0, k1, d0, nd, first, _ in items[ptr[g]:ptr[g + 1]]:
+                assert k0 % 256 == 0 and 0 <= k0 < k1 <= slabs * 64 and (k1 % 256 == 0 or k1 == slabs * 64)
+                assert d0 == 0 and nd == 2                     # (the way out adds X + (Y << 15): two accumulator sets)
+                units.setdefault((int(i0), int(j0)), []).append((int(k0), int(k1), int(first)))
+                q0, q1 = k0 // 256, (k1 + 255) // 256
+                cost[g] += 12 * max(0, min(q1, tri_quads) - q0) + 9 * max(0, q1 - max(q0, tri_quads))
+                assert mfma_item_reach(int(k0), (int(k1) + 255) // 256 * 256, lay) < lay["mfma_alloc_slabs"]
+        assert len(units) == n_tiles
+        for ranges in units.values():
+            ranges.sort()
+            assert ranges[0][0] == 0 and ranges[-1][1] == slabs * 64
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert sum(f for _, _, f in ranges) == 1 and ranges[0][2] == 1
+        if world == 1 and n_tiles >= n_cu:
+            # whole rounds + a remainder cut by cost: nobody carries more than a round's share plus one quad and an
+            # item's overhead more than anybody else
+            busy = cost[cost > 0]
+            assert busy.max() - busy.min() <= 12 * 2 + 32

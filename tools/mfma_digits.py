@@ -17,7 +17,8 @@ leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 tree, ptr, idx, val = synth.make(n, leaves, 0.1, synth.CONFIGS["C3"]["seed"])
 rng = np.random.default_rng(5)
 for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e-3 u), u uniform",
-              "log-normal lengths (sigma 1.5), as in a real phylogeny"):
+              "log-normal lengths (sigma 1.5), as in a real phylogeny", "log-normal lengths (sigma 2.5)",
+              "integers below 2^14 and one of 2^20"):
     nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
     plan = ff.Plan(nodes, False, precision="fixed32")
     out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
@@ -32,13 +33,24 @@ for label in ("generator lengths (multiples of 1/1024)", "the same times (1 + 1e
     e1.record()
     torch.cuda.synchronize()
     ms, k = plan.timing_collect()
-    print("%-44s digits %d  items %d  pair kernel %.4f ms  pass %.4f ms" % (
-        label, plan.info.n_digits, plan.info.n_items, ms / k, e0.elapsed_time(e1) / 20), flush=True)
+    print("%-44s digits %d (%d sweep(s) of %d planes)  items %d  kernel + reduce %.4f ms  pass %.4f ms" % (
+        label, plan.info.n_digits, plan.info.n_sweeps, plan.info.planes_per_sweep, plan.info.n_items, ms / k,
+        e0.elapsed_time(e1) / 20), flush=True)
     q, cap = plan.refined_pairs()
-    print("%-44s    scale 2^%d, pairs sent to the binary64 walk %d" % ("", plan.info.scale_log2, q), flush=True)
+    print("%-44s    scale 2^%d, pairs sent to the binary64 walk %d; staged rows %d, %d of them with three planes" % (
+        "", plan.info.scale_log2, q, plan.info.rows_padded, plan.info.rows_three_planes), flush=True)
     if label.startswith("generator"):
         tree.branch_len = tree.branch_len * (1.0 + 1e-3 * rng.random(tree.branch_len.shape[0]))
-    else:
+    elif label.startswith("the same"):
         bl = rng.lognormal(-3.0, 1.5, tree.branch_len.shape[0])
         bl[0] = 0.0
+        tree.branch_len = bl
+    elif label.endswith("1.5), as in a real phylogeny"):
+        bl = rng.lognormal(-3.0, 2.5, tree.branch_len.shape[0])
+        bl[0] = 0.0
+        tree.branch_len = bl
+    else:
+        bl = rng.integers(1, 1 << 14, tree.branch_len.shape[0]).astype(np.float64)
+        bl[0] = 0.0
+        bl[7] = float(1 << 20)
         tree.branch_len = bl
