@@ -876,6 +876,18 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     return FF_OK;
 }
 
+// Workgroups of refine_exact_kernel a compute unit holds at once: its grid is one round of them (a workgroup walks
+// its pairs one after the other; a second round of workgroups would wait for the first to finish all of theirs).
+int refine_blocks_per_cu()
+{
+    static const int n = [] {
+        int b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, refine_exact_kernel, REFINE_THREADS, 0) != hipSuccess || b < 1) b = 2;
+        return b;
+    }();
+    return n;
+}
+
 // One launch of the EXACT64 pair kernel with the plan's tile height.
 int launch_exact64(ff_plan *pl, hipStream_t st, double *d_out, char *err, size_t errlen)
 {
@@ -1599,7 +1611,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             finish_fixed32_kernel<<<dim3(nb), dim3(256), 0, st>>>(pl->d_num, pl->n_planes, pl->plane_stride, fin, inf.slot_begin, n_slots);
         }
         if (pl->refine)
-            refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * 8)), dim3(64), 0, st>>>(
+            refine_exact_kernel<<<dim3((unsigned)(inf.n_compute_units * refine_blocks_per_cu())), dim3(REFINE_THREADS), 0, st>>>(
                 pl->d_refine_list, pl->d_refine_count, pl->refine_cap, pl->d_indptr, pl->d_ids, pl->d_abnd,
                 pl->d_len, pl->weighted, inf.slot_begin, d_out);
         if (pl->refine && pl->n_audit > 0)

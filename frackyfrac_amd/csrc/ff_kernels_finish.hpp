@@ -113,19 +113,190 @@ __global__ void audit_compare_kernel(const int64_t *__restrict__ slots, const do
     atomicMax(&counters[2], (unsigned long long)__double_as_longlong(rel));
 }
 
-// The reference's merge walk (unifrac.go:144-205) for the queued pairs, one thread per
-// pair, in binary64 and in the reference's order: bit-for-bit the reference's value.
-__global__ void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,
-                                    const unsigned long long *__restrict__ refine_count,
-                                    unsigned long long refine_cap,
-                                    const int64_t *__restrict__ indptr,
-                                    const int32_t *__restrict__ branch_id,
-                                    const double *__restrict__ abnd,
-                                    const double *__restrict__ tree_dists, int weighted,
-                                    int64_t slot_begin, double *__restrict__ out)
+// The reference's merge walk (unifrac.go:144-205) for the queued pairs, in binary64 and in the reference's
+// order: bit-for-bit the reference's value.
+//
+// A walk is a chain of dependent loads -- id, then the branch's length -- and with one thread per pair it takes
+// about a microsecond a step whatever the queue holds: 3.9 ms for C3's samples (4,000 flat nodes each), which
+// a handful of queued pairs added to a pass of 0.35 ms (unweighted) or 5 ms.  Up to REFINE_BLOCK_PAIRS queued
+// pairs a WORKGROUP walks a pair instead: a window of each list's ids in LDS; every element finds its place in
+// the merged sequence by a binary search in the other window (ties: the first list's copy first, which then knows
+// the branch is shared), its thread loads its length and abundances and leaves its terms -- every product rounded
+// on its own, as the reference's are (-ffp-contract=off); +0.0 where the reference adds nothing -- at that place
+// of a table in LDS; then one wave adds up the table's column for each of the reference's two sums, in order.  Same
+// terms, same order, same bits (x + 0.0 = x); what is left of the waiting is the chain of additions itself.
+// Longer queues keep one thread per pair (more pairs in flight than workgroups could hold).
+constexpr int REFINE_THREADS = 256;
+constexpr int REFINE_WINDOW = 1024;                 // ids of each list in LDS at a time
+constexpr int REFINE_BATCH = 32;                    // table entries an adding wave reads at a time
+constexpr unsigned long long REFINE_BLOCK_PAIRS = 100000;
+
+__global__ __launch_bounds__(REFINE_THREADS)
+void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,
+                         const unsigned long long *__restrict__ refine_count,
+                         unsigned long long refine_cap,
+                         const int64_t *__restrict__ indptr,
+                         const int32_t *__restrict__ branch_id,
+                         const double *__restrict__ abnd,
+                         const double *__restrict__ tree_dists, int weighted,
+                         int64_t slot_begin, double *__restrict__ out)
 {
+    __shared__ int32_t sa[REFINE_WINDOW], sb[REFINE_WINDOW];
+    // what the p-th merged element adds to x (column 0) and to y (column 1)
+    __shared__ __attribute__((aligned(16))) double terms[2][2 * REFINE_WINDOW + REFINE_BATCH];
     unsigned long long n = *refine_count;
     if (n > refine_cap) n = refine_cap;
+    if (n <= REFINE_BLOCK_PAIRS) {
+        const int tid = threadIdx.x, wave = tid >> 6;
+        // (workgroups b, b + gridDim / 3 or / 4, ... share a compute unit: one round of the grid)
+        const int wave_x = (int)((uint64_t)blockIdx.x * 4 / gridDim.x) & 3, wave_y = (wave_x + 2) & 3;
+#ifdef FF_MFMA_DIAG  // diagnostic build: 100 MHz ticks workgroup 0 spends in each phase, over all its pairs
+        unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memrealtime();
+#define FF_RPHASE(k) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); ph[k] += now - t_last; t_last = now; }
+#else
+#define FF_RPHASE(k)
+#endif
+        for (unsigned long long q = blockIdx.x; q < n; q += gridDim.x) {
+            const int64_t t = (int64_t)refine_list[q];
+            int64_t si, sj;
+            slot_to_pair(slot_begin + t, &si, &sj);
+            int64_t i = indptr[si], j = indptr[sj];  // a = sample i (the higher index), b = sample j
+            const int64_t ie = indptr[si + 1], je = indptr[sj + 1];
+            double x = 0.0, y = 0.0;                 // numer/denom or result/common (the first wave's count)
+            while (i < ie || j < je) {
+                const int na = (int)(ie - i < REFINE_WINDOW ? ie - i : REFINE_WINDOW);
+                const int nb = (int)(je - j < REFINE_WINDOW ? je - j : REFINE_WINDOW);
+                __syncthreads();  // (everybody is done with the previous window and its table)
+                FF_RPHASE(4);
+                for (int k = tid; k < na; k += REFINE_THREADS) sa[k] = branch_id[i + k];
+                for (int k = tid; k < nb; k += REFINE_THREADS) sb[k] = branch_id[j + k];
+                __syncthreads();
+                FF_RPHASE(0);
+                // What can be merged now: everything up to the smaller of the windows' last ids (a list that ends
+                // inside its window does not limit).  ca / cb = elements of the windows not above that.
+                int ca = na, cb = nb;
+                if (na > 0 && nb > 0) {
+                    const int32_t la = i + na == ie ? INT32_MAX : sa[na - 1], lb = j + nb == je ? INT32_MAX : sb[nb - 1];
+                    const int32_t lim = la < lb ? la : lb;
+                    auto count_le = [lim](const int32_t *w, int m) {
+                        int lo = 0, hi = m;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (w[mid] <= lim) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        return lo;
+                    };
+                    ca = count_le(sa, na);
+                    cb = count_le(sb, nb);
+                }
+                const int total = ca + cb, total_r = (total + REFINE_BATCH - 1) / REFINE_BATCH * REFINE_BATCH;
+                FF_RPHASE(1);
+                // Every element finds its own place in the merged sequence: a's element ai stands behind the lb
+                // elements of b below it (ties: a's copy first), b's element bi behind the ub elements of a not above
+                // it.  A thread's eight searches advance together -- selects, not branches: one round of LDS reads for
+                // all of them per halving -- and then all its loads are in flight at once.
+                constexpr int EPT = 2 * REFINE_WINDOW / REFINE_THREADS, HALF = EPT / 2;  // a's elements: u < HALF
+                int lo[EPT], hi[EPT];
+                int32_t id[EPT];
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const bool is_a = u < HALF;
+                    const int e = tid + (u % HALF) * REFINE_THREADS;  // index in its window
+                    const bool in = e < (is_a ? ca : cb);
+                    id[u] = is_a ? sa[in ? e : 0] : sb[in ? e : 0];
+                    lo[u] = 0;
+                    hi[u] = in ? (is_a ? cb : ca) : 0;
+                }
+                for (int it = 0; it < 11; ++it) {  // (2^10 = REFINE_WINDOW: eleven halvings empty any range)
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) {
+                        const bool is_a = u < HALF, go = lo[u] < hi[u];
+                        const int mid = (lo[u] + hi[u]) >> 1;
+                        const int32_t other = is_a ? sb[go ? mid : 0] : sa[go ? mid : 0];
+                        const bool right = is_a ? other < id[u] : other <= id[u];  // lower bound in b / upper bound in a
+                        lo[u] = go && right ? mid + 1 : lo[u];
+                        hi[u] = go && !right ? mid : hi[u];
+                    }
+                }
+                static_assert(REFINE_WINDOW == 1024, "refine_exact_kernel: eleven halvings per search");
+                int kind[EPT];  // 0: nothing (b's copy of a shared branch, or no element), 1: only a's, 2: only b's, 3: shared
+                double l[EPT], aa[EPT], ab[EPT];
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const bool is_a = u < HALF;
+                    const int e = tid + (u % HALF) * REFINE_THREADS, r = lo[u];
+                    const bool in = e < (is_a ? ca : cb);
+                    if (is_a) {
+                        const bool shared = in && r < cb && sb[in && r < cb ? r : 0] == id[u];
+                        kind[u] = !in ? 0 : shared ? 3 : 1;
+                        aa[u] = abnd[weighted && in ? i + e : 0];
+                        ab[u] = abnd[weighted && shared ? j + r : 0];
+                    } else {
+                        const bool second = in && r > 0 && sa[in && r > 0 ? r - 1 : 0] == id[u];
+                        kind[u] = in && !second ? 2 : 0;
+                        aa[u] = 0.0;
+                        ab[u] = abnd[weighted && kind[u] ? j + e : 0];
+                    }
+                    l[u] = tree_dists[kind[u] ? id[u] : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int e = tid + (u % HALF) * REFINE_THREADS, p = e + lo[u];
+                    const bool in = e < (u < HALF ? ca : cb);
+                    const double a1 = kind[u] == 2 ? ab[u] : aa[u];               // the one abundance of a lone node
+                    const double wx = kind[u] == 3 ? l[u] * fabs(aa[u] - ab[u]) : l[u] * a1;
+                    const double wy = kind[u] == 3 ? l[u] * (aa[u] + ab[u]) : l[u] * a1;
+                    const double vx = kind[u] == 0 ? 0.0 : weighted ? wx : kind[u] == 3 ? 0.0 : l[u];
+                    const double vy = kind[u] == 0 ? 0.0 : weighted ? wy : kind[u] == 3 ? l[u] : 0.0;
+                    if (in) {
+                        terms[0][p] = vx;
+                        terms[1][p] = vy;
+                    }
+                }
+                if (tid < total_r - total) terms[0][total + tid] = terms[1][total + tid] = 0.0;  // (+0.0 up to a whole batch)
+                __syncthreads();
+                FF_RPHASE(2);
+                // One wave adds up x's column of the table, another y's -- two chains of dependent additions that do
+                // not wait for each other, on different SIMDs, and not the same ones in workgroups that share a compute
+                // unit; every lane of a wave alike (the reads are broadcasts, two entries each), a batch of entries at
+                // a time (the table is padded with +0.0 to a whole batch).
+                if (wave == wave_x || wave == wave_y) {
+                    const double2 *col = reinterpret_cast<const double2 *>(terms[wave == wave_x ? 0 : 1]);
+                    double acc = wave == wave_x ? x : y;
+                    for (int k = 0; k < total; k += REFINE_BATCH) {
+                        double2 v[REFINE_BATCH / 2];
+#pragma unroll
+                        for (int e = 0; e < REFINE_BATCH / 2; ++e) v[e] = col[k / 2 + e];
+#pragma unroll
+                        for (int e = 0; e < REFINE_BATCH / 2; ++e) {
+                            acc += v[e].x;
+                            acc += v[e].y;
+                        }
+                    }
+                    if (wave == wave_x) x = acc;
+                    else y = acc;
+                }
+                FF_RPHASE(3);
+                i += ca;
+                j += cb;
+            }
+            // (x lives in one wave, y in another)
+            __syncthreads();
+            if (tid == wave_y * 64) terms[1][0] = y;
+            __syncthreads();
+            if (tid == wave_x * 64) {
+                y = terms[1][0];
+                out[t] = weighted ? x / y : x / (x + y);
+            }
+        }
+#ifdef FF_MFMA_DIAG
+        if (g_small_stamps && tid == 0)
+            for (int k = 0; k < 5; ++k) g_small_stamps[(int64_t)blockIdx.x * 8 + k] = ph[k];
+#endif
+#undef FF_RPHASE
+        return;
+    }
     for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n;
          q += (unsigned long long)gridDim.x * blockDim.x) {
         const int64_t t = (int64_t)refine_list[q];

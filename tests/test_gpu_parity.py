@@ -270,6 +270,82 @@ def test_nearly_identical_samples_are_refined():
     plan.close()
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_refined_pairs_of_long_samples_are_the_reference_values(weighted):
+    """refine_exact_kernel walks a queued pair with a whole wave: windows of 512 ids of each sample's flat nodes,
+    the merged order found by merge-path searches, the terms added in that order (unifrac.go:144-205).  Samples of
+    about 5,000 flat nodes (ten windows each) that differ from sample 0 in a few leaves: their pairs are queued, and
+    what comes back must be the reference's value bit for bit -- same terms, same order of additions."""
+    import torch
+    rng = np.random.default_rng(23)
+    tree, ptr, idx, val = synth.make(48, 6000, 0.3, 77)
+    bl = rng.lognormal(-3.0, 1.0, len(tree.branch_len))   # lengths off the binary grid: unweighted refines too
+    bl[0] = 0.0
+    tree.branch_len = bl
+    base_i, base_v = idx[ptr[0]:ptr[1]], val[ptr[0]:ptr[1]]
+    rows = [(base_i, base_v)]
+    for s in range(1, 40):
+        keep = np.ones(len(base_i), bool)
+        keep[rng.integers(0, len(base_i), size=s % 4)] = False          # drop up to three leaves ...
+        v = base_v.copy()
+        v[rng.integers(0, len(v), size=1 + s // 8)] += 1.0              # ... and nudge a few counts
+        rows.append((base_i[keep], v[keep]))
+    for s in range(40, 48):
+        rows.append((idx[ptr[s]:ptr[s + 1]], val[ptr[s]:ptr[s + 1]]))   # eight unrelated samples
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx, val = np.concatenate([r[0] for r in rows]), np.concatenate([r[1] for r in rows])
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    assert np.diff(nodes.indptr).max() > 4000
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, weighted)
+    plan = ff.Plan(nodes, weighted, precision="fixed32")
+    out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    plan.run(out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    queued, cap = plan.refined_pairs()
+    plan.close()
+    near = np.array([i < 40 and j < 40 for i in range(48) for j in range(i)])   # IterPairs order (common.go:21-31)
+    assert near.sum() == 780 <= queued <= cap
+    assert np.array_equal(got[near], want[near])                        # the queued pairs: bit-exact
+    assert rel_err(got, want) <= WEIGHTED_RTOL
+
+
+def test_a_long_refinement_queue_keeps_one_thread_per_pair():
+    """More than 100,000 queued pairs (ff_kernels_finish.hpp REFINE_BLOCK_PAIRS; the queue holds 2^20) are walked by
+    one thread each -- more pairs in flight than workgroups could hold: 520 near-copies of one sample = 134,940 pairs,
+    every one the reference's value bit for bit."""
+    import torch
+    rng = np.random.default_rng(29)
+    tree, ptr, idx, val = synth.make(530, 400, 0.2, 57)
+    base_i, base_v = idx[ptr[0]:ptr[1]], val[ptr[0]:ptr[1]]
+    rows = []
+    for s in range(520):
+        v = base_v.copy()
+        v[rng.integers(0, len(v), size=1 + s % 3)] += 1.0
+        rows.append((base_i, v))
+    for s in range(520, 530):
+        rows.append((idx[ptr[s]:ptr[s + 1]], val[ptr[s]:ptr[s + 1]]))
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx, val = np.concatenate([r[0] for r in rows]), np.concatenate([r[1] for r in rows])
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+    plan.run(out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    queued, cap = plan.refined_pairs()
+    plan.close()
+    assert 100000 < 520 * 519 // 2 <= queued <= cap
+    near = np.array([i < 520 and j < 520 for i in range(530) for j in range(i)])
+    assert np.array_equal(got[near], want[near])
+    assert rel_err(got, want) <= WEIGHTED_RTOL
+
+
 def test_refinement_queue_overflow_falls_back_to_exact64():
     """A data set made of replicates overflows the refinement queue; the blocking entry
     point then repeats the shard in EXACT64 (bit-exact)."""
