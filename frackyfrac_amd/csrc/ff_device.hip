@@ -87,6 +87,7 @@ struct ff_plan {
     int32_t *d_ids = nullptr;
     double *d_abnd = nullptr;
     unsigned long long *d_refine_list = nullptr;
+    int32_t *d_n_nodes = nullptr;                  // flat nodes per sample (the refinement rule's k)
     unsigned long long *d_refine_count = nullptr;  // [0] pairs queued, [1] audited pairs that failed, [2] max audited error (double bits)
     unsigned long long refine_cap = 0;
     double *d_wex = nullptr;          // binary64 weights of the samples (exact_weight_kernel); null: integer denominators
@@ -389,6 +390,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_abnd);
     (void)hipFree(pl->d_refine_list);
     (void)hipFree(pl->d_refine_count);
+    (void)hipFree(pl->d_n_nodes);
     (void)hipFree(pl->d_wex);
     (void)hipFree(pl->d_audit_slots);
     (void)hipFree(pl->d_audit_exact);
@@ -1053,6 +1055,13 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
     pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
     FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)std::max<unsigned long long>(pl->refine_cap, 1)));
     if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * 3));
+    if (!pl->d_n_nodes) {
+        const int64_t ns = pl->info.n_samples;
+        FF_HIP(hipMalloc(&pl->d_n_nodes, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
+        if (ns > 0) node_counts_kernel<<<dim3((unsigned)((ns + 255) / 256)), dim3(256)>>>(pl->d_indptr, ns, pl->d_n_nodes);
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipDeviceSynchronize());  // (runs may come on any stream)
+    }
     FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long) * 3));
     if (n_slots > 0 && env_int("FF_AUDIT", 1) != 0) {
         const int n = (int)std::min<int64_t>(AUDIT_PAIRS, n_slots);
@@ -1531,7 +1540,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         fin.W = pl->d_W;
         fin.wex = pl->d_wex;
         fin.out = d_out;
-        fin.indptr = pl->refine ? pl->d_indptr : nullptr;
+        fin.n_nodes = pl->refine ? pl->d_n_nodes : nullptr;
         fin.refine_list = pl->d_refine_list;
         fin.refine_count = pl->d_refine_count;
         fin.refine_cap = pl->refine_cap;

@@ -33,6 +33,13 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
     }
 }
 
+// Flat nodes per sample (what the refinement rule of finish_pair_w wants of a pair's two samples).
+__global__ void node_counts_kernel(const int64_t *__restrict__ indptr, int64_t n_samples, int32_t *__restrict__ n_nodes)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_samples) n_nodes[s] = (int32_t)(indptr[s + 1] - indptr[s]);
+}
+
 // ---- Run-time audit of FIXED32 ------------------------------------------------------------
 // A fixed pseudo-random sample of the shard's pairs is computed in binary64 when the shard is
 // scheduled (audit_exact_kernel: the inputs of a plan do not change between runs) and compared

@@ -21,7 +21,7 @@ struct FinishArgs {
     const unsigned long long *W;   // integer column sums
     const double *wex;             // binary64 weights (null: the integer sums are exact)
     double *out;                   // the shard's distances, out[t] for local slot t
-    const int64_t *indptr;         // null: no refinement
+    const int32_t *n_nodes;        // flat nodes per sample; null: no refinement
     unsigned long long *refine_list, *refine_count;
     unsigned long long refine_cap;
     int scale_log2, weighted;
@@ -48,8 +48,8 @@ __device__ __forceinline__ void finish_pair_w(const FinishArgs &f, int64_t t, in
         d = fmin(d, 1.0);  // the integer numerator may pass the binary64 denominator by its rounding
     }
     f.out[t] = d;
-    if (f.indptr && w != 0) {
-        const double k = (double)((f.indptr[i + 1] - f.indptr[i]) + (f.indptr[j + 1] - f.indptr[j]));
+    if (f.n_nodes && w != 0) {
+        const double k = (double)f.n_nodes[i] + (double)f.n_nodes[j];
         const double a = (double)u * REFINE_BAR - 2.0;  // u * 1e-6 < C sqrt(k) + 2, without the square root
         if (a < 0.0 || a * a < REFINE_C * REFINE_C * k) {
             const unsigned long long at = atomicAdd(f.refine_count, 1ull);
