@@ -171,6 +171,17 @@ def make_problem(ctx, workload, n_samples=None):
     return cfg, nodes
 
 
+def with_lognormal_lengths(cfg, nodes):
+    """The same flat nodes with branch lengths as a real phylogeny has them: not short binary fractions but spread
+    over orders of magnitude (log-normal, sigma 1.5; zero-length branches stay zero).  Unweighted FIXED32 then stages
+    graded digit planes."""
+    import frackyfrac_amd as ff
+
+    bl = np.random.default_rng(cfg["seed"]).lognormal(-3.0, 1.5, nodes.n_branches)
+    bl[nodes.branch_len == 0.0] = 0.0
+    return ff.FlatNodes(nodes.indptr, nodes.branch_id, nodes.abnd, bl)
+
+
 def barrier(ctx):
     # every rank first drains its own streams (with the "ipc" transport a peer's slice
     # reaches the root from the PEER's copy stream), then all meet
@@ -311,13 +322,15 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                  "ms_per_step": elapsed / steps * 1e3,
                  "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8"}[int(info.kernel)],
                  "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
-                                        "leaf density %.2f, seed 0x%X" %
+                                        "leaf density %.2f, seed 0x%X%s" %
                                         (cfg["name"], n_samples, cfg["n_leaves"], B,
-                                         "weighted" if weighted else "unweighted", cfg["density"], cfg["seed"]),
+                                         "weighted" if weighted else "unweighted", cfg["density"], cfg["seed"],
+                                         ", branch lengths log-normal (sigma 1.5)" if cfg.get("lengths") == "lognormal" else ""),
                             "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
                             "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (ctx.world, run.transport)},
                  "roofline": roofline_of(info, B, n_samples, run.n_slots, kernel_ms, launches, weighted,
-                                         traffic_of(cfg["name"], ctx.world, info, weighted))}
+                                         # (the counters in profiles/traffic.json are the generator-length runs')
+                                         None if cfg.get("lengths") == "lognormal" else traffic_of(cfg["name"], ctx.world, info, weighted))}
         entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region
         entry["roofline"]["kernel_ms_between_events"] = kernel_ms_events
         if n_audit:
@@ -343,6 +356,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = samples grow as sqrt(N) (per-GPU pairs fixed), strong = the workload's own size")
     ap.add_argument("--unweighted", action="store_true")
+    ap.add_argument("--lengths", default="generator", choices=["generator", "lognormal"],
+                    help="branch lengths: the generator's multiples of 1/1024, or log-normal (sigma 1.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the primary line")
     ap.add_argument("--secondary-steps", type=int, default=5)
@@ -391,6 +406,9 @@ def main():
         n_override = int(round(int(args.workload.lower().split("x")[0]) * math.sqrt(world) / 32.0)) * 32
     cfg, nodes = make_problem(ctx, args.workload, n_override)
     weighted = cfg["weighted"] and not args.unweighted
+    if args.lengths == "lognormal":
+        nodes = with_lognormal_lengths(cfg, nodes)
+        cfg["lengths"] = "lognormal"
     # (steps of a few microseconds -- the unweighted matrix-core kernels -- carry the event pair on every 8th launch)
     primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup,
                       event_every=1 if weighted or args.precision == "exact64" else 8)
@@ -426,17 +444,24 @@ def main():
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
 
     # ---- secondary: the other claimed numbers, same clock ------------------------------------
-    if not args.no_secondary and args.workload == "C3" and not args.unweighted and args.precision == "fixed32":
+    if (not args.no_secondary and args.workload == "C3" and not args.unweighted and args.precision == "fixed32" and
+            args.lengths == "generator"):
         sec = []
         k, w = max(1, min(args.secondary_steps, args.steps)), 1
         if world == 1:
             sec.append(measure(ctx, cfg, nodes, True, "exact64", k, w))       # the reference-width figure
             sec.append(measure(ctx, cfg, nodes, False, "fixed32", max(k, args.steps), w, event_every=8))  # int8 matrix cores
+            # the same with branch lengths as a real phylogeny has them -- not short binary fractions but spread over
+            # orders of magnitude (log-normal, sigma 1.5; the root's stays 0): the integer lengths then take the 31-bit
+            # budget, and the matrix-core sweep multiplies graded digit planes
+            ln = measure(ctx, dict(cfg, lengths="lognormal"), with_lognormal_lengths(cfg, nodes), False, "fixed32",
+                         max(k, args.steps), w, event_every=8)
             del nodes
             for wl, wtd, steps, every in (("C2", False, max(k, args.steps), 8), ("C4", True, k, 1), ("C5", True, k, 1)):
                 c2, n2 = make_problem(ctx, wl)
                 sec.append(measure(ctx, c2, n2, wtd, "fixed32", steps, w, event_every=every))
                 del n2
+            sec.append(ln)  # (last: the entries before it keep the places they had in earlier rounds' lines)
         else:
             del nodes
             for wl in ("C4", "C5"):     # BASELINE configs[3], [4] at their stated sizes over the N GPUs

@@ -60,8 +60,13 @@ def test_single_gpu_line_carries_the_secondary_entries():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1
     sec = out["secondary"]
-    assert [e["config"]["workload"].split(":")[0] for e in sec] == ["C3", "C3", "C2", "C4", "C5"]
-    assert [e["dtype"] for e in sec] == ["f64", "i8", "i8", "u32", "u32"]
+    assert [e["config"]["workload"].split(":")[0] for e in sec] == ["C3", "C3", "C2", "C4", "C5", "C3"]
+    assert [e["dtype"] for e in sec] == ["f64", "i8", "i8", "u32", "u32", "i8"]
+    # the last one: C3 unweighted with log-normal branch lengths -- graded digit planes on the matrix cores, the
+    # run-time audit against binary64 in play (lengths off the binary grid), every audited pair inside the bar
+    assert "log-normal" in sec[5]["config"]["workload"] and sec[5]["roofline"]["kernel"] == "pair_common_mfma_kernel"
+    assert sec[5]["audit"]["failed"] == 0 and sec[5]["audit"]["worst_rel_err"] <= 5e-7
+    assert sec[1]["ms_per_step"] < sec[5]["ms_per_step"] < 2.0 * sec[1]["ms_per_step"]   # (two sweeps cost 1.85 x)
     assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_kernel"
     assert sec[1]["roofline"]["bound"] == "mfma" and "unweighted" in sec[1]["config"]["workload"]
     assert sec[1]["roofline"]["kernel"] == "pair_common_mfma_kernel" and sec[2]["roofline"]["kernel"] == "pair_common_small_kernel"
