@@ -175,7 +175,8 @@ typedef struct ff_plan_info {
     double staged_bytes;      /* bytes of the staged matrix in HBM                            */
     double elements;          /* sum over items of tile pairs * branches = |a-b| terms issued */
     int32_t kernel;           /* ff_kernel: which kernel does the pair reduction              */
-    int32_t n_digits;         /* FF_KERNEL_MFMA_I8: base-128 digits of the integer lengths    */
+    int32_t n_digits;         /* FF_KERNEL_MFMA_I8: base-128 digits of the staged rows' integer
+                                 lengths (graded rows: of the longest row, at most 4)         */
     int64_t n_rows;           /* branches staged: n_branches, or only those some sample has a
                                  flat node on when that drops a tenth of them (compaction)    */
     int32_t n_sweeps;         /* FF_KERNEL_MFMA_I8: passes over the branch range per pair tile */
