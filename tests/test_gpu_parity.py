@@ -1201,6 +1201,41 @@ def test_c3_unweighted_full_size_bit_exact_on_ranges():
         assert np.array_equal(got[a:a + 250_000], want)
 
 
+@pytest.mark.parametrize("name,sigma", [("C3", 1.5), ("C3", 3.0), ("C5", 1.5)])
+def test_unweighted_full_size_with_lognormal_lengths_sampled_parity(name, sigma):
+    """Unweighted at headline sizes with branch lengths as a real phylogeny has them (log-normal: not on the binary
+    grid, spread over orders of magnitude).  The integer lengths take the 31-bit budget of a sample's sum and the
+    matrix-core sweep multiplies graded digit planes: rows sorted by length, three signed planes then
+    two, the longest branches as several rows.  400,000 pairs in four ranges spread over the triangle against the
+    oracle (unifrac.go:144-171), worst relative error logged and held to half the bar; the run-time audit agrees."""
+    cfg = synth.CONFIGS[name]
+    n = cfg["n_samples"]
+    tree, ptr, idx, val = synth.make(n, cfg["n_leaves"], cfg["density"], cfg["seed"])
+    bl = np.random.default_rng(41).lognormal(-3.0, sigma, len(tree.branch_len))
+    bl[0] = 0.0
+    tree.branch_len = bl
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    info = plan.info
+    assert info.kernel == 2 and info.lengths_exact == 0 and (info.n_sweeps, info.planes_per_sweep) == (1, 3)
+    assert 0 < info.rows_three_planes < info.rows_padded          # both kinds of k-step in the sweep
+    got = plan.run_host()
+    queued, cap = plan.refined_pairs()
+    checked, failed, worst_audit = plan.audit()
+    plan.close()
+    assert failed == 0 and checked == 4096 and queued <= cap
+    assert not np.isnan(got).any() and got.min() >= 0.0 and got.max() <= 1.0
+    P = ff.num_pairs(n)
+    worst = 0.0
+    for a in (0, P // 3, 2 * P // 3, P - 100_000):
+        want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 100_000)
+        worst = max(worst, rel_err(got[a:a + 100_000], want))
+    record_margin("%s unweighted, log-normal lengths sigma %.1f (graded planes: %d of %d rows with three; %d pairs refined), "
+                  "audit worst %.2e" % (name, sigma, info.rows_three_planes, info.rows_padded, queued, worst_audit), worst, 400_000)
+
+
 @pytest.mark.parametrize("stride_kind", ["odd", "power_of_two"])
 def test_hashed_offset_on_arithmetic_progressions_of_branch_ids(stride_kind):
     """Adversarial input for FIXED32's per-branch rounding offset (ff_dither.hpp: a hash of the branch id).  A star
