@@ -136,7 +136,7 @@ __global__ void audit_compare_kernel(const int64_t *__restrict__ slots, const do
 constexpr int REFINE_THREADS = 256;
 constexpr int REFINE_WINDOW = 1024;                 // ids of each list in LDS at a time
 constexpr int REFINE_BATCH = 32;                    // table entries an adding wave reads at a time
-constexpr unsigned long long REFINE_BLOCK_PAIRS = 100000;
+constexpr unsigned long long REFINE_BLOCK_PAIRS = 20000;   // (C3's samples: 11 pairs per workgroup 1.6 ms; a thread's walk 3.9)
 
 __global__ __launch_bounds__(REFINE_THREADS)
 void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,

@@ -313,7 +313,7 @@ def test_refined_pairs_of_long_samples_are_the_reference_values(weighted):
 
 
 def test_a_long_refinement_queue_keeps_one_thread_per_pair():
-    """More than 100,000 queued pairs (ff_kernels_finish.hpp REFINE_BLOCK_PAIRS; the queue holds 2^20) are walked by
+    """More than 20,000 queued pairs (ff_kernels_finish.hpp REFINE_BLOCK_PAIRS; the queue holds 2^20) are walked by
     one thread each -- more pairs in flight than workgroups could hold: 520 near-copies of one sample = 134,940 pairs,
     every one the reference's value bit for bit."""
     import torch
