@@ -128,6 +128,12 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
 // out is then 16-byte stores of the accumulators in their own order, which reduce_private_kernel reads.
 // An item with a single digit plane runs its own instantiation of everything between the accumulators'
 // declaration and the way out (run_item), without the second plane.
+// GRADED: the rows are staged by descending length with SIGNED digits (ff_device.hip stage_for_mfma; Kd = their
+// three planes): the sweep runs k-steps of three MFMAs per tile (TRI: X += A d0, X += (A << 7)(-d1), Y += A d2) up
+// to slab duo_from_slab and of two (DUO: X alone) from there on -- kstep3 / kstep2 below; the accumulators meet
+// again as common = X + (Y << 15).  In these k-steps an accumulator tile is written twice, four MFMAs apart, and
+// the scaled A fragments are rewritten five or more MFMAs after their last use (the hardware reads an MFMA's A and
+// B operands when it issues).
 // DIAG (builds with -DFF_MFMA_DIAG only; results are then WRONG, the time is what is asked for):
 // bit 1 drops the global loads inside the loop, bit 2 the expansion (vector work), bit 3 the
 // digit reads, bit 4 the MFMAs.
