@@ -1,3 +1,7 @@
+"""RECORD OF AN EXPERIMENT (round 3): shards 3, 4 and 1 of 8 of an 11,584-sample problem under the 8-wave kernel and the
+12-wave one with plain thirds and with 4 / 8 / no XCD slices -- the run that found the 12-wave kernel's plain thirds 7 and
+15 % slower on shards 3 and 4 ("Three waves per SIMD, revisited").  Kernel ms (items).
+"""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

@@ -1,3 +1,6 @@
+"""RECORD OF AN EXPERIMENT (round 3): the weighted pair kernel with two and with three waves per SIMD (FF_WAVES_PER_WG = 8 / 12)
+on whole problems -- C3, 5,632 and 3,072 samples of its tree, C5 -- after the schedule was rewritten.
+"""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

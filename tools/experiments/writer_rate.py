@@ -1,3 +1,6 @@
+"""Rate of ff_write_distances (the Go-compatible text formatter) by thread count, into /tmp and into the repo's gpurun_out:
+8.4 M values, best of three.
+"""
 import time, numpy as np, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import frackyfrac_amd as ff
