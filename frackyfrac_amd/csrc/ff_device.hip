@@ -1263,7 +1263,7 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
         pl->m_duo_from_slab = 0;
         if (graded) {
             std::vector<int8_t> kt(plane_alloc * 3, 0);
-            int64_t first_duo = Rs;  // the first row whose length (and every later one's) needs no third digit
+            int64_t first_duo = 0;  // the first row whose length (and every later one's) needs no third digit
             for (int64_t r = 0; r < Rs; ++r) {
                 int8_t d[3];
                 tri_digits((int64_t)rows[(size_t)r].k, d);
