@@ -548,6 +548,30 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
             monkeypatch.delenv(k)
 
 
+def test_unweighted_mfma_graded_rows_without_a_third_digit(monkeypatch):
+    """Lengths of three base-128 digits (16,384 and more) that still fit TWO signed digits (up to 16,447,
+    ff_schedule.hpp DUO_KMAX): graded staging, and the whole sweep takes the two-plane k-steps (the last quad of
+    slabs, which always takes three, multiplies a zero plane).  Bit for bit against the oracle."""
+    import torch
+    monkeypatch.setenv("FF_MFMA_SMALL", "0")
+    tree, ptr, idx, val = synth.make(600, 1500, 0.1, 29)
+    rng = np.random.default_rng(13)
+    k = rng.integers(1, 16448, size=tree.n).astype(np.int64)
+    k[5], k[6], k[7] = 16447, 16384, 16446
+    tree.branch_len = k.astype(np.float64)
+    tree.branch_len[0] = 0.0
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    info = plan.info
+    assert info.kernel == 2 and info.lengths_exact == 1 and info.n_digits == 3
+    assert (info.n_sweeps, info.planes_per_sweep, info.rows_three_planes) == (1, 3, 0)
+    got = plan.run_host()
+    plan.close()
+    assert np.array_equal(got, O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS))
+
+
 @pytest.mark.parametrize("small", ["0", "1"])
 @pytest.mark.parametrize("graded", ["1", "0"])
 def test_unweighted_mfma_five_digits_and_long_lengths(monkeypatch, small, graded):
