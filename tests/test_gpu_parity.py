@@ -548,6 +548,41 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
             monkeypatch.delenv(k)
 
 
+def test_unweighted_mfma_graded_accumulator_wraps(monkeypatch):
+    """The graded sweep relies on v_mfma_i32 adding in two's complement (tools/microbench/mfma_i8_wrap.hip): with signed
+    digits an accumulator may pass 2^31 on the way to a sum that fits.  Here it does: 131,071 branches of integer
+    length 16,320 = 32768 - 16448 (d0 + 128 d1 = -16448 per shared branch, d2 = 1), samples that hold every leaf --
+    X reaches -2.156e9 < -2^31 while common = 2.139e9 < 2^31.  Bit for bit against the oracle (four LDS table
+    segments per item on the way)."""
+    monkeypatch.setenv("FF_MFMA_SMALL", "0")
+    tree, ptr, idx, val = synth.make(24, 65536, 1.0, 31)
+    assert tree.n == 131071 and np.all(np.diff(ptr) == 65536)
+    k = np.full(tree.n, 16320, dtype=np.int64)
+    k[0] = 0
+    k[1000:1010] = [16321, 1, 16447, 16449, 63, 64, 16319, 32767, 32769, 16323]   # (odd lengths: the scale stays 2^0)
+    tree.branch_len = k.astype(np.float64)
+    # samples 20..23 hold a part of the leaves only, so that not every pair is the same
+    rng = np.random.default_rng(3)
+    rows = [(idx[ptr[s]:ptr[s + 1]], val[ptr[s]:ptr[s + 1]]) for s in range(24)]
+    for s in range(20, 24):
+        keep = rng.random(65536) < 0.9
+        rows[s] = (rows[s][0][keep], rows[s][1][keep])
+    ptr = np.concatenate([[0], np.cumsum([len(r[0]) for r in rows])]).astype(np.int64)
+    idx, val = np.concatenate([r[0] for r in rows]), np.concatenate([r[1] for r in rows])
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    plan = ff.Plan(nodes, False, precision="fixed32")
+    info = plan.info
+    assert info.kernel == 2 and info.lengths_exact == 1 and info.scale_log2 == 0
+    assert (info.n_sweeps, info.planes_per_sweep) == (1, 3) and info.rows_padded >= 131072
+    got = plan.run_host()
+    plan.close()
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
+    assert np.array_equal(got, want)
+    assert 16448 * 131000 > 2 ** 31 > 16320 * 131070      # (what the accumulators and the sums reach)
+
+
 def test_unweighted_mfma_graded_rows_without_a_third_digit(monkeypatch):
     """Lengths of three base-128 digits (16,384 and more) that still fit TWO signed digits (up to 16,447,
     ff_schedule.hpp DUO_KMAX): graded staging, and the whole sweep takes the two-plane k-steps (the last quad of
