@@ -1,10 +1,11 @@
 """CPU emulation of the FIXED32 arithmetic (staging, integer sums, refine rule) against
 the oracle, on the low-diversity inputs that correlate the rounding residuals: equal
-branch lengths with repeated counts.  A design tool, not a product path: the numbers it
+branch lengths with repeated counts.  A design tool that uses the oracle as its checker (hence under tests/; a
+script, not collected by pytest), not a product path: the numbers it
 printed decided the staging rule of stage_fixed32_kernel (per-branch shared dither) and
 the refine threshold of finish_fixed32_kernel (DESIGN.md "Arithmetic").
 
-    python tools/emulate_fixed32.py [n_samples] [n_leaves] [density]
+    python tests/emulate_fixed32.py [n_samples] [n_leaves] [density]
 """
 import math
 import sys

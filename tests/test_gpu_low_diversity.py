@@ -2,7 +2,7 @@
 taxonomy trees, cladograms) with repeated counts (singletons).  With round-to-nearest
 staging thousands of branches shared one residual and the error of a weighted distance
 grew like k instead of sqrt(k): 2.7e-6 on case (a) below, no pair queued for refinement
-(round-1 VERDICT, "What's weak" #1; tools/emulate_fixed32.py reproduces it on the CPU).
+(round-1 VERDICT, "What's weak" #1; tests/emulate_fixed32.py reproduces it on the CPU).
 The staging now rounds with one offset per branch shared by all samples and divides by
 binary64 weights; these tests hold every pair of those inputs to the 1e-6 bar of
 unifracDistWeighted (frcfrc/unifrac.go:174-205) against the oracle, through the C ABI
