@@ -17,13 +17,24 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
          t += ((int64_t)gridDim.x - 1) * (256 * FINISH_RUN)) {
         int64_t i, j;
         slot_to_pair(slot_begin + t, &i, &j);
+        // the sums of the thread's FINISH_RUN slots first, all their loads in flight together (a slot past the
+        // shard's end reads the last one's: never used)
+        uint32_t u32[FINISH_RUN];
+#pragma unroll
+        for (int e = 0; e < FINISH_RUN; ++e) {
+            const int64_t te = t + 256 * e < n_slots ? t + 256 * e : n_slots - 1;
+            u32[e] = num[te];
+        }
+        for (int q = 1; q < n_planes; ++q) {
+#pragma unroll
+            for (int e = 0; e < FINISH_RUN; ++e) {
+                const int64_t te = t + 256 * e < n_slots ? t + 256 * e : n_slots - 1;
+                u32[e] += num[(int64_t)q * plane_stride + te];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < FINISH_RUN; ++e, t += 256) {
-            if (t < n_slots) {
-                uint32_t u32 = num[t];
-                for (int q = 1; q < n_planes; ++q) u32 += num[(int64_t)q * plane_stride + t];
-                finish_pair(f, t, i, j, u32);
-            }
+            if (t < n_slots) finish_pair(f, t, i, j, u32[e]);
             j += 256;
             while (j >= i) {  // (rows are shorter than 256 only at the top of the triangle)
                 j -= i;
