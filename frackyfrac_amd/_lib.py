@@ -55,7 +55,7 @@ class ff_plan_info(ctypes.Structure):
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
 
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
-                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel"}
+                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel"}
 
 
 # name -> (restype, argtypes); exactly the symbols include/frackyfrac_amd.h declares

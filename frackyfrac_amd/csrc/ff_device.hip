@@ -50,6 +50,7 @@ using namespace ff::sched;
 #include "ff_kernels_mfma_small.hpp"
 #include "ff_kernels_stage_a.hpp"
 #include "ff_kernels_finish.hpp"
+#include "ff_kernels_exact_unw.hpp"
 
 }  // namespace
 
@@ -122,6 +123,13 @@ struct ff_plan {
     XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
     int x_tile_h = 0;  // EXACT64 tile height in use (0: not chosen yet)
+    // EXACT64 unweighted (pair_exact_unw_kernel): presence bits, lengths by staged row, tiles
+    bool xu = false;
+    uint32_t *d_Xbits = nullptr;
+    int64_t xu_ldx = 0;
+    int xu_slabs = 0;
+    XUTile *d_xutiles = nullptr;
+    int n_xutiles = 0;
     // timing: one event pair per timed run since the last collect
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -407,6 +415,8 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_len_rows);
     (void)hipFree(pl->d_host_out);
     (void)hipFree(pl->d_xtiles);
+    (void)hipFree(pl->d_Xbits);
+    (void)hipFree(pl->d_xutiles);
     for (auto &e : pl->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -894,6 +904,14 @@ int refine_blocks_per_cu()
 int launch_exact64(ff_plan *pl, hipStream_t st, double *d_out, char *err, size_t errlen)
 {
     const ff_plan_info &inf = pl->info;
+    if (pl->xu) {
+        if (pl->n_xutiles > 0)
+            pair_exact_unw_kernel<<<dim3((unsigned)pl->n_xutiles), dim3(64), 0, st>>>(pl->d_Xbits, pl->xu_ldx, pl->d_len_rows, pl->xu_slabs,
+                                                                                     pl->d_xutiles, inf.row_begin, inf.row_end,
+                                                                                     inf.slot_begin, d_out);
+        FF_HIP(hipGetLastError());
+        return FF_OK;
+    }
     if (pl->n_xtiles <= 0) return FF_OK;
     const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
     const double *len = pl->d_len_rows ? pl->d_len_rows : pl->d_len;
@@ -952,9 +970,38 @@ int upload_exact64_tiles(ff_plan *pl, int h, char *err, size_t errlen)
 // and with FF_X_CALIBRATE=1 -- for a host that runs a plan many times -- a shard big enough for it to
 // matter (a quarter as many tiles of 16 rows as waves fit the device, or more) is timed with each height when it is
 // scheduled, results into a scratch array, and keeps the fastest (eleven extra launches at plan time).
+// The tiles of pair_exact_unw_kernel for the plan's shard.  Two column groups per tile (64 accumulator registers, six
+// waves per SIMD) is what the vector ALU wants; a shard with fewer such tiles than SIMDs is bound by one wave's chain
+// of steps and takes single groups (twice the waves, shorter steps).
+int schedule_exact_unw(ff_plan *pl, char *err, size_t errlen)
+{
+    ff_plan_info &inf = pl->info;
+    free_and_null(pl->d_xutiles);
+    std::vector<XUTile> tiles;
+    int jmax = XU_JMAX;
+    build_xu_tiles(inf.n_samples, inf.row_begin, inf.row_end, jmax, &tiles);
+    const int forced = env_int("FF_XU_JMAX", 0);
+    if (forced == 1 || forced == 2) jmax = forced;
+    else if ((int64_t)tiles.size() < (int64_t)inf.n_compute_units * 4) jmax = 1;
+    if (jmax != XU_JMAX) build_xu_tiles(inf.n_samples, inf.row_begin, inf.row_end, jmax, &tiles);
+    // one 64-thread workgroup per tile: a launch carries fewer than 2^31 of them
+    if (tiles.size() >= ((size_t)1 << 31))
+        return ff::fail(FF_ERR_ARG, err, errlen, "EXACT64: %zu pair tiles in one shard, at most %zu (use more shards)",
+                        tiles.size(), ((size_t)1 << 31) - 1);
+    inf.n_tiles = inf.n_items = inf.n_wave_slots = (int64_t)tiles.size();
+    double cols = 0;
+    for (const XUTile &t : tiles) cols += 64.0 * t.jn;
+    inf.elements = cols * XU_TILE_H * (double)inf.n_rows;
+    pl->n_xutiles = (int)tiles.size();
+    FF_HIP(hipMalloc(&pl->d_xutiles, sizeof(XUTile) * std::max<size_t>(tiles.size(), 1)));
+    if (!tiles.empty()) FF_HIP(hipMemcpy(pl->d_xutiles, tiles.data(), sizeof(XUTile) * tiles.size(), hipMemcpyHostToDevice));
+    return FF_OK;
+}
+
 int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
 {
     ff_plan_info &inf = pl->info;
+    if (pl->xu) return schedule_exact_unw(pl, err, errlen);
     if (pl->x_tile_h == 0) {
         const int forced = env_int("FF_X_TILE_H", 0);
         int h = X_TILE_H_DEFAULT;
@@ -1399,10 +1446,37 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     return schedule_sad(pl, err, errlen);
 }
 
+// EXACT64 unweighted: presence bits (a word per 32 staged rows and sample), the lengths by staged row, the tiles.
+int stage_for_exact_unw(StageCtx &x, char *err, size_t errlen)
+{
+    FF_STAGE_NAMES;
+    pl->xu = true;
+    inf.kernel = FF_KERNEL_EXACT_F64_UNW;
+    const int64_t ldx = xu_ld(N);
+    pl->xu_ldx = ldx;
+    pl->xu_slabs = (int)xu_slabs(R);
+    inf.ld = ldx;
+    inf.rows_padded = xu_slabs(R) * XU_SLAB;
+    const size_t bits_bytes = sizeof(uint32_t) * (size_t)xu_alloc_slabs(R) * (size_t)ldx;
+    const size_t len_count = (size_t)xu_alloc_lengths(R);
+    inf.staged_bytes = (double)bits_bytes + 8.0 * (double)len_count;
+    FF_ALLOC(pl->d_Xbits, bits_bytes, "the presence bits");
+    FF_HIP(hipMemset(pl->d_Xbits, 0, bits_bytes));
+    if (N > 0 && nnz > 0)
+        stage_xbits_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, row_of.p, pl->d_Xbits, ldx);
+    FF_HIP(hipGetLastError());
+    std::vector<double> lr(len_count, 0.0);  // treeDists by staged row, zeros behind
+    for (int64_t r = 0; r < R; ++r) lr[(size_t)r] = c->h_len[(size_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r])];
+    FF_HIP(hipMalloc(&pl->d_len_rows, sizeof(double) * len_count));
+    FF_HIP(hipMemcpy(pl->d_len_rows, lr.data(), sizeof(double) * len_count, hipMemcpyHostToDevice));
+    return schedule_exact_unw(pl, err, errlen);
+}
+
 // EXACT64: the branch-major binary64 matrix and its tiles.
 int stage_for_exact64(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
+    if (!weighted && N > 0 && B > 0 && env_int("FF_EXACT_UNW", 1) != 0) return stage_for_exact_unw(x, err, errlen);
     const int64_t ld = round_up(std::max<int64_t>(N, 1), X_TILE_J);
     inf.ld = ld;
     inf.rows_padded = R;
@@ -1452,16 +1526,25 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     inf.n_rows = R;
 
     int prec = o->precision;
+    const bool is_auto = prec == FF_PRECISION_AUTO;
     // AUTO: problems small enough that the binary64 walk costs about a millisecond
     // get the reference's exact roundings (this covers all of the reference's own
-    // test data); everything larger takes the 6x faster fixed-point path.
-    if (prec == FF_PRECISION_AUTO && (double)ff_num_pairs(N) * (double)R <= 4294967296.0)
+    // test data); everything larger takes the fixed-point path -- except UNWEIGHTED with
+    // a branch length off the binary grid (below).
+    if (is_auto && (double)ff_num_pairs(N) * (double)R <= 4294967296.0)
         prec = FF_PRECISION_EXACT64;
     if (prec != FF_PRECISION_EXACT64) {
         q = choose_quant(*c, weighted, pl->d_indptr, pl->d_ids, pl->d_abnd, pl->d_len);
         if (!q.fixed_ok) {
             if (prec == FF_PRECISION_FIXED32)
                 return ff::fail(FF_ERR_ARG, err, errlen, "FIXED32 not applicable: %s", q.why_not.c_str());
+            prec = FF_PRECISION_EXACT64;
+        } else if (is_auto && !weighted && !q.lengths_exact) {
+            // The reference's unweighted value is what its two chains of additions round to (unifrac.go:144-171), and
+            // the bar for unweighted is its bits, not a tolerance: integer lengths that carry a rounding (any real
+            // phylogeny) cannot give them, pair_exact_unw_kernel does (C3's shape: 10 ms a pass against 0.3 on the
+            // matrix cores -- a thirtieth of what the command spends reading the table and writing the distances).
+            // FIXED32 on such lengths stays available on request: within 1e-6, with refinement and audit.
             prec = FF_PRECISION_EXACT64;
         } else {
             prec = FF_PRECISION_FIXED32;

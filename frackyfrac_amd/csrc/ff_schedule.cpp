@@ -28,6 +28,22 @@ void build_tiles(int64_t N, int64_t rb, int64_t re, int ti, int tj, bool allow_n
     }
 }
 
+void build_xu_tiles(int64_t N, int64_t rb, int64_t re, int jmax, std::vector<XUTile> *tiles)
+{
+    tiles->clear();
+    if (re <= rb) return;
+    for (int64_t i0 = rb / XU_TILE_H * XU_TILE_H; i0 < re; i0 += XU_TILE_H) {
+        const int64_t w = std::min<int64_t>(std::min<int64_t>(i0 + XU_TILE_H, re) - 1, N);  // valid columns: j < w
+        for (int64_t j0 = 0; j0 < w;) {
+            int g = jmax;
+            while (g > 1 && w - j0 <= 64 * g / 2) g /= 2;  // the narrowest tile that covers what is left of the row block
+            tiles->push_back({(int32_t)i0, (int32_t)j0, g, 0});
+            j0 += 64 * g;
+        }
+    }
+    std::stable_sort(tiles->begin(), tiles->end(), [](const XUTile &a, const XUTile &b) { return a.jn > b.jn; });
+}
+
 // FF_XCD_SLICES: number of branch slices the main rounds pin to groups of XCDs (2, 4 or 8 of
 // an MI355X's 8 XCDs; 0 = rounds that ignore the XCDs).  Default 2: measured at C3, fabric
 // traffic 6.6 -> 2.2 GB per launch at the same kernel time (4 and 8 move no fewer bytes and
@@ -563,7 +579,7 @@ int64_t build_mfma_schedule(int64_t N, int64_t row_begin, int64_t row_end, int64
 // row_end) of n_samples samples with `rows` staged branch rows on a device with n_cu compute
 // units.  kernel = FF_KERNEL_SAD_U32 or FF_KERNEL_MFMA_I8 (then `rows` is the slab count and
 // n_digits applies).  Items come back as 8 int32 each: SAD {i0, j0, k0, k1, flags, 0, 0, 0},
-// MFMA {i0, j0, k0, k1, d0, nd, first, 0}; item_ptr has one entry per wave slot (SAD: 8 per
+// MFMA {i0, j0, k0, k1, d0, nd, first, 0}, EXACT_F64_UNW (tiles) {i0, j0, jn, 0, ...}; item_ptr has one entry per wave slot (SAD: 8 per
 // CU) or workgroup (MFMA: one per CU) plus one.  Returns the number of items, or -needed if
 // max_items is too small.
 extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows, int64_t row_begin, int64_t row_end,
@@ -580,6 +596,20 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
         n = (int64_t)items.size();
         if (n > max_items) return -n;
         if (n) memcpy(items_out, items.data(), sizeof(MItem) * (size_t)n);
+    } else if (kernel == FF_KERNEL_EXACT_F64_UNW) {  // (n_digits: the widest tile in column groups; no item_ptr)
+        std::vector<XUTile> tiles;
+        build_xu_tiles(n_samples, row_begin, row_end, n_digits, &tiles);
+        if (n_tiles_out) *n_tiles_out = (int64_t)tiles.size();
+        n = (int64_t)tiles.size();
+        if (n > max_items) return -n;
+        for (int64_t q = 0; q < n; ++q) {
+            int32_t *o = items_out + 8 * q;
+            memset(o, 0, 8 * sizeof(int32_t));
+            o[0] = tiles[(size_t)q].i0;
+            o[1] = tiles[(size_t)q].j0;
+            o[2] = tiles[(size_t)q].jn;
+        }
+        return n;
     } else {
         std::vector<Tile> tiles;
         build_tiles(n_samples, row_begin, row_end, TILE_I, TILE_J, allow_narrow != 0, &tiles);
@@ -598,15 +628,17 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
 
 // Diagnostics / tests: the constants that tie the kernels' prefetch depths to the padding of the staged
 // arrays (ff_schedule.hpp), and the allocation sizes ff_device.hip derives from them for R staged rows.
-// out[0..15] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
+// out[0..23] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
 //               M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
-//               mfma_staged_slabs(R), mfma_alloc_slabs(R)}
+//               mfma_staged_slabs(R), mfma_alloc_slabs(R),
+//               XU_TILE_H, XU_SLAB, XU_JMAX, XU_LEN_STEP, xu_slabs(R), xu_alloc_slabs(R), xu_alloc_lengths(R), 0}
 extern "C" void ff_debug_layout(int64_t R, int64_t *out)
 {
     using namespace ff::sched;
-    const int64_t v[16] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
+    const int64_t v[24] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
                            M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
-                           mfma_staged_slabs(R), mfma_alloc_slabs(R)};
+                           mfma_staged_slabs(R), mfma_alloc_slabs(R),
+                           XU_TILE_H, XU_SLAB, XU_JMAX, XU_LEN_STEP, xu_slabs(R), xu_alloc_slabs(R), xu_alloc_lengths(R), 0};
     memcpy(out, v, sizeof v);
 }
 

@@ -2,6 +2,7 @@
 // (pure host C++: built with g++, unit-tested on CPU through ff_debug_schedule).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -59,6 +60,29 @@ static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
 struct XTile {
     int32_t i0, j0;
 };
+
+// ---- EXACT64 unweighted kernel (pair_exact_unw_kernel): presence bits, two chains of additions per pair ----
+constexpr int XU_TILE_H = 8;       // rows of a wave's tile (scalar side)
+constexpr int XU_SLAB = 32;        // staged rows per presence word
+constexpr int XU_JMAX = 2;         // 64-sample column groups of a tile: 1 or 2
+constexpr int XU_LEN_STEP = 8;     // lengths fetched at a time (one s_load_dwordx16)
+//   the kernel requests slab s + 1's words while it works on slab s: one slab past the end is read (zeros); the
+//   lengths are read in whole slabs
+constexpr int XU_PAD_SLABS = 1;
+constexpr int XU_LEN_PAD = 0;
+inline int64_t xu_slabs(int64_t R) { return (std::max<int64_t>(R, 1) + XU_SLAB - 1) / XU_SLAB; }
+inline int64_t xu_alloc_slabs(int64_t R) { return xu_slabs(R) + XU_PAD_SLABS; }
+inline int64_t xu_alloc_lengths(int64_t R) { return xu_slabs(R) * XU_SLAB + XU_LEN_PAD; }
+inline int64_t xu_ld(int64_t N) { return round_up(std::max<int64_t>(N, 1), 64 * XU_JMAX); }  // samples per slab row
+struct XUTile {
+    int32_t i0, j0;  // rows i0 .. i0 + XU_TILE_H - 1, columns j0 + 64 t + lane, t < jn
+    int32_t jn;      // 64-sample column groups: 1 or 2 (the last tile of a row block may be the narrower one)
+    int32_t pad;
+};
+static_assert(sizeof(XUTile) == 16, "XUTile must be 16 bytes");
+// The tiles of rows [rb, re), widest first (the hardware hands them out in this order); jmax = 1: single groups only
+// (a shard of few tiles is bound by one wave's chain of steps: narrower tiles, more waves).
+void build_xu_tiles(int64_t N, int64_t rb, int64_t re, int jmax, std::vector<XUTile> *tiles);
 
 
 // ---- int8 MFMA kernel (pair_common_mfma_kernel) ----

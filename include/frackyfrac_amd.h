@@ -66,8 +66,11 @@ typedef struct ff_problem {
 
 /* How the pairwise sums are carried on the device (DESIGN.md "Arithmetic"). */
 typedef enum ff_precision {
-    FF_PRECISION_AUTO = 0,    /* EXACT64 when pairs*branches <= 2^32 (about a millisecond) or
-                                 when FIXED32 is not applicable, else FIXED32                 */
+    FF_PRECISION_AUTO = 0,    /* EXACT64 when pairs*branches <= 2^32 (about a millisecond), when
+                                 FIXED32 is not applicable, and for UNWEIGHTED whenever a branch
+                                 length is off the binary grid FIXED32 would need (any real
+                                 phylogeny): unweighted results are then the reference's bits;
+                                 else FIXED32                                                  */
     FF_PRECISION_FIXED32 = 1, /* 32-bit fixed point, integer sums: order-independent, exact
                                  for unweighted whenever all branch lengths are k * 2^-e,
                                  else within 1e-6 relative (per-branch shared rounding offset,
@@ -76,7 +79,9 @@ typedef enum ff_precision {
                                  weighted runs on the vector ALU (v_sad_u32), unweighted on
                                  the int8 matrix cores (same integers, same results)          */
     FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
-                                 the reference for any finite input; about 6x slower          */
+                                 the reference for any finite input; weighted about 6x slower
+                                 than FIXED32, unweighted about 2x slower than the vector-ALU
+                                 FIXED32 path (40x slower than the matrix cores)              */
 } ff_precision;
 
 typedef struct ff_options {
@@ -194,8 +199,11 @@ typedef enum ff_kernel {
     FF_KERNEL_MFMA_I8 = 2,   /* pair_common_mfma_kernel: FIXED32 unweighted, int8 matrix cores     */
     FF_KERNEL_SAD_U32_SPARSE = 3, /* pair_sad_sparse_kernel: as SAD_U32, skipping branch rows on which
                                      none of a tile's 32 samples has a flat node (sparse tables)   */
-    FF_KERNEL_MFMA_I8_SMALL = 4   /* pair_common_small_kernel: as MFMA_I8 for a shard smaller than one round
+    FF_KERNEL_MFMA_I8_SMALL = 4,  /* pair_common_small_kernel: as MFMA_I8 for a shard smaller than one round
                                      of it (few hundred samples): 32 x 32 tiles, one launch per pass     */
+    FF_KERNEL_EXACT_F64_UNW = 5   /* pair_exact_unw_kernel: EXACT64 unweighted from presence bits -- the
+                                     reference's two chains of binary64 additions per pair and no other
+                                     arithmetic (unifrac.go:144-171)                                      */
 } ff_kernel;
 
 /* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM

@@ -193,10 +193,11 @@ def layout(R):
     fn = L.lib().ff_debug_layout
     fn.restype = None
     fn.argtypes = [ctypes.c_int64, ctypes.c_void_p]
-    v = np.zeros(16, dtype=np.int64)
+    v = np.zeros(24, dtype=np.int64)
     fn(R, v.ctypes.data)
     names = ("TILE_I TILE_J KSTEP SLACK_ROWS SAD_ROWS_AHEAD SPARSE_LIST_AHEAD SPARSE_LIST_PAD M_KSLAB M_QUAD_SLABS "
-             "M_PAIRS_IN_FLIGHT M_PAD_SLABS X_VALUES_PAD sad_staged_rows sad_alloc_rows mfma_staged_slabs mfma_alloc_slabs")
+             "M_PAIRS_IN_FLIGHT M_PAD_SLABS X_VALUES_PAD sad_staged_rows sad_alloc_rows mfma_staged_slabs mfma_alloc_slabs "
+             "XU_TILE_H XU_SLAB XU_JMAX XU_LEN_STEP xu_slabs xu_alloc_slabs xu_alloc_lengths _")
     return dict(zip(names.split(), (int(x) for x in v)))
 
 
@@ -314,6 +315,55 @@ def test_exact64_operands_past_the_last_row_are_padded():
             ld = (n + 63) // 64 * 64
             i0_max = (n - 1) // h * h          # build_tiles: i0 = multiples of h below the shard's end
             assert i0_max + h - 1 < ld + lay["X_VALUES_PAD"]
+
+
+def xu_tiles(n, rb, re, jmax):
+    fn = L.lib().ff_debug_schedule
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    cap = 1 << 20
+    items = np.zeros((cap, 8), dtype=np.int32)
+    nt = ctypes.c_int64()
+    k = fn(5, n, 0, rb, re, 256, jmax, 0, items.ctypes.data, cap, None, ctypes.byref(nt))   # FF_KERNEL_EXACT_F64_UNW
+    assert k >= 0 and k == nt.value
+    return items[:k, :3]
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 63, 64, 65, 129, 200, 1000, 4096])
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("jmax", [1, 2])
+def test_exact_unw_tiles_cover_the_shard_once_and_stay_inside_the_staged_words(n, world, jmax):
+    """pair_exact_unw_kernel: every pair (i, j < i) of the shard's rows lies in exactly one tile; a tile's column
+    words (64 jn lanes from j0) and its eight row words (from i0) lie inside a slab row of xu_ld(N) samples; the widest
+    tiles come first; and what the kernel requests ahead -- slab s + 1's words during slab s -- lies inside the
+    padding (XU_PAD_SLABS: ff_schedule.hpp), the lengths it reads in whole slabs inside theirs."""
+    lay = layout(1000)
+    H, slab, step = lay["XU_TILE_H"], lay["XU_SLAB"], lay["XU_LEN_STEP"]
+    ld = (max(n, 1) + 64 * lay["XU_JMAX"] - 1) // (64 * lay["XU_JMAX"]) * (64 * lay["XU_JMAX"])
+    seen = np.zeros((n, n), dtype=np.int32)
+    for rank in range(world):
+        rb, re = ff.shard_rows(n, rank, world)
+        tiles = xu_tiles(n, rb, re, jmax)
+        assert all(a >= b for a, b in zip(tiles[:, 2], tiles[1:, 2]))           # widest first
+        for i0, j0, jn in tiles:
+            assert jn in (1, 2) and jn <= jmax and i0 % H == 0 and j0 % 64 == 0
+            assert j0 + 64 * jn <= ld and i0 + H <= ld                           # one slab row holds what a wave reads of it
+            for i in range(max(i0, rb), min(i0 + H, re)):
+                hi = min(j0 + 64 * jn, i)
+                if hi > j0:
+                    seen[i, j0:hi] += 1
+    want = np.tril(np.ones((n, n), dtype=np.int32), -1)
+    assert np.array_equal(seen, want)
+    for R in (1, 31, 32, 33, 1000, 19999):
+        lay = layout(R)
+        n_slabs = lay["xu_slabs"]
+        assert n_slabs * slab >= R > (n_slabs - 1) * slab
+        # the loop: for s < n_slabs request slab s + 1; per step the lengths [32 s + k0, 32 s + k0 + step)
+        hi_slab = max(s + 1 for s in range(n_slabs))
+        hi_len = max(s * slab + k0 + step - 1 for s in range(n_slabs) for k0 in range(0, slab, step))
+        assert hi_slab == n_slabs                                                # (the model sees the over-read)
+        assert hi_slab < lay["xu_alloc_slabs"] and hi_len < lay["xu_alloc_lengths"]
 
 
 def test_row_shards_of_a_multi_gpu_run_take_xcd_sliced_rounds(monkeypatch):
