@@ -13,16 +13,20 @@ N > 1: one rank per GPU under torch.distributed.run.  Started WITHOUT that launc
 (`python bench.py --gpus 8 ...`, the way the N = 1 run is started) this process launches
 it itself: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
 child BEFORE importing torch or touching HIP, relays rank 0's JSON line and exit code, and
-never uses the GPU.  The primary line scales WEAKLY by default (samples = 4096*sqrt(N), so
-every GPU keeps C3's pair count; `--scaling strong` keeps 4096 samples); `value` is all
-ranks' pairs / max-over-ranks time.
+never uses the GPU.  With nothing else asked for the N > 1 line leads with BASELINE configs[3]
+-- C4, 16,384 samples, pair tiles sharded over the N GPUs: strong scaling by construction --
+and carries the weak-scaled C3 (samples = 4096*sqrt(N), every GPU keeps C3's pair count) beside
+it as `weak_scaling`; `--scaling weak|strong` with a `--workload` runs just that.  `value` is
+all ranks' pairs / max-over-ranks time.
 
 `secondary` carries the other claimed numbers under the same clock, each with its own
 `config.workload`, `dtype`, `ms_per_step` and `roofline`:
-  N = 1: C3 in EXACT64 (the reference's binary64 roundings), C3 unweighted (int8 matrix
-         cores), C2 (BASELINE configs[1]), C4 and C5 on one GPU;
-  N > 1: BASELINE configs[3] and [4] -- C4 and C5 at their stated sizes, row shards over
-         the N GPUs (strong by construction), with the gather transport that ran.
+  N = 1: C3 in EXACT64 (the reference's binary64 roundings; also `reference_width` of the
+         primary record), C3 unweighted (int8 matrix cores), C2 (BASELINE configs[1]), C4 and
+         C5 on one GPU, C3 unweighted with log-normal branch lengths on request (fixed32,
+         graded digit planes) and as the engine runs it by itself (EXACT64, the reference's bits);
+  N > 1: BASELINE configs[4] -- C5 at its stated size, row shards over the N GPUs -- with the
+         gather transport that ran.
 
 Prints ONE JSON line on rank 0; `roofline` describes the dominant kernel, timed with HIP
 events around every launch of the timed region on the stream it is launched on
@@ -47,6 +51,7 @@ import numpy as np  # noqa: E402
 
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
 HBM_PEAK_GBPS = 8000.0            # HBM3E spec
+HBM_COPY_GBPS = 6290.0            # measured copy ceiling (same guide)
 VALU_PEAK_TLANEOPS = 78.65        # 157.3 TFLOP/s FP32 vector / 2 flops per lane-op
 MFMA_I8_PEAK_TOPS = 5000.0        # int8 MFMA issues at 2x the dense bf16 rate (~2.5 PFLOP/s)
 
@@ -195,6 +200,7 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     """Roofline of the dominant kernel from the ALGORITHMIC work of one launch."""
     from frackyfrac_amd._lib import KERNEL_NAMES
 
+    kernel = int(info.kernel)
     elem_bytes = 4 if info.precision == 1 else 8
     # per pair 8 + (elem*N*B + 4*B + 4*N)/P bytes: one f64 result + the pair's share of one
     # compulsory read of the staged matrix, lengths and row sums
@@ -202,29 +208,50 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     sec = max(kernel_ms, 1e-9) * 1e-3
     hbm = {"bound": "hbm", "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
-    kname = KERNEL_NAMES[int(info.kernel)]
-    if info.kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
+    if traffic and traffic.get("traffic"):
+        # what the counters saw move (2*FETCH_SIZE + WRITE_SIZE of the profiled build, per launch) over THIS run's
+        # kernel time: the rocprof-reported rate SURVEY 8(d) asks for, against the spec and the measured-copy ceiling
+        gbps = traffic["traffic"] / sec / 1e9
+        hbm["measured_GBps"] = gbps
+        hbm["measured_frac_of_8000"] = gbps / HBM_PEAK_GBPS
+        hbm["measured_frac_of_6290"] = gbps / HBM_COPY_GBPS
+        hbm["traffic_ratio"] = traffic["traffic"] / alg_bytes   # counter bytes / algorithmic bytes: re-reads
+    kname = KERNEL_NAMES[kernel]
+    if kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
         kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,072 samples)
     common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
-    # the binding floor of THIS launch (one rank's shard): its algorithmic work at the unit's peak
-    peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2}.get(int(info.kernel), VALU_PEAK_TLANEOPS) * 1e12
-    common["floor_ms"] = (6.0 if info.kernel == 1 else 2.0) * B * shard_pairs / peak_ops * 1e3
+    # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
+    peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2,
+                5: VALU_PEAK_TLANEOPS / 2}.get(kernel, VALU_PEAK_TLANEOPS) * 1e12
+    common["floor_ms"] = 2.0 * B * shard_pairs / peak_ops * 1e3
     common.update(traffic or {"traffic": None})
-    if info.kernel in (2, 4):
+    if kernel in (2, 4):
         # unweighted on the matrix cores: one multiply-add per branch and pair is the
         # algorithmic work (the base-128 digit passes are the implementation's)
         achieved = 2.0 * B * shard_pairs / sec / 1e12
         return dict({"bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                      "frac": achieved / MFMA_I8_PEAK_TOPS, "digits": int(info.n_digits),
                      "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs)}, **common)
-    if info.kernel == 1:
-        # EXACT64: the reference's roundings need six unfused binary64 operations per branch and
-        # pair (numer: sub, mul by |.|, add; denom: add, mul, add; unifrac.go:191-192); the FP64
-        # vector rate is half the FP32 one (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s)
-        achieved = 6.0 * B * shard_pairs / sec / 1e12
-        return dict({"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS / 2, "unit": "T f64 op/s",
-                     "frac": achieved / (VALU_PEAK_TLANEOPS / 2),
-                     "algorithmic": "6*B unfused binary64 ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs)},
+    if kernel == 1:
+        # EXACT64 weighted.  SURVEY 8(d) prices the f64 variant like the f32 one: 2*B lane-ops per pair, at the FP64
+        # vector peak (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s) -> `frac`.  The reference's ROUNDINGS need
+        # six unfused binary64 operations per branch and pair (numer: sub, mul by |.|, add; denom: add, mul, add;
+        # unifrac.go:191-192), which no bit-exact kernel can go under -> `frac_unfused6`, the builder's count.
+        peak = VALU_PEAK_TLANEOPS / 2
+        achieved = 2.0 * B * shard_pairs / sec / 1e12
+        return dict({"bound": "valu", "achieved": achieved, "peak": peak, "unit": "T f64 op/s", "frac": achieved / peak,
+                     "achieved_unfused6": 3.0 * achieved, "frac_unfused6": 3.0 * achieved / peak,
+                     "algorithmic": "2*B binary64 lane-ops per pair (SURVEY 8d; frac_unfused6: the 6*B unfused operations "
+                                    "the reference's roundings need), B=%d, %d pairs per launch" % (B, shard_pairs)},
+                    **common)
+    if kernel == 5:
+        # EXACT64 unweighted: the reference's two running sums are two binary64 ADDITIONS per branch and pair
+        # (result or common, unifrac.go:151-167) -- 2*B per pair at the FP64 vector rate.  The kernel issues fewer
+        # (a branch a row has not adds to one sum only) plus 5/8 of an instruction per term to prepare operands.
+        peak = VALU_PEAK_TLANEOPS / 2
+        achieved = 2.0 * B * shard_pairs / sec / 1e12
+        return dict({"bound": "valu", "achieved": achieved, "peak": peak, "unit": "T f64 add/s", "frac": achieved / peak,
+                     "algorithmic": "2*B binary64 additions per pair (SURVEY 8d), B=%d, %d pairs per launch" % (B, shard_pairs)},
                     **common)
     achieved = 2.0 * B * shard_pairs / sec / 1e12
     return dict({"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
@@ -320,7 +347,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
         n_audit, bad, worst = run.plan.audit()
         entry = {"value": P / (elapsed / steps), "unit": "pairs/s", "steps": steps, "warmup": warmup,
                  "ms_per_step": elapsed / steps * 1e3,
-                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8"}[int(info.kernel)],
+                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8", 5: "f64"}[int(info.kernel)],
                  "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
                                         "leaf density %.2f, seed 0x%X%s" %
                                         (cfg["name"], n_samples, cfg["n_leaves"], B,
@@ -353,8 +380,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", help="C2|C3|C4|C5 or SAMPLESxLEAVES (e.g. 2048x5000)")
     ap.add_argument("--precision", default="fixed32", choices=["auto", "fixed32", "exact64"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = samples grow as sqrt(N) (per-GPU pairs fixed), strong = the workload's own size")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: weak = samples grow as sqrt(N) (per-GPU pairs fixed), strong = the workload's own size; "
+                         "not given (and the default workload): BASELINE configs[3] -- C4, 16,384 samples, pair tiles over "
+                         "the N GPUs, strong by construction -- as the primary line and the weak-scaled C3 beside it")
     ap.add_argument("--unweighted", action="store_true")
     ap.add_argument("--lengths", default="generator", choices=["generator", "lognormal"],
                     help="branch lengths: the generator's multiples of 1/1024, or log-normal (sigma 1.5)")
@@ -399,12 +428,20 @@ def main():
     # ---- primary: BASELINE's metric on its configuration --------------------------------
     from frackyfrac_amd import synth
 
+    # N > 1 with nothing asked for: the line leads with a BASELINE config -- configs[3], C4 at its stated size, its pair
+    # tiles sharded over the N GPUs (strong scaling by construction; the N = 1 point of the same curve is C3, whose pairs
+    # cost the same: same tree) -- and carries the weak-scaled C3 (samples = 4096 sqrt(N): every GPU keeps C3's pair
+    # count, the regime in which the gather is easiest to hide) beside it as `weak_scaling`.
+    lead_c4 = (world > 1 and args.scaling is None and args.workload == "C3" and not args.unweighted and
+               args.precision == "fixed32" and args.lengths == "generator")
+    scaling = "strong" if lead_c4 else (args.scaling or "weak")
+    workload = "C4" if lead_c4 else args.workload
     n_override = None
-    if world > 1 and args.scaling == "weak" and args.workload in synth.CONFIGS:
-        n_override = int(round(synth.CONFIGS[args.workload]["n_samples"] * math.sqrt(world) / 32.0)) * 32
-    elif world > 1 and args.scaling == "weak":
-        n_override = int(round(int(args.workload.lower().split("x")[0]) * math.sqrt(world) / 32.0)) * 32
-    cfg, nodes = make_problem(ctx, args.workload, n_override)
+    if world > 1 and scaling == "weak" and workload in synth.CONFIGS:
+        n_override = int(round(synth.CONFIGS[workload]["n_samples"] * math.sqrt(world) / 32.0)) * 32
+    elif world > 1 and scaling == "weak":
+        n_override = int(round(int(workload.lower().split("x")[0]) * math.sqrt(world) / 32.0)) * 32
+    cfg, nodes = make_problem(ctx, workload, n_override)
     weighted = cfg["weighted"] and not args.unweighted
     if args.lengths == "lognormal":
         nodes = with_lognormal_lengths(cfg, nodes)
@@ -412,6 +449,14 @@ def main():
     # (steps of a few microseconds -- the unweighted matrix-core kernels -- carry the event pair on every 8th launch)
     primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup,
                       event_every=1 if weighted or args.precision == "exact64" else 8)
+    weak_entry = None
+    if lead_c4:
+        del nodes
+        n_weak = int(round(synth.CONFIGS["C3"]["n_samples"] * math.sqrt(world) / 32.0)) * 32
+        cfg_w, nodes = make_problem(ctx, "C3", n_weak)
+        weak_entry = measure(ctx, cfg_w, nodes, True, "fixed32", args.steps, args.warmup)
+        if rank == 0:
+            weak_entry["scaling"] = "weak"
 
     e2e = None
     if rank == 0 and world == 1 and args.end_to_end:
@@ -432,12 +477,17 @@ def main():
                          if cfg["name"] == "C3" and weighted else "sample-pairs/sec (lower triangle)",
                "value": primary["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": primary["ms_per_step"], "higher_is_better": True,
-               "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": primary["dtype"],
+               "scaling": scaling if world > 1 else "weak", "vs_baseline": None, "dtype": primary["dtype"],
                "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, not a measurement)" if ctx.rehearse else ""),
                "config": primary["config"], "roofline": primary["roofline"]}
         for k in ("audit", "gather", "ranks"):
             if k in primary:
                 out[k] = primary[k]
+        if weak_entry is not None:
+            out["weak_scaling"] = weak_entry
+            out["scaling_note"] = ("N > 1: value = BASELINE configs[3] (C4, 16,384 samples) over the N GPUs, total work fixed; the "
+                                   "N = 1 point is BASELINE's headline C3 (4,096 samples, same tree: the same cost per pair); "
+                                   "weak_scaling = C3 grown to 4096*sqrt(N) samples, per-GPU pairs fixed")
         if e2e is not None:
             out["host_buffers_ms"] = e2e * 1e3  # PCIe-inclusive, informational
         if world == 1 and not args.no_cpu_baseline:
@@ -445,29 +495,38 @@ def main():
 
     # ---- secondary: the other claimed numbers, same clock ------------------------------------
     if (not args.no_secondary and args.workload == "C3" and not args.unweighted and args.precision == "fixed32" and
-            args.lengths == "generator"):
+            args.lengths == "generator" and (world == 1 or lead_c4)):
         sec = []
         k, w = max(1, min(args.secondary_steps, args.steps)), 1
         if world == 1:
             sec.append(measure(ctx, cfg, nodes, True, "exact64", k, w))       # the reference-width figure
             sec.append(measure(ctx, cfg, nodes, False, "fixed32", max(k, args.steps), w, event_every=8))  # int8 matrix cores
             # the same with branch lengths as a real phylogeny has them -- not short binary fractions but spread over
-            # orders of magnitude (log-normal, sigma 1.5; the root's stays 0): the integer lengths then take the 31-bit
-            # budget, and the matrix-core sweep multiplies graded digit planes
-            ln = measure(ctx, dict(cfg, lengths="lognormal"), with_lognormal_lengths(cfg, nodes), False, "fixed32",
-                         max(k, args.steps), w, event_every=8)
-            del nodes
+            # orders of magnitude (log-normal, sigma 1.5; the root's stays 0).  What the engine does BY ITSELF with them
+            # (precision auto): EXACT64 on pair_exact_unw_kernel, the reference's bits.  On request (fixed32): the
+            # integer lengths take the 31-bit budget and the matrix-core sweep multiplies graded digit planes (DESIGN
+            # 4.2), within 1e-6.
+            nodes_ln = with_lognormal_lengths(cfg, nodes)
+            ln = measure(ctx, dict(cfg, lengths="lognormal"), nodes_ln, False, "fixed32", max(k, args.steps), w, event_every=8)
+            lx = measure(ctx, dict(cfg, lengths="lognormal"), nodes_ln, False, "auto", k, w)
+            del nodes, nodes_ln
             for wl, wtd, steps, every in (("C2", False, max(k, args.steps), 8), ("C4", True, k, 1), ("C5", True, k, 1)):
                 c2, n2 = make_problem(ctx, wl)
                 sec.append(measure(ctx, c2, n2, wtd, "fixed32", steps, w, event_every=every))
                 del n2
             sec.append(ln)  # (last: the entries before it keep the places they had in earlier rounds' lines)
+            sec.append(lx)
+            if rank == 0:
+                # the reference's width next to the headline's: binary64 in the reference's own order of operations
+                # (EXACT64), same inputs, same clock -- in the primary record, not only among the secondary ones
+                out["reference_width"] = {kk: sec[0][kk] for kk in ("dtype", "value", "unit", "ms_per_step", "steps", "roofline")}
+                out["reference_width"]["note"] = ("the headline is 32-bit fixed point (within 1e-6 of the reference, refined + audited); "
+                                                  "this is the same workload bit for bit with the reference (FF_PRECISION_EXACT64)")
         else:
             del nodes
-            for wl in ("C4", "C5"):     # BASELINE configs[3], [4] at their stated sizes over the N GPUs
-                c2, n2 = make_problem(ctx, wl)
-                sec.append(measure(ctx, c2, n2, True, "fixed32", k, w))
-                del n2
+            c2, n2 = make_problem(ctx, "C5")    # BASELINE configs[4] at its stated size over the N GPUs
+            sec.append(measure(ctx, c2, n2, True, "fixed32", k, w))
+            del n2
         if rank == 0:
             out["secondary"] = sec
     if rank == 0:

@@ -60,13 +60,25 @@ def test_single_gpu_line_carries_the_secondary_entries():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1
     sec = out["secondary"]
-    assert [e["config"]["workload"].split(":")[0] for e in sec] == ["C3", "C3", "C2", "C4", "C5", "C3"]
-    assert [e["dtype"] for e in sec] == ["f64", "i8", "i8", "u32", "u32", "i8"]
+    assert [e["config"]["workload"].split(":")[0] for e in sec] == ["C3", "C3", "C2", "C4", "C5", "C3", "C3"]
+    assert [e["dtype"] for e in sec] == ["f64", "i8", "i8", "u32", "u32", "i8", "f64"]
     # the last one: C3 unweighted with log-normal branch lengths -- graded digit planes on the matrix cores, the
     # run-time audit against binary64 in play (lengths off the binary grid), every audited pair inside the bar
     assert "log-normal" in sec[5]["config"]["workload"] and sec[5]["roofline"]["kernel"] == "pair_common_mfma_kernel"
     assert sec[5]["audit"]["failed"] == 0 and sec[5]["audit"]["worst_rel_err"] <= 5e-7
-    assert sec[1]["ms_per_step"] < sec[5]["ms_per_step"] < 2.0 * sec[1]["ms_per_step"]   # (two sweeps cost 1.85 x)
+    # ... and what the engine does with such lengths when nobody asks for fixed32: the reference's bits, on
+    # pair_exact_unw_kernel, priced at two binary64 additions per branch and pair
+    assert "log-normal" in sec[6]["config"]["workload"] and sec[6]["config"]["precision"] == "exact64"
+    assert sec[6]["roofline"]["kernel"] == "pair_exact_unw_kernel" and "audit" not in sec[6]
+    # the reference-width figure sits in the primary record too, with both operation counts
+    rw = out["reference_width"]
+    assert rw["dtype"] == "f64" and rw["value"] == sec[0]["value"] and rw["roofline"]["kernel"] == "pair_exact64_kernel"
+    assert abs(rw["roofline"]["frac_unfused6"] - 3.0 * rw["roofline"]["frac"]) < 1e-9
+    # the rocprof-reported rate: counter bytes of the profiled build over this run's kernel time
+    hbm = out["roofline"]["hbm"]
+    if out["roofline"]["traffic"]:
+        assert hbm["measured_GBps"] > hbm["achieved"] and 0 < hbm["measured_frac_of_8000"] < hbm["measured_frac_of_6290"] < 1
+        assert hbm["traffic_ratio"] > 1.0
     assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_kernel"
     assert sec[1]["roofline"]["bound"] == "mfma" and "unweighted" in sec[1]["config"]["workload"]
     assert sec[1]["roofline"]["kernel"] == "pair_common_mfma_kernel" and sec[2]["roofline"]["kernel"] == "pair_common_small_kernel"
@@ -75,14 +87,29 @@ def test_single_gpu_line_carries_the_secondary_entries():
         assert e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < 1.0
 
 
-def test_c2_pass_is_one_launch_of_a_few_microseconds():
+def test_c2_pass_is_one_launch():
     """BASELINE configs[1] (512 samples x 2k-leaf tree, unweighted): the small-shard matrix-core kernel does the pair
-    reduction, the sum over branch ranges and the division in one launch -- 25 us per pass of two launches in round 2,
-    under 10 now (6-7 us measured; the bar of round 2's VERDICT).  Steps this short are timed with an event pair
-    around every 8th launch."""
+    reduction, the sum over branch ranges and the division in ONE launch (two in round 2).  Steps this short are timed
+    with an event pair around every 8th launch.  How many microseconds a pass takes is asserted in test_gpu_perf.py
+    (`-m perf`), not here: a slower-clocked box must not be able to fail the parity gate."""
     out, _ = run_bench("--workload", "C2", "--steps", "400", "--warmup", "20", "--no-cpu-baseline", "--no-secondary")
     assert out["config"]["workload"].startswith("C2:") and out["dtype"] == "i8" and out["config"]["pairs"] == 130816
     assert out["roofline"]["kernel"] == "pair_common_small_kernel" and out["roofline"]["bound"] == "mfma"
-    assert out["ms_per_step"] <= 0.010, out["ms_per_step"]
     assert out["roofline"]["timed_every"] == 8 and out["roofline"]["launches"] == 50
-    assert 0 < out["roofline"]["kernel_ms"] <= out["ms_per_step"] <= out["roofline"]["kernel_ms_between_events"] + 0.005
+    assert 0 < out["roofline"]["kernel_ms"] <= out["ms_per_step"]
+
+
+def test_default_multi_gpu_line_leads_with_c4_strong_and_carries_the_weak_one():
+    """`python bench.py --gpus N` as the driver starts it (no --scaling, no --workload): the line leads with BASELINE
+    configs[3] -- C4 at its stated size, pair tiles over the N ranks, "scaling": "strong" -- and carries the
+    weak-scaled C3 beside it; C5 is the secondary entry.  Rehearsed with two ranks on the one GPU."""
+    out, _ = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--secondary-steps", "1",
+                       "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["workload"].startswith("C4:") and out["config"]["pairs"] == 16384 * 16383 // 2
+    assert sum(r["pairs"] for r in out["ranks"]) == 16384 * 16383 // 2
+    assert 0 < out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"]
+    weak = out["weak_scaling"]
+    assert weak["scaling"] == "weak" and weak["config"]["workload"].startswith("C3:") and weak["config"]["pairs"] == 5792 * 5791 // 2
+    assert [r["rank"] for r in weak["ranks"]] == [0, 1] and "C3" in out["scaling_note"]
+    assert [e["config"]["workload"].split(":")[0] for e in out["secondary"]] == ["C5"]

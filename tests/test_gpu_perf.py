@@ -1,0 +1,23 @@
+"""Wall-clock bounds, kept OUT of the parity gate: collected only by `pytest -m perf` on an MI355X
+(tests/conftest.py deselects them under every other selection).  The numbers of record are the driver's
+BENCH_r*.json and the rocprofv3 summaries under profiles/; these bounds are tripwires an order of magnitude out of
+the way of clock-speed differences between boxes (C2: 6.9 us on one box, 8.6 on the driver's)."""
+import pytest
+
+from test_gpu_bench import run_bench
+
+pytestmark = pytest.mark.perf
+
+
+def test_c2_pass_takes_microseconds_not_tens_of_them():
+    """25 us per pass of two launches in round 2; 6.2-8.6 us measured since round 3 (one launch)."""
+    out, _ = run_bench("--workload", "C2", "--steps", "400", "--warmup", "20", "--no-cpu-baseline", "--no-secondary")
+    assert out["ms_per_step"] <= 0.020, out["ms_per_step"]
+    assert out["ms_per_step"] <= out["roofline"]["kernel_ms_between_events"] + 0.005
+
+
+def test_graded_planes_cost_less_than_two_sweeps_and_exact_unweighted_a_third_of_the_weighted_walk():
+    out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--no-cpu-baseline")
+    sec = out["secondary"]
+    assert sec[1]["ms_per_step"] < sec[5]["ms_per_step"] < 2.0 * sec[1]["ms_per_step"]   # (two sweeps cost 1.85 x)
+    assert sec[6]["ms_per_step"] < 0.5 * sec[0]["ms_per_step"]       # pair_exact_unw_kernel 10 ms, pair_exact64_kernel 30
