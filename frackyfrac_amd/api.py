@@ -283,10 +283,19 @@ def unifrac_dists_stream(nodes: FlatNodes, weighted: bool, precision="auto", dev
 
     pieces: "queue.Queue" = queue.Queue(maxsize=1)
     resume = threading.Semaphore(0)
-    state = {"stop": False}
+    state = {"stop": False, "error": None, "delivered": 0}
 
     def on_piece(_user, slot_begin, dists, n):
-        pieces.put((int(slot_begin), np.ctypeslib.as_array(dists, shape=(int(n),)).copy()))
+        # An exception that leaves a ctypes callback is printed and SWALLOWED, and the callback then returns 0 --
+        # "the consumer stopped" to the C side, which ends with FF_OK: a truncated sequence that looks complete.
+        # So nothing may leave: what goes wrong here (MemoryError on the copy of a 256 MB piece) is kept for the
+        # consumer, and 0 stops the computation.
+        try:
+            pieces.put((int(slot_begin), np.ctypeslib.as_array(dists, shape=(int(n),)).copy()))
+            state["delivered"] += int(n)
+        except BaseException as e:  # noqa: BLE001
+            state["error"] = e
+            return 0
         resume.acquire()
         return 0 if state["stop"] else 1
 
@@ -313,9 +322,15 @@ def unifrac_dists_stream(nodes: FlatNodes, weighted: bool, precision="auto", dev
         while True:
             item = pieces.get()
             if item[0] == "done":
+                if state["error"] is not None:
+                    raise state["error"]
                 if isinstance(item[1], BaseException):
                     raise item[1]
                 L.check(item[1], err)
+                a, b = shard_slots(nodes.n_samples, rank, world)
+                if state["delivered"] != b - a:   # (the consumer did not stop, no error: every slot must have come)
+                    raise RuntimeError("ff_unifrac_dists_stream delivered %d of the shard's %d distances"
+                                       % (state["delivered"], b - a))
                 return
             yield item
             resume.release()

@@ -1152,6 +1152,7 @@ struct StageCtx {
     int64_t R = 0;                       // staged rows: B, or the branches in use (compaction)
     Scratch<int32_t> row_of;             // branch id -> staged row (null: identity)
     std::vector<int32_t> branch_of_row;  // staged row -> branch id (empty: identity)
+    std::vector<unsigned char> branch_used;  // [B] 1: some sample has a flat node on the branch (empty: not known)
     Quant q;
 };
 
@@ -1195,6 +1196,7 @@ int compact_branches(StageCtx &x, char *err, size_t errlen)
         FF_HIP(hipMemcpy(hm.data(), mark.p, (size_t)B, hipMemcpyDeviceToHost));
         int64_t used = 0;
         for (unsigned char m : hm) used += m;
+        x.branch_used = hm;
         if (used * 10 <= B * 9) {
             h_row_of.assign((size_t)B, 0);
             branch_of_row.reserve((size_t)used);
@@ -1220,6 +1222,12 @@ int stage_for_mfma(StageCtx &x, char *err, size_t errlen)
     inf.kernel = FF_KERNEL_MFMA_I8;
     inf.lengths_exact = q.lengths_exact;
     inf.scale_log2 = q.e;
+    // A branch no sample has a flat node on multiplies presence bits that are all zero: its integer length is never
+    // used (choose_quant only keeps it in range, up to 2^31), so it must not decide the digits of the sweep or be cut
+    // into hundreds of all-zero rows when fewer than a tenth of the branches are like that and the rows stay as they are.
+    if (!x.branch_used.empty())
+        for (int64_t b = 0; b < B; ++b)
+            if (!x.branch_used[(size_t)b]) q.klen[(size_t)b] = 0;
     uint32_t kmax = 0;
     for (uint32_t k : q.klen) kmax = std::max(kmax, k);
     auto digits_of = [](uint32_t k) {

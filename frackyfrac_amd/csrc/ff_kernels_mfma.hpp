@@ -53,7 +53,9 @@ static_assert(M_PAIRS_IN_FLIGHT == 4 && M_QUAD_SLABS == 4, "pair_common_mfma_ker
 // loads per pair of slabs, two lanes per address); 0: one row per lane (three loads) and a
 // v_permlane32_swap per word and k-step to bring them there.
 constexpr bool M_DIRECT_WORDS = FF_MFMA_DIRECT_WORDS != 0;
-constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time (128 bytes each: 64 KiB)
+constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time: 64 bytes per plane and slab -- 64 KiB with two
+                                    // planes, 96 KiB with the graded sweep's three; a segment's last k-step reads one slab
+                                    // past its table (static_assert in the kernel: inside the 128 KiB either way)
 
 // Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,
 // 65,536 branch rows at a time, and stores it slab by slab.  Also W_s = sum of the sample's
@@ -180,6 +182,9 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
         const uint4 *pa = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.i0 + wi * 128 + wlane;
         const uint4 *pb = Pbits + (int64_t)(item.k0 / (2 * M_KSLAB)) * n8 + item.j0 + wj * 64 + wlane;
         constexpr int NPL = TRI ? 3 : 2;  // digit planes of a slab in the LDS table
+        // the table of a segment, plus the slab past it that the last k-step's read-ahead touches (read_digits(.., + 2)
+        // / read_digits3(+ 1): never used), must lie inside the workgroup's LDS (the epilogue's tile sizes it)
+        static_assert((M_TABLE_SLABS + 1) * NPL * M_KSLAB <= M_LDS_BYTES, "pair_common_mfma_kernel: digit table + read-ahead past LDS");
         const int8_t *dig_src[3] = {Kd + (int64_t)item.d0 * ldb + item.k0,
                                     Kd + (int64_t)(item.d0 + (nd > 1 ? 1 : 0)) * ldb + item.k0,
                                     Kd + (int64_t)(TRI ? 2 : 0) * ldb + item.k0};  // (TRI: Kd = the three signed planes, d0 = 0)

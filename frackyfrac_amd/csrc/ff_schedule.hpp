@@ -117,8 +117,9 @@ inline void tri_digits(int64_t k, int8_t out[3])
     out[1] = (int8_t)(-d1);
     out[2] = (int8_t)((q1 - d1) >> 8);
 }
-constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB, ff_kernels_mfma.hpp
-                                                      // M_TABLE_SLABS), then the epilogue's 256 x 128 tile of 32-bit sums
+constexpr int M_LDS_BYTES = M_TILE_I * M_TILE_J * 4;  // 128 KiB: the digit table of up to 512 slabs (64 KiB with two planes, 96
+                                                      // with three: ff_kernels_mfma.hpp M_TABLE_SLABS), then the epilogue's
+                                                      // 256 x 128 tile of 32-bit sums
 // what one more item costs a workgroup of pair_common_mfma_kernel, in slabs of its loop (measured:
 // about 10 us of prologue, accumulator write-out and copy-out against 0.63 us per two-digit slab)
 constexpr int64_t M_ITEM_OVERHEAD_SLABS = 16;  // (a multiple of M_QUAD_SLABS)

@@ -49,6 +49,30 @@ def bounded_barrier(group=None, what: str = "a barrier", timeout_s: float = 120.
     work.wait()
 
 
+def wait_requests(reqs, what: str, timeout_s: Optional[float] = None) -> None:
+    """Waits for point-to-point requests, but not for ever: a peer that never posts its side (it died, or left the
+    exchange through an exception of its own) makes this rank raise after timeout_s (FF_GATHER_TIMEOUT_S, 600 s)
+    instead of sitting in the wait until the process group's own timeout.  (gloo honours the timeout of Work.wait;
+    with RCCL a wait only orders the current stream behind the transfer and the process group's watchdog bounds it.)"""
+    import datetime
+    import os
+    import time
+
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("FF_GATHER_TIMEOUT_S", "600"))
+    t0 = time.monotonic()
+    for q in reqs:
+        left = max(0.05, timeout_s - (time.monotonic() - t0))
+        try:
+            ok = q.wait(datetime.timedelta(seconds=left))
+        except RuntimeError as e:
+            raise RuntimeError("frackyfrac_amd: waited %.0f s for %s; a peer is gone or never entered the exchange (%s)"
+                               % (timeout_s, what, str(e).splitlines()[0][:200])) from e
+        if ok is False:
+            raise RuntimeError("frackyfrac_amd: waited %.0f s for %s; a peer is gone or never entered the exchange"
+                               % (timeout_s, what))
+
+
 def status_all(code: int, group=None, device=None) -> int:
     """Largest `code` over all ranks (one all_reduce that every rank always reaches): 0 = fine,
     1 = FIXED32's guarantee missed somewhere, 2 = some other error somewhere."""
@@ -83,12 +107,10 @@ def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, f
             if b > a:
                 ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
         # one group call: the 7 incoming transfers run concurrently, one per xGMI link
-        for q in (dist.batch_isend_irecv(ops) if ops else []):
-            q.wait()
+        wait_requests(dist.batch_isend_irecv(ops) if ops else [], "the peers' slices (root)")
         return full
     if local.numel() > 0:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]):
-            q.wait()
+        wait_requests(dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]), "the root to take this rank's slice")
     return None
 
 
@@ -169,8 +191,7 @@ def gather_slices_chunked(produce: Callable, n_samples: int, rank: int, world: i
             # enqueued behind sub-shard c's kernels on the communication stream; sub-shard c + 1 is
             # launched right after and overlaps with the transfer
             reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, part, root, group)])
-    for q in reqs:
-        q.wait()
+    wait_requests(reqs, "the sub-shards' transfers")
     return full if rank == root else None
 
 
@@ -363,6 +384,10 @@ class ShardedRun:
         self.gather_events = (ready, done)
         return None
 
+    def sync(self):
+        """This rank's own streams are drained (no collective)."""
+        self.torch.cuda.synchronize(self.device)
+
     def wait(self):
         """Every step issued so far is complete on the root: each rank drains its own
         streams (compute, copies, RCCL), then all meet."""
@@ -442,6 +467,32 @@ class ShardedRun:
         return gather_slices_chunked(produce, self.n_samples, self.rank, self.world, self.chunks, self.root, self.full,
                                      self.group)
 
+    def compute_local(self, timed: bool = False):
+        """The first half of a step with NO collective in it: this rank's kernels are enqueued (every sub-shard into
+        its own buffer) and, with the "ipc" transport, the copy of its slice into the root's mapped array -- a DMA of
+        its own, which no peer waits for.  A caller that must survive a failure on one rank (unifrac_dists_sharded)
+        runs this, takes the joint status, and only then enters gather()."""
+        torch = self.torch
+        if self.transport == "ipc":
+            return self._step_ipc(timed)
+        stream = torch.cuda.current_stream(self.device)
+        for p, buf in zip(self.plans, self.locals):
+            p.run(buf.data_ptr(), stream.cuda_stream, timed=timed)
+        return self.local if self.world == 1 else None
+
+    def gather(self):
+        """The second half: the point-to-point exchange of the "nccl" transport (every rank must enter it: a rank
+        that stays out leaves the root waiting in its receive).  Nothing to do for "ipc" (the slices travel by
+        themselves) and for one rank.  Returns what step() returns."""
+        if self.world == 1:
+            return self.local
+        if self.transport == "ipc":
+            return self.full if self.rank == self.root else None
+        if self.chunks == 1:
+            return gather_slices(self.local, self.n_samples, self.rank, self.world, self.root, self.full, self.group)
+        return gather_slices_chunked(lambda c: self.locals[c], self.n_samples, self.rank, self.world, self.chunks,
+                                     self.root, self.full, self.group)
+
     def timing_collect(self):
         ms = n = 0
         for p in self.plans:
@@ -478,6 +529,43 @@ class ShardedRun:
         self.plans = None
 
 
+def run_jointly(run, world: int, group=None):
+    """One pass of a sharded run in which EVERY rank reaches EVERY collective whatever fails locally:
+
+        local work (compute_local + a device sync; no collective inside)   -> joint status
+        the exchange (gather: point-to-point, entered by all or by none)   -> joint status
+        the precision verdict (check_precision: joint by itself)
+
+    A rank that fails raises its own exception AFTER the joint status that reports it; the others raise a
+    RuntimeError naming the step.  (Until round 4 the exchange of the "nccl" transport sat inside the first try: a
+    rank whose kernels failed skipped its send, the root waited in its receive for ever and the other ranks sat in a
+    mismatched all_reduce.)  `run` is a ShardedRun, or anything with its compute_local / gather / check_precision /
+    close / sync methods (the CPU tests drive this with a gloo group and a stand-in).  Returns gather()'s value."""
+    def joint(failure, what):
+        worst = status_all(2 if failure is not None else 0, group, getattr(run, "device", None)) if world > 1 else (2 if failure else 0)
+        if worst:
+            # (every rank has drained its device by now: no copy into the root's array is in flight, nobody needs to
+            # wait for anybody before unmapping / freeing)
+            run.close(collective=False)
+            raise failure if failure is not None else RuntimeError("frackyfrac_amd: another rank failed in %s" % what)
+
+    failure = None
+    try:
+        run.compute_local()
+        run.sync()
+    except Exception as e:  # noqa: BLE001
+        failure = e
+    joint(failure, "its kernels")
+    res = None
+    try:
+        res = run.gather()
+        run.sync()
+    except Exception as e:  # noqa: BLE001
+        failure = e
+    joint(failure, "the gather")
+    return res
+
+
 def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto", root: int = 0,
                           group=None, compute: Optional[Callable] = None) -> Optional[np.ndarray]:
     """unifracDists over every rank of the default process group; the root gets
@@ -486,7 +574,6 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
     `compute(nodes, weighted, rank, world) -> 1-D float64 torch tensor` replaces the
     per-rank GPU reduction; it exists so the sharding/gather logic can be exercised
     on CPU process groups (gloo) in tests -- the product path leaves it None."""
-    import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -495,24 +582,11 @@ def unifrac_dists_sharded(nodes: api.FlatNodes, weighted: bool, precision="auto"
 
         for attempt in (precision, "exact64"):
             run = ShardedRun(nodes, weighted, rank, world, precision=attempt, root=root, group=group)
-            # Every rank walks the same sequence of collectives whatever fails locally: local work
-            # (no collective inside a try that can be left early), then one joint status, then the joint
-            # precision verdict, then the collective close.
-            res, failure = None, None
+            res = run_jointly(run, world, group)   # (closes the run and raises on every rank if any rank failed)
             try:
-                res = run.step()
-                torch.cuda.synchronize(run.device)
-            except Exception as e:  # noqa: BLE001
-                failure = e
-            worst = status_all(2 if failure is not None else 0, group, run.device) if world > 1 else (2 if failure else 0)
-            if worst:
-                # (every rank has drained its device above, so no copy into the root's array is in flight: nobody
-                # needs to wait for anybody before unmapping / freeing)
-                run.close(collective=False)
-                raise failure if failure is not None else RuntimeError("frackyfrac_amd: another rank's step failed")
-            try:
-                run.wait()
-                run.check_precision()  # joint: raises on every rank or on none
+                # joint by itself: every rank drains its device inside a try, then ONE all_reduce of the verdicts --
+                # which is also the point at which every peer's slice has landed in the root's array ("ipc")
+                run.check_precision()
             except FFError as e:
                 run.close()
                 if e.code != FF_ERR_PRECISION or attempt == "exact64":

@@ -225,3 +225,91 @@ def test_joint_status_and_bounded_barrier_gloo():
     (b,) = [x for x in got if x[0] == "barrier"]
     assert b[1] == 0 and " s at the ipc set-up; a peer is gone or stuck" in b[2], b
     assert float(b[2].split()[0]) < 5.0
+
+
+def _worker_failing(rank, world, port, fail_at, q):
+    """run_jointly with a stand-in for ShardedRun over gloo: the "nccl"-style point-to-point gather is real, the
+    kernels are a constant fill.  Rank 1 fails where `fail_at` says."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FF_GATHER_TIMEOUT_S"] = "20"
+    import torch
+    import torch.distributed as dist
+
+    import frackyfrac_amd as ff
+    from frackyfrac_amd.distributed import gather_slices, run_jointly
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 90
+
+    class Run:
+        device = None
+        closed = None
+
+        def compute_local(self):
+            if rank == 1 and fail_at == "compute":
+                raise ValueError("boom in the kernels of rank 1")
+            a, b = ff.shard_slots(n, rank, world)
+            self.local = torch.full((b - a,), float(rank + 1), dtype=torch.float64)
+
+        def sync(self):
+            pass
+
+        def gather(self):
+            if rank == 1 and fail_at == "gather":
+                raise ValueError("boom in the gather of rank 1")   # (it never posts its send)
+            return gather_slices(self.local, n, rank, world, 0, None, None)
+
+        def close(self, collective=True):
+            self.closed = collective
+
+    run = Run()
+    try:
+        res = run_jointly(run, world)
+        if rank == 0:
+            want = np.concatenate([np.full(ff.shard_slots(n, r, world)[1] - ff.shard_slots(n, r, world)[0], r + 1.0)
+                                   for r in range(world)])
+            q.put((rank, "ok", bool(np.array_equal(res.numpy(), want)), run.closed))
+        else:
+            q.put((rank, "ok", res is None, run.closed))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, type(e).__name__, str(e), run.closed))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_at", ["none", "compute", "gather"])
+def test_a_rank_that_fails_takes_every_rank_out_of_the_exchange_instead_of_hanging_it(fail_at):
+    """with the point-to-point transport a rank whose kernels failed skipped its send, the
+    root waited in its receive for ever and the others sat in a mismatched all_reduce.  Now the local work comes first,
+    then a joint status, and the exchange is entered by all ranks or by none: the failing rank raises its own
+    exception, the others a RuntimeError that says where, all within seconds, and everybody closes without the
+    collective tear-down.  A rank that fails INSIDE the exchange cannot be waited out jointly; there the peers'
+    bounded request waits (FF_GATHER_TIMEOUT_S) end the wait."""
+    import torch.multiprocessing as mp
+
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_failing, args=(r, world, port, fail_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, kind, msg, closed = q.get(timeout=120)
+        got[r] = (kind, msg, closed)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if fail_at == "none":
+        assert all(got[r][0] == "ok" and got[r][1] is True and got[r][2] is None for r in range(world)), got
+    elif fail_at == "compute":
+        assert got[1][0] == "ValueError" and "boom in the kernels" in got[1][1]
+        for r in (0, 2):
+            assert got[r][0] == "RuntimeError" and "another rank failed in its kernels" in got[r][1], got
+        assert all(got[r][2] is False for r in range(world))          # closed without the collective tear-down
+    else:
+        assert got[1][0] == "ValueError" and "boom in the gather" in got[1][1]
+        # (the root either times out in its bounded receive or learns of the failure from the joint status)
+        for r in (0, 2):
+            assert got[r][0] == "RuntimeError" and ("waited" in got[r][1] or "another rank failed in the gather" in got[r][1]), got
