@@ -361,7 +361,10 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
         entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region
         entry["roofline"]["kernel_ms_between_events"] = kernel_ms_events
         if n_audit:
-            entry["audit"] = {"pairs": n_audit, "failed": bad, "worst_rel_err": worst}
+            uni, found, chk, headroom = run.plan.audit_detail()
+            entry["audit"] = {"pairs": n_audit, "failed": bad, "worst_rel_err": worst, "uniform_sample": uni,
+                              "risk_pairs_found": found, "risk_pairs_checked": chk,
+                              "min_headroom": None if math.isinf(headroom) else headroom}
         if ctx.world > 1:
             entry["gather"] = {"transport": run.transport, "fallback_reason": run.transport_note or None,
                                "backend": dist.get_backend(), "world_size": dist.get_world_size(),

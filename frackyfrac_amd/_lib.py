@@ -49,7 +49,8 @@ class ff_plan_info(ctypes.Structure):
                 ("n_tiles", c_int64), ("n_items", c_int64), ("n_wave_slots", c_int64),
                 ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32),
                 ("n_rows", c_int64), ("n_sweeps", c_int32), ("planes_per_sweep", c_int32),
-                ("rows_three_planes", c_int64)]
+                ("rows_three_planes", c_int64), ("audit_checked", c_int64), ("audit_failed", c_int64),
+                ("audit_worst_rel_err", c_double), ("audit_min_headroom", c_double)]
 
 # ff_dists_fn: int (*)(void *user, int64_t slot_begin, const double *dists, int64_t n)
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
@@ -80,6 +81,7 @@ SIGNATURES = {
     "ff_plan_timing_collect": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int32)]),
     "ff_plan_refined_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "ff_plan_audit": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),
+    "ff_plan_audit_detail": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),
     "ff_device_alloc": (c_int, [c_int32, c_size_t, POINTER(c_void_p), c_char_p, c_size_t]),
     "ff_device_free": (c_int, [c_void_p, c_char_p, c_size_t]),
     "ff_ipc_export": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),

@@ -437,6 +437,15 @@ class Plan:
             raise FFError(rc, "ff_plan_audit failed")
         return n.value, bad.value, worst.value
 
+    def audit_detail(self) -> Tuple[int, int, int, float]:
+        """(pairs of the uniform sample, pairs of the last run with a headroom under 1.25 over the refinement rule's
+        bound, how many of those were computed in binary64, the run's smallest headroom) -- ff_plan_audit_detail."""
+        u, found, chk, h = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        rc = L.lib().ff_plan_audit_detail(self._h, ctypes.byref(u), ctypes.byref(found), ctypes.byref(chk), ctypes.byref(h))
+        if rc:
+            raise FFError(rc, "ff_plan_audit_detail failed")
+        return u.value, found.value, chk.value, h.value
+
     def check_precision(self) -> None:
         """Raises FFError(FF_ERR_PRECISION) unless the last completed run keeps FIXED32's
         promise: refinement queue not overflowed, audit sample within its bar."""

@@ -8,6 +8,7 @@
 // Errors print "ERROR: <msg>" and exit 2 (common/common.go:13-18).
 // Extensions (not in the reference): -precision auto|fixed32|exact64, -stats, -gpus N.
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <memory>
 #include <thread>
@@ -327,6 +328,14 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
                 snprintf(err, sizeof err, "%s", errs[(size_t)g].c_str());
             }
         if (pass == 0) info = infos[0];
+        for (int64_t g = 0; g < G && rc == 0; ++g) {  // the audit's verdict over every shard of every pass
+            if (pass > 0 || g > 0) {
+                info.audit_checked += infos[(size_t)g].audit_checked;
+                info.audit_failed += infos[(size_t)g].audit_failed;
+                info.audit_worst_rel_err = std::max(info.audit_worst_rel_err, infos[(size_t)g].audit_worst_rel_err);
+                info.audit_min_headroom = std::min(info.audit_min_headroom, infos[(size_t)g].audit_min_headroom);
+            }
+        }
         auto p1 = std::chrono::steady_clock::now();
         t_dist += std::chrono::duration<double>(p1 - p0).count();
         if (wr.joinable()) wr.join();  // the previous pass is on its way out: its buffers are the next ones
@@ -366,14 +375,17 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     if (f.stats)
         fprintf(stderr,
                 "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"bit_exact\": %s, \"tiles\": %lld, "
-                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"seconds\": {\"tree\": %.3f, "
+                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"audit\": {\"checked\": %lld, "
+                "\"failed\": %lld, \"worst_rel_err\": %.3g, \"min_headroom\": %s}, \"seconds\": {\"tree\": %.3f, "
                 "\"load\": %.3f, \"validate\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f}}\n",
                 info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
                 info.lengths_exact,
                 info.precision == FF_PRECISION_EXACT64 || (!f.weighted && info.lengths_exact) ? "true" : "false",
                 (long long)info.n_tiles, (long long)info.n_items,
-                (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, phase[0], phase[1], phase[2], phase[3], phase[4],
-                phase[5]);
+                (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, (long long)info.audit_checked,
+                (long long)info.audit_failed, info.audit_worst_rel_err,
+                std::isfinite(info.audit_min_headroom) ? std::to_string(info.audit_min_headroom).c_str() : "null", phase[0],
+                phase[1], phase[2], phase[3], phase[4], phase[5]);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Took %s\n", go_duration(sec).c_str());
     fputs("Done\n", stderr);

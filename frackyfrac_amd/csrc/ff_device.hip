@@ -89,7 +89,8 @@ struct ff_plan {
     double *d_abnd = nullptr;
     unsigned long long *d_refine_list = nullptr;
     int32_t *d_n_nodes = nullptr;                  // flat nodes per sample (the refinement rule's k)
-    unsigned long long *d_refine_count = nullptr;  // [0] pairs queued, [1] audited pairs that failed, [2] max audited error (double bits)
+    unsigned long long *d_refine_count = nullptr;  // CNT_N counters of a run (ff_kernels_finish_pair.hpp: pairs queued, audit verdicts, risk list)
+    unsigned long long *d_risk_list = nullptr;     // the run's pairs just above the refinement rule's bound (RISK_CAP slots)
     unsigned long long refine_cap = 0;
     double *d_wex = nullptr;          // binary64 weights of the samples (exact_weight_kernel); null: integer denominators
     int64_t *d_audit_slots = nullptr;  // run-time audit: sampled slots of the shard and their binary64 distances
@@ -398,6 +399,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_abnd);
     (void)hipFree(pl->d_refine_list);
     (void)hipFree(pl->d_refine_count);
+    (void)hipFree(pl->d_risk_list);
     (void)hipFree(pl->d_n_nodes);
     (void)hipFree(pl->d_wex);
     (void)hipFree(pl->d_audit_slots);
@@ -447,6 +449,7 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
                         pl->device, prop->gcnArchName);
     pl->weighted = o->weighted != 0;
     ff_plan_info &inf = pl->info;
+    inf.audit_min_headroom = INFINITY;
     inf.n_samples = N;
     inf.n_branches = B;
     inf.n_compute_units = prop->multiProcessorCount;
@@ -1101,7 +1104,8 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
     pl->n_audit = 0;
     pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
     FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)std::max<unsigned long long>(pl->refine_cap, 1)));
-    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * 3));
+    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * CNT_N));
+    if (!pl->d_risk_list && env_int("FF_AUDIT", 1) != 0) FF_HIP(hipMalloc(&pl->d_risk_list, sizeof(unsigned long long) * RISK_CAP));
     if (!pl->d_n_nodes) {
         const int64_t ns = pl->info.n_samples;
         FF_HIP(hipMalloc(&pl->d_n_nodes, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
@@ -1109,9 +1113,12 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());  // (runs may come on any stream)
     }
-    FF_HIP(hipMemset(pl->d_refine_count, 0, sizeof(unsigned long long) * 3));
+    reset_counters_kernel<<<dim3(1), dim3(64)>>>(pl->d_refine_count);
+    FF_HIP(hipGetLastError());
     if (n_slots > 0 && env_int("FF_AUDIT", 1) != 0) {
-        const int n = (int)std::min<int64_t>(AUDIT_PAIRS, n_slots);
+        // the uniform sample grows with the shard: AUDIT_PAIRS per 2^23 pairs of it (C3 as a whole: 4,096; C4: 65,536)
+        const int64_t want_n = std::min<int64_t>(AUDIT_PAIRS_MAX, AUDIT_PAIRS * ((n_slots + ((int64_t)1 << 23) - 1) >> 23));
+        const int n = (int)std::min<int64_t>(want_n, n_slots);
         std::vector<int64_t> slots((size_t)n);
         uint64_t x = 0x5EEDF4ACull ^ (uint64_t)pl->info.slot_begin;
         for (int q = 0; q < n; ++q) {  // splitmix64
@@ -1119,7 +1126,7 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
             z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
             z ^= z >> 31;
-            slots[(size_t)q] = n_slots <= AUDIT_PAIRS ? q : (int64_t)(z % (uint64_t)n_slots);
+            slots[(size_t)q] = n_slots <= n ? q : (int64_t)(z % (uint64_t)n_slots);
         }
         FF_HIP(hipMalloc(&pl->d_audit_slots, sizeof(int64_t) * (size_t)n));
         FF_HIP(hipMalloc(&pl->d_audit_exact, sizeof(double) * (size_t)n));
@@ -1635,10 +1642,11 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         fin.refine_list = pl->d_refine_list;
         fin.refine_count = pl->d_refine_count;
         fin.refine_cap = pl->refine_cap;
+        fin.risk_list = pl->refine ? pl->d_risk_list : nullptr;
         fin.scale_log2 = inf.scale_log2;
         fin.weighted = pl->weighted;
         const bool fused = pl->mfma && pl->m_fused;  // (decided when the shard was scheduled: schedule_mfma)
-        if (pl->refine) FF_HIP(hipMemsetAsync(pl->d_refine_count, 0, sizeof(unsigned long long) * 3, st));
+        if (pl->refine) reset_counters_kernel<<<dim3(1), dim3(64), 0, st>>>(pl->d_refine_count);
         if (!fused && (!pl->mfma || pl->m_any_atomic))
             FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
@@ -1717,6 +1725,9 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         if (pl->refine && pl->n_audit > 0)
             audit_compare_kernel<<<dim3((unsigned)((pl->n_audit + 255) / 256)), dim3(256), 0, st>>>(
                 pl->d_audit_slots, pl->d_audit_exact, pl->n_audit, d_out, pl->d_refine_count);
+        if (pl->refine && pl->d_risk_list)
+            audit_risk_kernel<<<dim3((unsigned)RISK_CAP), dim3(64), 0, st>>>(pl->d_risk_list, pl->d_refine_count, pl->d_indptr, pl->d_ids,
+                                                                             pl->d_abnd, pl->d_len, pl->weighted, inf.slot_begin, d_out);
     } else {
         if (timed) FF_HIP(hipEventRecord(ev0, st));
         {
@@ -1736,7 +1747,7 @@ int plan_fixed32_verdict(ff_plan *pl, bool *ok, std::string *why)
 {
     *ok = true;
     if (!pl->refine) return FF_OK;
-    unsigned long long c[3] = {0, 0, 0};
+    unsigned long long c[CNT_N] = {};
     if (hipMemcpy(c, pl->d_refine_count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
     char buf[256];
     if (c[0] > pl->refine_cap) {
@@ -1745,12 +1756,23 @@ int plan_fixed32_verdict(ff_plan *pl, bool *ok, std::string *why)
     } else if (c[1] > 0) {
         double worst;
         memcpy(&worst, &c[2], sizeof worst);
-        snprintf(buf, sizeof buf, "%llu of %d audited pairs are further than %.1e from their binary64 value (worst %.2e)",
-                 c[1], pl->n_audit, AUDIT_REL, worst);
+        snprintf(buf, sizeof buf, "%llu of %llu audited pairs are further than %.1e from their binary64 value (worst %.2e)",
+                 c[1], (unsigned long long)pl->n_audit + c[CNT_RISK_CHECKED], AUDIT_REL, worst);
         *ok = false;
     }
     if (!*ok && why) *why = buf;
     return FF_OK;
+}
+
+// The audit's verdict on the run that has just completed, into an ff_plan_info that is handed back to a caller.
+void fill_audit_info(ff_plan *pl, ff_plan_info *info)
+{
+    info->audit_checked = info->audit_failed = 0;
+    info->audit_worst_rel_err = 0.0;
+    info->audit_min_headroom = INFINITY;
+    int64_t uniform = 0, found = 0, chk = 0;
+    (void)ff_plan_audit(pl, &info->audit_checked, &info->audit_failed, &info->audit_worst_rel_err);
+    (void)ff_plan_audit_detail(pl, &uniform, &found, &chk, &info->audit_min_headroom);
 }
 
 }  // namespace
@@ -1860,7 +1882,7 @@ int ff_plan_refined_pairs(ff_plan *pl, int64_t *queued, int64_t *capacity)
     *queued = 0;
     *capacity = (int64_t)pl->refine_cap;
     if (!pl->refine) return FF_OK;
-    unsigned long long n = 0;
+    unsigned long long n = 0;  // (CNT_QUEUED is the first counter)
     if (hipMemcpy(&n, pl->d_refine_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
     *queued = (int64_t)n;
     return FF_OK;
@@ -1903,12 +1925,30 @@ int ff_plan_audit(ff_plan *pl, int64_t *checked, int64_t *failed, double *max_re
     *checked = 0;
     *failed = 0;
     *max_rel_err = 0.0;
-    if (!pl->refine || pl->n_audit <= 0) return FF_OK;
-    unsigned long long c[3] = {0, 0, 0};
+    if (!pl->refine || (pl->n_audit <= 0 && !pl->d_risk_list)) return FF_OK;
+    unsigned long long c[CNT_N] = {};
     if (hipMemcpy(c, pl->d_refine_count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
-    *checked = pl->n_audit;
-    *failed = (int64_t)c[1];
-    memcpy(max_rel_err, &c[2], sizeof(double));
+    *checked = pl->n_audit + (int64_t)c[CNT_RISK_CHECKED];
+    *failed = (int64_t)c[CNT_AUDIT_FAILED];
+    memcpy(max_rel_err, &c[CNT_AUDIT_WORST], sizeof(double));
+    return FF_OK;
+}
+
+int ff_plan_audit_detail(ff_plan *pl, int64_t *uniform_checked, int64_t *risk_found, int64_t *risk_checked, double *min_headroom)
+{
+    if (!pl || !uniform_checked || !risk_found || !risk_checked || !min_headroom) return FF_ERR_ARG;
+    *uniform_checked = *risk_found = *risk_checked = 0;
+    *min_headroom = INFINITY;
+    if (!pl->refine) return FF_OK;
+    unsigned long long c[CNT_N] = {};
+    if (hipMemcpy(c, pl->d_refine_count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return FF_ERR_DEVICE;
+    *uniform_checked = pl->n_audit;
+    *risk_found = (int64_t)c[CNT_RISK_FOUND];
+    *risk_checked = (int64_t)c[CNT_RISK_CHECKED];
+    const uint32_t bits = (uint32_t)c[CNT_MIN_HEADROOM2];
+    float h2;
+    memcpy(&h2, &bits, sizeof h2);
+    *min_headroom = pl->d_risk_list ? std::sqrt((double)h2) : INFINITY;
     return FF_OK;
 }
 
@@ -2327,7 +2367,10 @@ int ff::run_plan_to_host(ff_plan *pl, const std::function<int(ff_plan **)> &recr
         }
         (void)hipFree(d_out);
     }
-    if (info_out && pl) *info_out = pl->info;
+    if (info_out && pl) {
+        *info_out = pl->info;
+        if (rc == FF_OK) fill_audit_info(pl, info_out);
+    }
     ff_plan_destroy(pl);
     return rc;
 }
@@ -2396,7 +2439,10 @@ int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info 
             return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
         }
     }
-    if (info) *info = pl_->info;
+    if (info) {
+        *info = pl_->info;
+        fill_audit_info(pl_, info);
+    }
     return FF_OK;
 }
 

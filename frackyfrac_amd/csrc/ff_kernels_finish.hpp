@@ -60,7 +60,8 @@ __global__ void node_counts_kernel(const int64_t *__restrict__ indptr, int64_t n
 // callers).  The staging's error model makes that a < 1e-9 event per sampled pair; the audit is
 // there for what a model cannot promise.
 constexpr double AUDIT_REL = 0.5e-6;
-constexpr int AUDIT_PAIRS = 4096;
+constexpr int AUDIT_PAIRS = 4096;        // per 2^23 pairs of the shard
+constexpr int AUDIT_PAIRS_MAX = 65536;   // and at most this many
 
 // Position of id b in ids[lo, hi) (ascending), or -1.
 __device__ __forceinline__ int64_t find_branch(const int32_t *__restrict__ ids, int64_t lo, int64_t hi, int32_t b)
@@ -74,20 +75,18 @@ __device__ __forceinline__ int64_t find_branch(const int32_t *__restrict__ ids, 
     return (lo < end && ids[lo] == b) ? lo : -1;
 }
 
-// One wave per sampled pair: the sums of unifrac.go:144-205 in binary64, lanes striding over
+// A wave computes one pair (samples si > sj) in binary64: the sums of unifrac.go:144-205, lanes striding over
 // the flat nodes of either sample and looking the branch up in the other.  Not the reference's
-// ORDER of additions (the differences are ~1e-15 relative, nine orders below what is checked).
-__global__ __launch_bounds__(64)
-void audit_exact_kernel(const int64_t *__restrict__ slots, const int64_t *__restrict__ indptr,
-                        const int32_t *__restrict__ branch_id, const double *__restrict__ abnd,
-                        const double *__restrict__ tree_dists, int weighted, int64_t slot_begin,
-                        double *__restrict__ exact)
+// ORDER of additions (the differences are ~1e-15 relative, nine orders below what is checked).  Every lane returns
+// the distance.
+__device__ __forceinline__ double exact_pair_wave(int64_t si, int64_t sj, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ branch_id, const double *__restrict__ abnd,
+                                                  const double *__restrict__ tree_dists, int weighted)
 {
-    int64_t si, sj;
-    slot_to_pair(slot_begin + slots[blockIdx.x], &si, &sj);
+    const int lane = threadIdx.x & 63;
     const int64_t i0 = indptr[si], i1 = indptr[si + 1], j0 = indptr[sj], j1 = indptr[sj + 1];
     double x = 0.0, y = 0.0;  // numer/denom or result/common
-    for (int64_t t = i0 + threadIdx.x; t < i1; t += 64) {
+    for (int64_t t = i0 + lane; t < i1; t += 64) {
         const int32_t b = branch_id[t];
         const double l = tree_dists[b];
         const int64_t p = find_branch(branch_id, j0, j1, b);
@@ -99,7 +98,7 @@ void audit_exact_kernel(const int64_t *__restrict__ slots, const int64_t *__rest
             if (p >= 0) y += l; else x += l;
         }
     }
-    for (int64_t t = j0 + threadIdx.x; t < j1; t += 64) {
+    for (int64_t t = j0 + lane; t < j1; t += 64) {
         const int32_t b = branch_id[t];
         if (find_branch(branch_id, i0, i1, b) >= 0) continue;  // counted above
         const double l = tree_dists[b];
@@ -109,26 +108,71 @@ void audit_exact_kernel(const int64_t *__restrict__ slots, const int64_t *__rest
         x += __shfl_xor(x, m);
         y += __shfl_xor(y, m);
     }
-    if (threadIdx.x == 0) exact[blockIdx.x] = weighted ? x / y : x / (x + y);
+    return weighted ? x / y : x / (x + y);
 }
 
-// counters[1] += sampled pairs further than AUDIT_REL from their binary64 value,
-// counters[2] = max over the sample of the relative error (bits of a non-negative double).
+// The uniform sample: one wave per sampled pair, once per plan and shard.
+__global__ __launch_bounds__(64)
+void audit_exact_kernel(const int64_t *__restrict__ slots, const int64_t *__restrict__ indptr,
+                        const int32_t *__restrict__ branch_id, const double *__restrict__ abnd,
+                        const double *__restrict__ tree_dists, int weighted, int64_t slot_begin,
+                        double *__restrict__ exact)
+{
+    int64_t si, sj;
+    slot_to_pair(slot_begin + slots[blockIdx.x], &si, &sj);
+    const double d = exact_pair_wave(si, sj, indptr, branch_id, abnd, tree_dists, weighted);
+    if (threadIdx.x == 0) exact[blockIdx.x] = d;
+}
+
+// |got - want| / |want| as the audit counts it (NaN where the reference has NaN: 0; anything else off a NaN or a
+// zero: infinite).
+__device__ __forceinline__ double audit_rel_err(double got, double want)
+{
+    if (want != want) return got != got ? 0.0 : INFINITY;
+    if (want == 0.0) return got == 0.0 ? 0.0 : INFINITY;
+    const double rel = fabs(got - want) / fabs(want);
+    return rel != rel ? INFINITY : rel;
+}
+
+// counters[CNT_AUDIT_FAILED] += sampled pairs further than AUDIT_REL from their binary64 value,
+// counters[CNT_AUDIT_WORST] = max over the sample of the relative error (bits of a non-negative double).
 __global__ void audit_compare_kernel(const int64_t *__restrict__ slots, const double *__restrict__ exact, int n,
                                      const double *__restrict__ out, unsigned long long *__restrict__ counters)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const double want = exact[q], got = out[slots[q]];
-    double rel;
-    if (want != want) rel = got != got ? 0.0 : INFINITY;
-    else if (want == 0.0) rel = got == 0.0 ? 0.0 : INFINITY;
-    else rel = fabs(got - want) / fabs(want);
-    if (!(rel <= AUDIT_REL)) {
-        if (rel != rel) rel = INFINITY;
-        atomicAdd(&counters[1], 1ull);
-    }
-    atomicMax(&counters[2], (unsigned long long)__double_as_longlong(rel));
+    const double rel = audit_rel_err(out[slots[q]], exact[q]);
+    if (!(rel <= AUDIT_REL)) atomicAdd(&counters[CNT_AUDIT_FAILED], 1ull);
+    atomicMax(&counters[CNT_AUDIT_WORST], (unsigned long long)__double_as_longlong(rel));
+}
+
+// The pairs of THIS run that stand just above the refinement rule's bound (finish_pair_w's risk list): one wave each
+// computes the pair in binary64 and holds what was delivered to the same bar.  A grid of RISK_CAP workgroups whatever
+// the list holds (usually nothing: a few microseconds).
+__global__ __launch_bounds__(64)
+void audit_risk_kernel(const unsigned long long *__restrict__ risk_list, unsigned long long *__restrict__ counters,
+                       const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                       const double *__restrict__ abnd, const double *__restrict__ tree_dists, int weighted,
+                       int64_t slot_begin, const double *__restrict__ out)
+{
+    unsigned long long n = counters[CNT_RISK_FOUND];
+    if (n > RISK_CAP) n = RISK_CAP;
+    if (blockIdx.x >= n) return;
+    const int64_t t = (int64_t)risk_list[blockIdx.x];
+    int64_t si, sj;
+    slot_to_pair(slot_begin + t, &si, &sj);
+    const double want = exact_pair_wave(si, sj, indptr, branch_id, abnd, tree_dists, weighted);
+    if (threadIdx.x != 0) return;
+    const double rel = audit_rel_err(out[t], want);
+    if (!(rel <= AUDIT_REL)) atomicAdd(&counters[CNT_AUDIT_FAILED], 1ull);
+    atomicMax(&counters[CNT_AUDIT_WORST], (unsigned long long)__double_as_longlong(rel));
+    atomicAdd(&counters[CNT_RISK_CHECKED], 1ull);
+}
+
+// Before every run of a plan that refines: counters to zero, the smallest headroom to +infinity.
+__global__ void reset_counters_kernel(unsigned long long *__restrict__ counters)
+{
+    if (threadIdx.x < CNT_N) counters[threadIdx.x] = threadIdx.x == CNT_MIN_HEADROOM2 ? 0x7F800000ull : 0ull;
 }
 
 // The reference's merge walk (unifrac.go:144-205) for the queued pairs, in binary64 and in the reference's

@@ -16,6 +16,14 @@
 // variances -- and that only for the pairs right at the threshold.
 constexpr double REFINE_BAR = 1e-6;   // the relative bar of BASELINE.json ("within 1e-6 relative for weighted")
 constexpr double REFINE_C = 5.0;
+// HEADROOM of a pair that is not queued: (U * 1e-6 - 2) / (C sqrt(k)) >= 1 -- how many times over the rule's bound its
+// numerator stands.  The pairs the statistical argument protects least are those just above 1: every run hands the
+// ones below RISK_HEADROOM (up to RISK_CAP of them) to audit_risk_kernel, which computes them in binary64 and holds
+// what was delivered to the audit's bar; the smallest headroom of the run is kept for the caller (ff_plan_audit_detail).
+constexpr float RISK_HEADROOM = 1.25f;
+constexpr unsigned long long RISK_CAP = 4096;
+// slots of FinishArgs::refine_count (one allocation, reset before every run by reset_counters_kernel)
+enum { CNT_QUEUED = 0, CNT_AUDIT_FAILED = 1, CNT_AUDIT_WORST = 2, CNT_RISK_FOUND = 3, CNT_MIN_HEADROOM2 = 4, CNT_RISK_CHECKED = 5, CNT_N = 6 };
 
 struct FinishArgs {
     const unsigned long long *W;   // integer column sums
@@ -24,6 +32,7 @@ struct FinishArgs {
     const int32_t *n_nodes;        // flat nodes per sample; null: no refinement
     unsigned long long *refine_list, *refine_count;
     unsigned long long refine_cap;
+    unsigned long long *risk_list;  // local slots of the pairs just above the refinement rule's bound (null: none kept)
     int scale_log2, weighted;
 };
 
@@ -51,9 +60,20 @@ __device__ __forceinline__ void finish_pair_w(const FinishArgs &f, int64_t t, in
     if (f.n_nodes && w != 0) {
         const double k = (double)f.n_nodes[i] + (double)f.n_nodes[j];
         const double a = (double)u * REFINE_BAR - 2.0;  // u * 1e-6 < C sqrt(k) + 2, without the square root
-        if (a < 0.0 || a * a < REFINE_C * REFINE_C * k) {
-            const unsigned long long at = atomicAdd(f.refine_count, 1ull);
+        const double c2k = REFINE_C * REFINE_C * k;
+        if (a < 0.0 || a * a < c2k) {
+            const unsigned long long at = atomicAdd(&f.refine_count[CNT_QUEUED], 1ull);
             if (at < f.refine_cap) f.refine_list[at] = (unsigned long long)t;
+        } else if (f.risk_list) {
+            const float h2 = (float)(a * a) / (float)c2k;  // headroom squared, >= 1 (single precision: it ranks pairs, no more)
+            if (h2 < RISK_HEADROOM * RISK_HEADROOM) {
+                const unsigned long long at = atomicAdd(&f.refine_count[CNT_RISK_FOUND], 1ull);
+                if (at < RISK_CAP) f.risk_list[at] = (unsigned long long)t;
+            }
+            // the run's smallest: an atomic only from a pair below what is there already (a stale read costs an
+            // atomic too many, never a wrong minimum); non-negative floats order like their bit patterns
+            const unsigned long long bits = (unsigned long long)__float_as_uint(h2);
+            if (bits < *(volatile unsigned long long *)&f.refine_count[CNT_MIN_HEADROOM2]) atomicMin(&f.refine_count[CNT_MIN_HEADROOM2], bits);
         }
     }
 }

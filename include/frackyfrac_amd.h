@@ -191,6 +191,15 @@ typedef struct ff_plan_info {
                                  digits: rows sorted by length, longest first, a branch longer than
                                  three signed digits hold as several rows): the leading rows of
                                  rows_padded whose blocks take three planes; the rest take two  */
+    /* FIXED32's run-time audit of the LAST COMPLETED RUN (ff_plan_audit, ff_plan_audit_detail).  Filled by
+       the blocking entry points that hand an ff_plan_info back after running (ff_unifrac and the frcfrc
+       command: their -stats); ff_plan_info_get leaves them 0 / infinity -- ask ff_plan_audit.          */
+    int64_t audit_checked;     /* pairs held against their binary64 value: the uniform sample + the pairs
+                                  just above the refinement rule's bound                                  */
+    int64_t audit_failed;      /* of those, further than 0.5e-6 (relative) from it                        */
+    double audit_worst_rel_err;
+    double audit_min_headroom; /* smallest (U * 1e-6 - 2) / (5 sqrt(k)) over the run's pairs that were not
+                                  re-computed exactly (the rule queues everything under 1); infinity: none */
 } ff_plan_info;
 
 typedef enum ff_kernel {
@@ -262,15 +271,24 @@ int ff_plan_timing_collect(ff_plan *plan, double *total_ms, int32_t *launches);
 int ff_plan_refined_pairs(ff_plan *plan, int64_t *queued, int64_t *capacity);
 
 /*
- * FIXED32's run-time audit.  When a shard is scheduled, a fixed pseudo-random sample of its
- * pairs (up to 4096) is computed in binary64 on the device; every run compares what it
- * delivered for them.  After a run has completed: the sample size, how many sampled pairs were
- * further than 0.5e-6 (relative) from their binary64 value, and the largest relative error seen.
+ * FIXED32's run-time audit, in two parts.  (1) When a shard is scheduled, a fixed pseudo-random
+ * sample of its pairs (4096 per 2^23 pairs of the shard, at most 65536) is computed in binary64 on
+ * the device; every run compares what it delivered for them.  (2) Every run also collects the
+ * pairs that stand just above the refinement rule's bound -- headroom
+ * (U * 1e-6 - 2) / (5 sqrt(k)) in [1, 1.25): the ones the statistical argument protects least --
+ * and computes up to 4096 of them in binary64 on the spot.  After a run has completed: the pairs
+ * checked (both parts), how many of them were further than 0.5e-6 (relative) from their binary64
+ * value, and the largest relative error seen.
  * failed > 0 means the run must not be trusted to the 1e-6 bar: ff_plan_run_host returns
  * FF_ERR_PRECISION, ff_unifrac_dists / ff_unifrac / the CLI repeat the shard in EXACT64.
  * checked == 0 when the plan's integers are exact (EXACT64; unweighted on the binary grid).
  */
 int ff_plan_audit(ff_plan *plan, int64_t *checked, int64_t *failed, double *max_rel_err);
+/* The parts: the uniform sample's size, how many pairs of the last run had a headroom under 1.25,
+ * how many of those were computed in binary64 (the first 4096), and the smallest headroom over all
+ * pairs of the run that were not re-computed exactly (infinity: none, or no audit). */
+int ff_plan_audit_detail(ff_plan *plan, int64_t *uniform_checked, int64_t *risk_found,
+                         int64_t *risk_checked, double *min_headroom);
 
 /* -- Device buffers shared between the processes of one node (the multi-GPU gather) --
  *

@@ -37,19 +37,20 @@ def test_struct_layouts(tmp_path):
     import ctypes
     assert ctypes.sizeof(L.ff_problem) == 48
     assert ctypes.sizeof(L.ff_options) == 32
-    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8 + 8 + 8 + 8 + 4 * 8   # (+ the audit's four fields)
     # the same from the header itself, as a C compiler lays it out (sizes and the offsets of the last fields)
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "frackyfrac_amd.h"\n'
                    'int main(void) { printf("%zu %zu %zu %zu %zu %zu", sizeof(ff_problem), sizeof(ff_options), '
                    'sizeof(ff_plan_info), offsetof(ff_plan_info, n_rows), offsetof(ff_plan_info, planes_per_sweep), '
-                   'offsetof(ff_plan_info, rows_three_planes)); return 0; }\n')
+                   'offsetof(ff_plan_info, rows_three_planes)); printf(" %zu %zu", offsetof(ff_plan_info, audit_checked), '
+                   'offsetof(ff_plan_info, audit_min_headroom)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     I = L.ff_plan_info
     assert got == [ctypes.sizeof(L.ff_problem), ctypes.sizeof(L.ff_options), ctypes.sizeof(I), I.n_rows.offset,
-                   I.planes_per_sweep.offset, I.rows_three_planes.offset]
+                   I.planes_per_sweep.offset, I.rows_three_planes.offset, I.audit_checked.offset, I.audit_min_headroom.offset]
 
 
 def test_frcfrc_binary_links_the_library():

@@ -56,7 +56,9 @@ def test_single_gpu_line_carries_the_secondary_entries():
     out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--cpu-budget", "3")
     assert out["n_gpus"] == 1 and out["dtype"] == "u32" and out["config"]["workload"].startswith("C3:")
     assert out["roofline"]["kernel"] == "pair_sad_kernel12" and 0.5 < out["roofline"]["frac"] < 1.0
-    assert out["audit"]["pairs"] == 4096 and out["audit"]["failed"] == 0
+    a = out["audit"]
+    assert a["uniform_sample"] == 4096 and a["pairs"] == 4096 + a["risk_pairs_checked"] and a["failed"] == 0
+    assert a["min_headroom"] is None or a["min_headroom"] >= 1.0   # (everything under 1 is re-computed exactly)
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1
     sec = out["secondary"]

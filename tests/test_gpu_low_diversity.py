@@ -70,7 +70,8 @@ def test_fixed32_weighted_low_diversity_every_pair(case, leave):
     err = rel_err(got, want)
     assert err.max() <= WEIGHTED_RTOL, (case, leave, float(err.max()), int(err.argmax()))
     n, bad, worst = plan.audit()
-    assert n == min(4096, len(want)) and bad == 0 and worst <= 0.5e-6
+    uni, found, chk, headroom = plan.audit_detail()   # (+ the run's pairs just above the refinement rule's bound)
+    assert uni == min(4096, len(want)) and n == uni + chk and chk == min(found, 4096) and bad == 0 and worst <= 0.5e-6
     # the audit sample covers every pair here (fewer than 4096): its worst error is the one measured
     # (to the ~1e-15 by which its order of additions differs from the oracle's)
     assert worst <= err.max() * 1.001 + 1e-12
@@ -116,7 +117,7 @@ def test_fixed32_unweighted_few_distinct_lengths(mfma, monkeypatch):
     got = plan.run_host()
     assert rel_err(got, want).max() <= WEIGHTED_RTOL
     n, bad, worst = plan.audit()
-    assert n == len(want) and bad == 0
+    assert n >= len(want) and plan.audit_detail()[0] == len(want) and bad == 0
     plan.close()
 
 
@@ -199,3 +200,51 @@ def test_cli_says_when_unweighted_is_tolerance_grade(tmp_path):
         assert ("Note: branch lengths are not multiples of a power of two" in r.stderr) == noted
         assert ('"bit_exact": false' in r.stderr) == noted and ('"bit_exact": true' in r.stderr) == (not noted)
         tree, _, _, _ = synth.make(40, 300, 0.2, 7)
+
+
+def test_pairs_just_above_the_refinement_bound_are_the_ones_audited():
+    """FIXED32's guarantee is statistical, and the pairs it protects least are those just ABOVE the refinement
+    rule's bound U * 1e-6 >= 5 sqrt(k) + 2 (everything under it is re-computed exactly).  Round 3 audited 4,096
+    uniformly drawn pairs and so, in a table with a handful of such pairs, none of them.  Here a table is built to
+    have them: 300 near-copies of one sample, copy t with a fifth of its leaves scaled by (1 + f_t), f_t a
+    geometric ladder from 0.02 to 4 -- the pairs (base, copy t) and (copy t, copy t') sweep U through the
+    bound.  Every run must find pairs of headroom in [1, 1.25), compute them (up to 4,096) in binary64, hold what
+    it delivered to the audit's bar, and report the run's smallest headroom; and the whole result is within 1e-6
+    of the oracle, the planted pairs included."""
+    tree, ptr, idx, val = synth.make(1, 1500, 0.4, 5)
+    base = np.zeros(tree.n)
+    base[idx] = 1000.0 + 50.0 * (np.arange(len(idx)) % 7)
+    leaves = np.flatnonzero(base)
+    pick = leaves[::5]
+    rows = [base]
+    for f in np.geomspace(0.02, 4.0, 300):
+        r = base.copy()
+        r[pick] *= 1.0 + f
+        rows.append(r)
+    n = len(rows)
+    ptr = np.arange(n + 1, dtype=np.int64) * len(leaves)
+    idx = np.tile(leaves, n).astype(np.int64)
+    val = np.concatenate([r[leaves] for r in rows])
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=4)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    assert plan.info.precision == L.PRECISION_FIXED32
+    got = plan.run_host()
+    queued, cap = plan.refined_pairs()
+    checked, failed, worst = plan.audit()
+    uniform, found, chk, headroom = plan.audit_detail()
+    plan.close()
+    assert 0 < queued < len(want)                       # the ladder starts under the bound ...
+    assert found > 0 and chk == min(found, 4096)        # ... passes through the band just above it ...
+    assert 1.0 <= headroom < 1.25                       # ... and the smallest headroom of the run is in that band
+    assert checked == uniform + chk and failed == 0 and worst <= 0.5e-6
+    assert rel_err(got, want).max() <= WEIGHTED_RTOL
+    # the risk list is per RUN: a second run of the same plan reports the same band (not twice as many)
+    plan = ff.Plan(nodes, True, precision="fixed32")
+    plan.run_host()
+    plan.run_host()
+    assert plan.audit_detail()[1] == found
+    plan.close()
