@@ -38,7 +38,7 @@ class ff_problem(ctypes.Structure):
 
 class ff_options(ctypes.Structure):
     _fields_ = [("weighted", c_int32), ("precision", c_int32), ("device", c_int32),
-                ("rank", c_int32), ("world", c_int32), ("reserved", c_int32 * 3)]
+                ("rank", c_int32), ("world", c_int32), ("flags", c_int32), ("reserved", c_int32 * 2)]
 
 
 class ff_plan_info(ctypes.Structure):
@@ -56,7 +56,9 @@ class ff_plan_info(ctypes.Structure):
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
 
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
-                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel"}
+                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel", 6: "pair_walk_kernel"}
+FLAG_UNSORTED_WALK = 1
+L_REFERENCE = 2
 
 
 # name -> (restype, argtypes); exactly the symbols include/frackyfrac_amd.h declares

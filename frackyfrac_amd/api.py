@@ -18,7 +18,8 @@ from . import _lib as L
 from ._lib import FFError, ff_options, ff_plan_info, ff_problem
 
 
-def _opts(weighted: bool, precision="auto", device: int = -1, rank: int = 0, world: int = 1) -> ff_options:
+def _opts(weighted: bool, precision="auto", device: int = -1, rank: int = 0, world: int = 1,
+          unsorted_walk: bool = False) -> ff_options:
     o = ff_options()
     L.lib().ff_options_default(ctypes.byref(o))
     o.weighted = 1 if weighted else 0
@@ -26,7 +27,16 @@ def _opts(weighted: bool, precision="auto", device: int = -1, rank: int = 0, wor
     o.device = device
     o.rank = rank
     o.world = world
+    o.flags = L.FLAG_UNSORTED_WALK if unsorted_walk else 0
     return o
+
+
+def _l_mode(leave_unnormalized) -> int:
+    """The -l argument of the entry points that flatten: False / True, or "reference" for what the reference really
+    does under -l -- lists neither divided nor SORTED (unifrac.go:57-59,108-110; FF_L_REFERENCE)."""
+    if leave_unnormalized == "reference":
+        return L.L_REFERENCE
+    return 1 if leave_unnormalized else 0
 
 
 def num_pairs(n: int) -> int:
@@ -226,7 +236,7 @@ class FlatNodes:
 def flatten(table: Table, tree: Tree, leave_unnormalized: bool = False) -> FlatNodes:
     """Stage A (unifrac.go:32-67,99-116) on the host."""
     h, err = ctypes.c_void_p(), L.errbuf()
-    L.check(L.lib().ff_flatten(table._h, tree._h, 1 if leave_unnormalized else 0, ctypes.byref(h), err, L.ERRLEN), err)
+    L.check(L.lib().ff_flatten(table._h, tree._h, _l_mode(leave_unnormalized), ctypes.byref(h), err, L.ERRLEN), err)
     return FlatNodes._from_handle(h)
 
 
@@ -236,7 +246,7 @@ def flatten_leaf_csr(tree: Tree, leaf_ptr, leaf_idx, leaf_val, leave_unnormalize
     leaf_val = np.ascontiguousarray(leaf_val, dtype=np.float64)
     h, err = ctypes.c_void_p(), L.errbuf()
     L.check(L.lib().ff_flatten_leaf_csr(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data, leaf_idx.ctypes.data,
-                                        leaf_val.ctypes.data, 1 if leave_unnormalized else 0,
+                                        leaf_val.ctypes.data, _l_mode(leave_unnormalized),
                                         ctypes.byref(h), err, L.ERRLEN), err)
     return FlatNodes._from_handle(h)
 
@@ -248,20 +258,20 @@ def flatten_device(tree: Tree, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized:
     leaf_val = np.ascontiguousarray(leaf_val, dtype=np.float64)
     h, err = ctypes.c_void_p(), L.errbuf()
     L.check(L.lib().ff_flatten_device(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data, leaf_idx.ctypes.data,
-                                      leaf_val.ctypes.data, 1 if leave_unnormalized else 0,
+                                      leaf_val.ctypes.data, _l_mode(leave_unnormalized),
                                       ctypes.byref(h), err, L.ERRLEN), err)
     return FlatNodes._from_handle(h)
 
 
 def unifrac_dists(nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1,
-                  rank: int = 0, world: int = 1, out: Optional[np.ndarray] = None) -> np.ndarray:
+                  rank: int = 0, world: int = 1, out: Optional[np.ndarray] = None, unsorted_walk: bool = False) -> np.ndarray:
     """unifracDists (frcfrc/unifrac.go:209): all pair distances of this shard in
     IterPairs order, computed on the GPU.  Returns the full-length array; slots
     outside the shard keep NaN (or the contents of `out`)."""
     n = nodes.n_samples
     if out is None:
         out = np.full(num_pairs(n), np.nan, dtype=np.float64)
-    p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+    p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world, unsorted_walk), L.errbuf()
     L.check(L.lib().ff_unifrac_dists(ctypes.byref(p), ctypes.byref(o), out.ctypes.data, err, L.ERRLEN), err)
     return out
 
@@ -345,7 +355,7 @@ def unifrac(table: Table, tree: Tree, weighted: bool, leave_unnormalized: bool =
     """unifrac (frcfrc/unifrac.go:97): flatten on the host, distances on the GPU."""
     out = np.full(num_pairs(len(table)), np.nan, dtype=np.float64)
     o, err = _opts(weighted, precision, device), L.errbuf()
-    L.check(L.lib().ff_unifrac(table._h, tree._h, ctypes.byref(o), 1 if leave_unnormalized else 0,
+    L.check(L.lib().ff_unifrac(table._h, tree._h, ctypes.byref(o), _l_mode(leave_unnormalized),
                                out.ctypes.data, err, L.ERRLEN), err)
     return out
 
@@ -354,9 +364,9 @@ class Plan:
     """Staged inputs resident in HBM + tile schedule (ff_plan)."""
 
     def __init__(self, nodes: Optional[FlatNodes], weighted: bool, precision="auto", device: int = -1,
-                 rank: int = 0, world: int = 1, _handle=None):
+                 rank: int = 0, world: int = 1, _handle=None, unsorted_walk: bool = False):
         if _handle is None:
-            p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world), L.errbuf()
+            p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world, unsorted_walk), L.errbuf()
             self._h = ctypes.c_void_p()
             L.check(L.lib().ff_plan_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(self._h), err, L.ERRLEN), err)
         else:
@@ -374,7 +384,7 @@ class Plan:
         o, err, h = _opts(weighted, precision, device, rank, world), L.errbuf(), ctypes.c_void_p()
         L.check(L.lib().ff_plan_create_from_leaves(tree._h, len(leaf_ptr) - 1, leaf_ptr.ctypes.data,
                                                    leaf_idx.ctypes.data, leaf_val.ctypes.data,
-                                                   1 if leave_unnormalized else 0, ctypes.byref(o),
+                                                   _l_mode(leave_unnormalized), ctypes.byref(o),
                                                    ctypes.byref(h), err, L.ERRLEN), err)
         return cls(None, weighted, _handle=h)
 

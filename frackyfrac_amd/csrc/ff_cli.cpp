@@ -30,6 +30,7 @@ void usage()
     fputs("  -gpus int\n    \tNumber of GPUs to shard the pair space over (default 1)\n", stderr);
     fputs("  -i string\n    \tPath to input file (default stdin)\n", stderr);
     fputs("  -l\tLeave abundance values unnormalized (default normalize each sample to sum up to 1)\n", stderr);
+    fputs("  -l-compat\n    \tWith -l: the reference's own -l, whose lists stay unsorted (its values, bit for bit)\n", stderr);
     fputs("  -o string\n    \tPath to output file (default stdout)\n", stderr);
     fputs("  -p int\n    \tNumber of threads (default 1)\n", stderr);
     fputs("  -precision string\n    \tDevice arithmetic: auto, fixed32 or exact64 (default \"auto\")\n", stderr);
@@ -47,7 +48,7 @@ int die(const char *msg)
 
 struct Flags {
     std::string in, out, tree, precision = "auto";
-    bool weighted = false, sparse = false, nnorm = false, stats = false;
+    bool weighted = false, sparse = false, nnorm = false, stats = false, lcompat = false;
     long nt = 1, gpus = 1;
 };
 
@@ -93,7 +94,7 @@ int parse_flags(int argc, char **argv, Flags *f)
             return 2;
         }
         bool *bp = name == "w" ? &f->weighted : name == "s" ? &f->sparse : name == "l" ? &f->nnorm
-                   : name == "stats" ? &f->stats : nullptr;
+                   : name == "stats" ? &f->stats : name == "l-compat" ? &f->lcompat : nullptr;
         if (bp) {
             if (has_value) {
                 if (!parse_bool(value, bp)) {
@@ -176,6 +177,10 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         return die(m);
     }
     if (f.nnorm && !f.weighted) return die("-l can only be used with weighted unifrac");  // :84-86
+    // The reference's -l skips normalizeFlatNodes and with it the SORT of the lists (unifrac.go:57-59,108-110), so its
+    // merge walk mis-pairs branches.  -l alone gives the evidently intended values (sorted lists, raw
+    // abundances); -l -l-compat the reference's own, bit for bit (FF_L_REFERENCE: unsorted lists, the literal walk).
+    if (f.lcompat && !f.nnorm) return die("-l-compat can only be used with -l");
     if (f.gpus < 1 || f.gpus > 64) {
         char m[64];
         snprintf(m, sizeof m, "bad number of GPUs: %ld", f.gpus);
@@ -278,7 +283,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         ff_options o = opt;
         o.device = (int32_t)(g % ndev);
         runners.emplace_back(new ff::ShardRunner(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
-                                                 f.nnorm ? 1 : 0, o));
+                                                 f.nnorm ? (f.lcompat ? FF_L_REFERENCE : 1) : 0, o));
     }
     std::vector<std::vector<double>> sets[2] = {std::vector<std::vector<double>>((size_t)G),
                                                 std::vector<std::vector<double>>((size_t)G)};

@@ -124,6 +124,7 @@ struct ff_plan {
     XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
     int x_tile_h = 0;  // EXACT64 tile height in use (0: not chosen yet)
+    bool walk = false;  // FF_FLAG_UNSORTED_WALK: no staging at all, pair_walk_kernel over the flat nodes as they stand
     // EXACT64 unweighted (pair_exact_unw_kernel): presence bits, lengths by staged row, tiles
     bool xu = false;
     uint32_t *d_Xbits = nullptr;
@@ -191,7 +192,7 @@ unsigned host_threads(int64_t work)
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, hw), work / 2000000));
 }
 
-int validate_problem(const ff_problem *p, char *err, size_t errlen)
+int validate_problem(const ff_problem *p, char *err, size_t errlen, bool unsorted_ok = false)
 {
     if (!p) return ff::fail(FF_ERR_ARG, err, errlen, "null problem");
     if (p->n_samples < 0 || p->n_branches < 0 || p->n_branches > (int64_t)INT32_MAX - 64)
@@ -219,7 +220,7 @@ int validate_problem(const ff_problem *p, char *err, size_t errlen)
                 const int32_t id = p->branch_id[t];
                 int kind = 0;
                 if (id < 0 || id >= p->n_branches) kind = 1;
-                else if (t > b && id <= p->branch_id[t - 1]) kind = 2;
+                else if (!unsorted_ok && t > b && id <= p->branch_id[t - 1]) kind = 2;
                 else if (!(p->abnd[t] > 0) || !std::isfinite(p->abnd[t])) kind = 3;
                 if (kind) {
                     bad_sample[th] = s;
@@ -1143,6 +1144,7 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
 
 int schedule_for_shard(ff_plan *pl, char *err, size_t errlen)
 {
+    if (pl->walk) return FF_OK;  // (a grid-stride loop over the shard's slots: nothing to build)
     int rc = pl->mfma ? schedule_mfma(pl, err, errlen)
              : pl->info.precision == FF_PRECISION_FIXED32 ? schedule_sad(pl, err, errlen)
                                                           : schedule_exact64(pl, err, errlen);
@@ -1529,6 +1531,21 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     c->d_ids = nullptr;
     c->d_abnd = nullptr;
 
+    if (o->flags & FF_FLAG_UNSORTED_WALK) {
+        // nothing to stage: the walk reads the flat nodes as they stand, and every reformulation above (dense rows,
+        // integer sums, presence bits) assumes lists a merge pairs up correctly
+        pl->walk = true;
+        inf.n_rows = B;
+        inf.rows_padded = B;
+        inf.precision = FF_PRECISION_EXACT64;
+        inf.kernel = FF_KERNEL_WALK_F64;
+        inf.staged_bytes = 12.0 * (double)c->nnz;
+        inf.n_tiles = inf.n_items = 0;
+        inf.n_wave_slots = (int64_t)inf.n_compute_units * 8 * 4;
+        inf.elements = 0;
+        FF_HIP(hipDeviceSynchronize());
+        return FF_OK;
+    }
     StageCtx x;
     x.o = o;
     x.c = c;
@@ -1632,6 +1649,14 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         ev0 = pl->events[pl->events_used].first;
         ev1 = pl->events[pl->events_used].second;
         ++pl->events_used;
+    }
+    if (pl->walk) {
+        if (timed) FF_HIP(hipEventRecord(ev0, st));
+        pair_walk_kernel<<<dim3((unsigned)std::min<int64_t>((n_slots + 255) / 256, (int64_t)inf.n_compute_units * 8)), dim3(256), 0, st>>>(
+            pl->d_indptr, pl->d_ids, pl->d_abnd, pl->d_len, pl->weighted, inf.slot_begin, n_slots, d_out);
+        if (timed) FF_HIP(hipEventRecord(ev1, st));
+        FF_HIP(hipGetLastError());
+        return FF_OK;
     }
     if (inf.precision == FF_PRECISION_FIXED32) {
         FinishArgs fin;
@@ -1790,7 +1815,8 @@ int ff_plan_create(const ff_problem *p, const ff_options *o, ff_plan **plan, cha
         return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", o->rank, o->world);
     if (o->precision < FF_PRECISION_AUTO || o->precision > FF_PRECISION_EXACT64)
         return ff::fail(FF_ERR_ARG, err, errlen, "bad precision %d", o->precision);
-    int rc = validate_problem(p, err, errlen);
+    if ((o->flags & ~FF_FLAG_UNSORTED_WALK) != 0) return ff::fail(FF_ERR_ARG, err, errlen, "unknown flags %d", o->flags);
+    int rc = validate_problem(p, err, errlen, (o->flags & FF_FLAG_UNSORTED_WALK) != 0);
     if (rc) return rc;
     auto *pl = new ff_plan();
     rc = plan_create_impl(p, o, pl, err, errlen);
@@ -2161,7 +2187,7 @@ int ff_unifrac_dists_stream(const ff_problem *p, const ff_options *o, int64_t ma
     if (base.world < 1 || base.rank < 0 || base.rank >= base.world)
         return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", base.rank, base.world);
     if (max_pairs <= 0) max_pairs = (int64_t)1 << 25;
-    int rc = validate_problem(p, err, errlen);
+    int rc = validate_problem(p, err, errlen, (base.flags & FF_FLAG_UNSORTED_WALK) != 0);
     if (rc) return rc;
     int64_t rb = 0, re = 0;
     if (ff_shard_rows(p->n_samples, base.rank, base.world, &rb, &re) != FF_OK)
@@ -2241,6 +2267,8 @@ int ff_flatten_device(const ff_tree *tree, int64_t n_samples, const int64_t *lea
 {
     if (!tree || !leaf_ptr || !flat || n_samples < 0 || (leaf_ptr[n_samples] > 0 && (!leaf_idx || !leaf_val)))
         return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten_device: bad argument");
+    if (leave_unnormalized == FF_L_REFERENCE)  // (the recursion's order is made on the host)
+        return ff_flatten_leaf_csr(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, leave_unnormalized, flat, err, errlen);
     ff_options o;
     ff_options_default(&o);
     ff_plan tmp;  // only to run the device checks of plan_begin
@@ -2300,14 +2328,24 @@ int ff_plan_create_from_leaves(const ff_tree *tree, int64_t n_samples, const int
     const int64_t B = (int64_t)tree->size.size();
     if (B > (int64_t)INT32_MAX - 64 || n_samples > (int64_t)1 << 22)
         return ff::fail(FF_ERR_ARG, err, errlen, "bad problem size N=%lld B=%lld", (long long)n_samples, (long long)B);
+    if (leave_unnormalized < 0 || leave_unnormalized > FF_L_REFERENCE)
+        return ff::fail(FF_ERR_ARG, err, errlen, "leave_unnormalized must be 0, 1 or FF_L_REFERENCE");
+    // FF_L_REFERENCE: the lists as the reference's -l leaves them (unsorted) and the literal walk over them
+    ff_options o_walk = *o;
+    const bool reference_l = leave_unnormalized == FF_L_REFERENCE;
+    if (reference_l) {
+        o_walk.flags |= FF_FLAG_UNSORTED_WALK;
+        o = &o_walk;
+    }
     auto *pl = new ff_plan();
     hipDeviceProp_t prop;
     int rc = plan_begin(o, n_samples, B, pl, &prop, err, errlen);
     DeviceCsr c;
     if (rc == FF_OK) {
-        bool too_deep = false;
-        rc = csr_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized, &c, &too_deep, err,
-                             errlen);
+        bool too_deep = reference_l;  // (the recursion's order is made on the host)
+        if (!reference_l)
+            rc = csr_from_leaves(tree, n_samples, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized, &c, &too_deep, err,
+                                 errlen);
         if (too_deep) {  // a caterpillar: flatten on the host instead
             c.release();
             ff_flat *flat = nullptr;

@@ -23,8 +23,11 @@ namespace {
 
 // One sample: leaf values already scattered into val[] (zero elsewhere).
 // Appends (id, abundance) with abundance > 0 in ascending id.  `sum` is scratch [B].
+// post_order (may be null): emit in THAT order instead -- what the reference's lists look like under -l, where
+// normalizeFlatNodes is skipped together with its sort (unifrac.go:57-59,108-110) and the recursion's own order,
+// children before their parent, stays.
 void flatten_one(const ff_tree &t, const double *val, double *sum, bool normalize,
-                 std::vector<int32_t> *ids, std::vector<double> *ab)
+                 std::vector<int32_t> *ids, std::vector<double> *ab, const std::vector<int32_t> *post_order = nullptr)
 {
     const int64_t B = (int64_t)t.size.size();
     for (int64_t id = B - 1; id >= 0; --id) {
@@ -39,6 +42,14 @@ void flatten_one(const ff_tree &t, const double *val, double *sum, bool normaliz
     }
     size_t first = ids->size();
     double total = 0.0;
+    if (post_order) {
+        for (int32_t id : *post_order)
+            if (sum[id] > 0) {  // :49-51, appended when the recursion returns from the node
+                ids->push_back(id);
+                ab->push_back(sum[id]);
+            }
+        return;
+    }
     for (int64_t id = 0; id < B; ++id)
         if (sum[id] > 0) {  // :49-51
             ids->push_back((int32_t)id);
@@ -50,10 +61,29 @@ void flatten_one(const ff_tree &t, const double *val, double *sum, bool normaliz
 }
 
 int flatten_impl(const ff_tree &t, int64_t ns, const int64_t *leaf_ptr, const int64_t *leaf_idx,
-                 const double *leaf_val, bool normalize, unsigned threads, ff_flat **out,
+                 const double *leaf_val, bool normalize, bool reference_l_order, unsigned threads, ff_flat **out,
                  char *err, size_t errlen)
 {
     const int64_t B = (int64_t)t.size.size();
+    // the order in which abundanceToFlatNodes' recursion appends (unifrac.go:35-52): a node after its subtree
+    std::vector<int32_t> post_order;
+    if (reference_l_order && B > 0 && B <= INT32_MAX) {
+        post_order.reserve((size_t)B);
+        std::vector<std::pair<int64_t, int64_t>> st;  // (node, next child to visit)
+        st.push_back({0, 1});
+        while (!st.empty()) {
+            auto &top = st.back();
+            const int64_t id = top.first, end = id + t.size[(size_t)id];
+            if (top.second < end) {
+                const int64_t c = top.second;
+                top.second = c + t.size[(size_t)c];
+                st.push_back({c, c + 1});
+            } else {
+                post_order.push_back((int32_t)id);
+                st.pop_back();
+            }
+        }
+    }
     if (B > INT32_MAX) return ff::fail(FF_ERR_ARG, err, errlen, "tree has too many nodes (%lld)", (long long)B);
     for (int64_t k = 0; k < leaf_ptr[ns]; ++k)
         if (leaf_idx[k] < 0 || leaf_idx[k] >= B)
@@ -77,7 +107,7 @@ int flatten_impl(const ff_tree &t, int64_t ns, const int64_t *leaf_ptr, const in
         for (int64_t s = b; s < e; ++s) {
             for (int64_t k = leaf_ptr[s]; k < leaf_ptr[s + 1]; ++k) val[(size_t)leaf_idx[k]] = leaf_val[k];
             size_t before = p.ids.size();
-            flatten_one(t, val.data(), sum.data(), normalize, &p.ids, &p.ab);
+            flatten_one(t, val.data(), sum.data(), normalize, &p.ids, &p.ab, reference_l_order ? &post_order : nullptr);
             p.cnt.push_back((int64_t)(p.ids.size() - before));
             for (int64_t k = leaf_ptr[s]; k < leaf_ptr[s + 1]; ++k) val[(size_t)leaf_idx[k]] = 0.0;
         }
@@ -173,7 +203,9 @@ int ff_flatten_leaf_csr(const ff_tree *tree, int64_t ns, const int64_t *leaf_ptr
     if (!tree || !leaf_ptr || !flat || ns < 0 || (leaf_ptr[ns] > 0 && (!leaf_idx || !leaf_val)))
         return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten_leaf_csr: bad argument");
     unsigned hw = std::thread::hardware_concurrency();
-    return flatten_impl(*tree, ns, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized,
+    if (leave_unnormalized < 0 || leave_unnormalized > FF_L_REFERENCE)
+        return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten_leaf_csr: leave_unnormalized must be 0, 1 or FF_L_REFERENCE");
+    return flatten_impl(*tree, ns, leaf_ptr, leaf_idx, leaf_val, !leave_unnormalized, leave_unnormalized == FF_L_REFERENCE,
                         ff::clamp_threads(hw ? (int)hw : 1), flat, err, errlen);
 }
 

@@ -188,6 +188,43 @@ __global__ void reset_counters_kernel(unsigned long long *__restrict__ counters)
 // of a table in LDS; then one wave adds up the table's column for each of the reference's two sums, in order.  Same
 // terms, same order, same bits (x + 0.0 = x); what is left of the waiting is the chain of additions itself.
 // Longer queues keep one thread per pair (more pairs in flight than workgroups could hold).
+// unifracDistWeighted / unifracDistUnweighted (unifrac.go:144-205) as written: two pointers, three cases, the tails;
+// a = sample si (the higher index: IterPairs yields {s[i], s[j]}, common.go:24-26), b = sample sj.
+__device__ __forceinline__ double literal_walk(int64_t si, int64_t sj, const int64_t *__restrict__ indptr,
+                                               const int32_t *__restrict__ branch_id, const double *__restrict__ abnd,
+                                               const double *__restrict__ tree_dists, int weighted)
+{
+    int64_t i = indptr[si], ie = indptr[si + 1];
+    int64_t j = indptr[sj], je = indptr[sj + 1];
+    double x = 0.0, y = 0.0;                      // numer/denom or result/common
+    while (i < ie && j < je) {
+        const int32_t ia = branch_id[i], ib = branch_id[j];
+        if (ia < ib) {
+            const double l = tree_dists[ia];
+            if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
+            ++i;
+        } else if (ia > ib) {
+            const double l = tree_dists[ib];
+            if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
+            ++j;
+        } else {
+            const double l = tree_dists[ia];
+            if (weighted) { x += l * fabs(abnd[i] - abnd[j]); y += l * (abnd[i] + abnd[j]); } else { y += l; }
+            ++i;
+            ++j;
+        }
+    }
+    for (; i < ie; ++i) {
+        const double l = tree_dists[branch_id[i]];
+        if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
+    }
+    for (; j < je; ++j) {
+        const double l = tree_dists[branch_id[j]];
+        if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
+    }
+    return weighted ? x / y : x / (x + y);
+}
+
 constexpr int REFINE_THREADS = 256;
 constexpr int REFINE_WINDOW = 1024;                 // ids of each list in LDS at a time
 constexpr int REFINE_BATCH = 32;                    // table entries an adding wave reads at a time
@@ -364,35 +401,22 @@ void refine_exact_kernel(const unsigned long long *__restrict__ refine_list,
         const int64_t t = (int64_t)refine_list[q];
         int64_t si, sj;
         slot_to_pair(slot_begin + t, &si, &sj);
-        int64_t i = indptr[si], ie = indptr[si + 1];  // a = sample i (the higher index)
-        int64_t j = indptr[sj], je = indptr[sj + 1];  // b = sample j
-        double x = 0.0, y = 0.0;                      // numer/denom or result/common
-        while (i < ie && j < je) {
-            const int32_t ia = branch_id[i], ib = branch_id[j];
-            if (ia < ib) {
-                const double l = tree_dists[ia];
-                if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
-                ++i;
-            } else if (ia > ib) {
-                const double l = tree_dists[ib];
-                if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
-                ++j;
-            } else {
-                const double l = tree_dists[ia];
-                if (weighted) { x += l * fabs(abnd[i] - abnd[j]); y += l * (abnd[i] + abnd[j]); } else { y += l; }
-                ++i;
-                ++j;
-            }
-        }
-        for (; i < ie; ++i) {
-            const double l = tree_dists[branch_id[i]];
-            if (weighted) { x += l * abnd[i]; y += l * abnd[i]; } else { x += l; }
-        }
-        for (; j < je; ++j) {
-            const double l = tree_dists[branch_id[j]];
-            if (weighted) { x += l * abnd[j]; y += l * abnd[j]; } else { x += l; }
-        }
-        out[t] = weighted ? x / y : x / (x + y);
+        out[t] = literal_walk(si, sj, indptr, branch_id, abnd, tree_dists, weighted);
+    }
+}
+
+// The reference's driver as it stands (unifrac.go:209-228): every pair of the shard by the literal walk, a thread
+// per pair.  For lists that are NOT ascending -- what the reference's -l leaves behind (FF_FLAG_UNSORTED_WALK): the
+// walk's result then depends on the order of the lists, and no reformulation of it exists.
+__global__ __launch_bounds__(256)
+void pair_walk_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                      const double *__restrict__ abnd, const double *__restrict__ tree_dists, int weighted,
+                      int64_t slot_begin, int64_t n_slots, double *__restrict__ out)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t si, sj;
+        slot_to_pair(slot_begin + t, &si, &sj);
+        out[t] = literal_walk(si, sj, indptr, branch_id, abnd, tree_dists, weighted);
     }
 }
 

@@ -90,8 +90,19 @@ typedef struct ff_options {
     int32_t device;       /* HIP device ordinal; -1 = current device                          */
     int32_t rank;         /* pair-space shard: this process computes the rows of shard `rank` */
     int32_t world;        /* of `world` equal-work shards (1 = everything); see ff_shard_rows */
-    int32_t reserved[3];  /* must be 0                                                        */
+    int32_t flags;        /* FF_FLAG_*                                                        */
+    int32_t reserved[2];  /* must be 0                                                        */
 } ff_options;
+
+/* ff_options.flags.
+ * FF_FLAG_UNSORTED_WALK: the lists of the problem are NOT ascending in branch id and the distance of a
+ * pair is whatever the reference's two-pointer merge (unifrac.go:148-167, 178-203) makes of them as they
+ * stand.  That is what frcfrc -l computes in the reference: with -l it skips normalizeFlatNodes and, with
+ * it, the sort (unifrac.go:57-59,108-110), so the lists stay in the recursion's post-order and the merge
+ * mis-pairs branches.  This engine's -l sorts; with this flag (leave_unnormalized =
+ * FF_L_REFERENCE in the entry points that flatten, `frcfrc -l -l-compat`) it reproduces the reference
+ * bit for bit instead: one thread per pair walks the two lists literally, in binary64. */
+#define FF_FLAG_UNSORTED_WALK 1
 
 /* Fills *o with the defaults: unweighted, AUTO, current device, rank 0 of 1. */
 void ff_options_default(ff_options *o);
@@ -210,9 +221,11 @@ typedef enum ff_kernel {
                                      none of a tile's 32 samples has a flat node (sparse tables)   */
     FF_KERNEL_MFMA_I8_SMALL = 4,  /* pair_common_small_kernel: as MFMA_I8 for a shard smaller than one round
                                      of it (few hundred samples): 32 x 32 tiles, one launch per pass     */
-    FF_KERNEL_EXACT_F64_UNW = 5   /* pair_exact_unw_kernel: EXACT64 unweighted from presence bits -- the
+    FF_KERNEL_EXACT_F64_UNW = 5,  /* pair_exact_unw_kernel: EXACT64 unweighted from presence bits -- the
                                      reference's two chains of binary64 additions per pair and no other
                                      arithmetic (unifrac.go:144-171)                                      */
+    FF_KERNEL_WALK_F64 = 6        /* pair_walk_kernel: the reference's merge walk itself, a thread per pair,
+                                     over lists as they stand (FF_FLAG_UNSORTED_WALK)                     */
 } ff_kernel;
 
 /* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM
@@ -375,9 +388,14 @@ int ff_validate_species(const ff_table *table, const ff_tree *tree, char *err, s
 
 /* Stage A (frcfrc/unifrac.go:32-67,99-116) on the host: abundanceToFlatNodes +
  * normalizeFlatNodes for every sample, in the reference's order of float
- * additions.  leave_unnormalized = the -l flag (frcfrc.go:25): lists are sorted
- * but not divided (the reference also skips the sort, SURVEY.md Q2 -- a defect
- * this engine does not reproduce). */
+ * additions.  leave_unnormalized = the -l flag (frcfrc.go:25): 1 = lists are sorted
+ * but not divided (the evidently intended semantics); FF_L_REFERENCE = what the
+ * reference really does under -l: neither divided NOR SORTED (it skips the sort with
+ * the division, unifrac.go:57-59,108-110), i.e. every list in the
+ * order the recursion appends it, a node after its subtree.  Lists in that order
+ * go with FF_FLAG_UNSORTED_WALK; ff_unifrac and ff_plan_create_from_leaves set it
+ * themselves when given FF_L_REFERENCE. */
+#define FF_L_REFERENCE 2
 typedef struct ff_flat ff_flat; /* owns the CSR arrays an ff_problem points into */
 int ff_flatten(const ff_table *table, const ff_tree *tree, int leave_unnormalized,
                ff_flat **flat, char *err, size_t errlen);

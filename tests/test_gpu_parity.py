@@ -384,6 +384,51 @@ def test_leave_unnormalized_flag():
     assert rel_err(ff.unifrac_dists(nodes, True, precision="fixed32"), want) <= WEIGHTED_RTOL
 
 
+def test_l_as_the_reference_computes_it(tmp_path):
+    """The reference's own -l: lists neither divided NOR SORTED (unifrac.go:57-59,108-110), so its merge
+    walk mis-pairs branches.  The engine's -l sorts; behind a switch -- leave_unnormalized="reference" /
+    FF_FLAG_UNSORTED_WALK / `frcfrc -w -l -l-compat` -- it reproduces the reference instead, bit for bit: the lists
+    as the recursion leaves them and the literal two-pointer walk (pair_walk_kernel).  Checked against the oracle's
+    restatement of that quirk; the two -l's differ (the switch bites); shards tile the result; the command prints it."""
+    tree, ptr, idx, val = synth.make(90, 400, 0.15, 23)
+    T = ff.parse_newick(tree.newick())
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 1)            # reference -l: post-order, raw
+    want = O.unifrac_dists(ip, on, ft.dist, True)
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val, leave_unnormalized="reference")
+    got = ff.unifrac_dists(nodes, True, unsorted_walk=True)
+    assert np.array_equal(got, want)
+    with pytest.raises(ff.FFError):                              # such lists are not a problem the other paths accept
+        ff.unifrac_dists(nodes, True)
+    # stage A inside the call (ff_plan_create_from_leaves with FF_L_REFERENCE), in shards
+    parts = []
+    for rank in range(3):
+        plan = ff.Plan.from_leaves(T, ptr, idx, val, True, leave_unnormalized="reference", rank=rank, world=3)
+        assert plan.info.kernel == 6 and plan.info.precision == 2
+        parts.append(plan.run_host())
+        plan.close()
+    assert np.array_equal(np.concatenate(parts), want)
+    # the intended -l is something else
+    ip2, on2 = O.flatten_samples(ft, ptr, idx, val, 2)
+    sorted_l = O.unifrac_dists(ip2, on2, ft.dist, True)
+    assert np.array_equal(ff.unifrac_dists(ff.flatten_leaf_csr(T, ptr, idx, val, leave_unnormalized=True), True,
+                                           precision="exact64"), sorted_l)
+    assert not np.array_equal(sorted_l, want)
+    # the command
+    (tmp_path / "t.tree").write_text(tree.newick())
+    lines = [" ".join("%s:%s" % (tree.names[idx[k]], repr(float(val[k]))) for k in range(ptr[s], ptr[s + 1]))
+             for s in range(len(ptr) - 1)]
+    (tmp_path / "t.sparse").write_text("\n".join(lines) + "\n")
+    for flags, expect in ((["-l", "-l-compat"], want), (["-l"], sorted_l)):
+        out = tmp_path / "out.txt"
+        r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", *flags, "-i", str(tmp_path / "t.sparse"), "-t", str(tmp_path / "t.tree"),
+                            "-o", str(out), "-precision", "exact64"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert out.read_text() == O.format_output(expect), flags
+    r = subprocess.run([L.FRCFRC_PATH, "-w", "-l-compat", "-t", str(tmp_path / "t.tree")], capture_output=True, text=True)
+    assert r.returncode == 2 and "-l-compat can only be used with -l" in r.stderr
+
+
 def test_bad_problems_are_rejected():
     nodes, *_ = synth_problem(4, 8, 0.5, 1)
     bad = ff.FlatNodes(nodes.indptr, nodes.branch_id[::-1].copy(), nodes.abnd, nodes.branch_len)

@@ -196,6 +196,38 @@ def test_stage_a_quirks():
         assert np.array_equal(got.abnd, nodes["abnd"])
 
 
+def test_stage_a_as_the_reference_leaves_it_under_l():
+    """-l in the reference skips normalizeFlatNodes and with it the SORT (unifrac.go:57-59,108-110): the lists stay
+    in the order the recursion appends them, a node after its subtree (unifrac.go:35-52).  leave_unnormalized =
+    "reference" (FF_L_REFERENCE) reproduces those lists: ids, raw values and ORDER as the oracle's mode 1; the same
+    entries as the sorted -l lists, and not ascending once a sample reaches an internal node."""
+    tree = "((a:1,b:0,c:3,a:2)in:1.5,(d:1e-3,(e:7,f:0.1):2)x:0,g:5)r:9;"
+    table = "a:0.1 b:0.7 c:1e-9 in:5\n\ne:3 f:1e10 g:2.5\nd:1\n"
+    t = ff.parse_newick(tree)
+    tb = ff.parse_sparse_abundance(table)
+    got = ff.flatten(tb, t, leave_unnormalized="reference")
+    ft = O.flatten_tree(O.parse_newick(tree))
+    ptr, idx, val = O.leaf_csr(O.parse_sparse_abundance(table), ft)
+    ip, nodes = O.flatten_samples(ft, ptr, idx, val, 1)
+    assert np.array_equal(got.indptr, ip) and np.array_equal(got.branch_id, nodes["id"]) and np.array_equal(got.abnd, nodes["abnd"])
+    srt = ff.flatten(tb, t, leave_unnormalized=True)
+    assert np.array_equal(srt.indptr, got.indptr)
+    unsorted = 0
+    for s in range(len(ip) - 1):
+        a, b = ip[s], ip[s + 1]
+        order = np.argsort(got.branch_id[a:b], kind="stable")
+        assert np.array_equal(got.branch_id[a:b][order], srt.branch_id[a:b]) and np.array_equal(got.abnd[a:b][order], srt.abnd[a:b])
+        unsorted += int(np.any(np.diff(got.branch_id[a:b]) < 0))
+    assert unsorted >= 2
+    # a synthetic table, the leaf-CSR entry point
+    tree2, ptr2, idx2, val2 = synth.make(40, 300, 0.1, 17)
+    T2 = ff.parse_newick(tree2.newick())
+    g2 = ff.flatten_leaf_csr(T2, ptr2, idx2, val2, leave_unnormalized="reference")
+    ft2 = O.FlatTree(tree2.names, tree2.branch_len, tree2.size, tree2.parent)
+    ip2, n2 = O.flatten_samples(ft2, ptr2, idx2, val2, 1)
+    assert np.array_equal(g2.indptr, ip2) and np.array_equal(g2.branch_id, n2["id"]) and np.array_equal(g2.abnd, n2["abnd"])
+
+
 @pytest.mark.parametrize("seed,ns,nl,dens", [(1, 64, 200, 0.1), (2, 33, 1000, 0.02), (3, 8, 50, 0.9)])
 def test_stage_a_synthetic_matches_oracle(seed, ns, nl, dens):
     tree, ptr, idx, val = synth.make(ns, nl, dens, seed)
