@@ -698,19 +698,21 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     inf.n_tiles = (int64_t)tiles.size();
     // 8 waves per workgroup (two per SIMD) for pair_sad_kernel and the sparse-aware kernel, 12 (three per SIMD,
     // paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12 forces one; otherwise
-    // the 12-wave variant takes every shard that BEGINS AT ROW 0 -- a whole problem, a first shard: a triangle --
-    // and holds more than 2.25 tiles per workgroup (3,072 samples up on 256 CUs).  (Round 2 kept it for shards of two
-    // or more rounds of its slots under 2 GB staged: with that round's schedule it lost 1-2 % at 4,096 samples and
-    // on the 3.3 GB matrix of 8,192 x 50k leaves.  With the round-3 schedule it wins on triangles from 3,072 samples
-    // up -- tools/shape_sweep.py with either value: 4,096 samples 4.98 -> 4.91 ms, 5,120 7.96 -> 7.56, 8,192 19.9
-    // -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9; it ties at 2,560 and loses below 2,048.  On the TRAPEZOID of a
-    // later row shard it gains nothing on average and has outliers -- shards 3 and 4 of 8 of 11,584 samples 15 and
-    // 7 % slower with its plain thirds, shard 6 of 8 of 16,384 samples 10.43 against 10.03 ms with sliced halves
-    // (tools/experiments/xcd_variants.py) -- so the ranks of a multi-GPU run, whose slowest sets the
-    // time, keep the 8-wave kernel.)
+    // the 12-wave variant takes
+    //   * a shard that BEGINS AT ROW 0 -- a whole problem, the first rank's shard: a triangle -- and holds more than
+    //     2.25 tiles per workgroup (3,072 samples up on 256 CUs): tools/shape_sweep.py, 4,096 samples 4.98 -> 4.91 ms,
+    //     8,192 19.9 -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9; it ties at 2,560 and loses below 2,048;
+    //   * ANY shard with 200,000 or more (tile, branch row) units per workgroup -- about 11 ms of kernel: on the
+    //     trapezoid of a later row shard the third wave pays once a shard is several rounds long, and not before
+    //     (tools/shard_balance.py at HEAD, profiles/r04_shard_balance.txt, max over ranks in ms, 8 waves / 12 waves:
+    //     C4 over 2 GPUs 40.2 / 38.5, over 4 19.9 / 19.3, over 8 10.12 / 10.42 (one rank 4 % behind the others);
+    //     C5 over 2 50.3 / 48.4, over 4 25.0 / 24.5, over 8 13.06 / 12.73; the weak problem, C3's pairs per rank,
+    //     5.00-5.13 / 5.04-5.26).  Round 3's rule gave the first rank alone the 12-wave kernel whatever the shard's
+    //     size, and said otherwise in this comment.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
-    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() && inf.row_begin == 0 &&
-        inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 9)
+    if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() &&
+        ((inf.row_begin == 0 && inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 9) ||
+         (double)inf.n_tiles * (double)rows >= 200000.0 * (double)pl->n_workgroups))
         pl->waves_per_wg = L_WAVES_PER_WG;
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     const int U = pl->n_workgroups * pl->waves_per_wg;

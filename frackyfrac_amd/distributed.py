@@ -201,8 +201,9 @@ class ShardedRun:
 
     chunks > 1 (default from FF_GATHER_CHUNKS, 1) cuts the rank's shard into that many
     equal-pair sub-shards (shard rank*chunks+c of world*chunks, still contiguous) that
-    run back to back; each finished chunk is handed to RCCL while the next one computes,
-    so only the last chunk's transfer is exposed."""
+    run back to back; each finished sub-shard is on its way to the root -- by the copy
+    engines ("ipc") or by RCCL -- while the next one computes, so only the last
+    sub-shard's transfer is exposed."""
 
     def __init__(self, nodes: api.FlatNodes, weighted: bool, rank: int, world: int,
                  precision="auto", device: Optional[int] = None, root: int = 0, group=None,
@@ -239,7 +240,7 @@ class ShardedRun:
         # torch without a copy; otherwise a plain torch tensor.
         self.full, self._full_buf, self._full_note = None, None, ""
         if rank == root and world > 1:
-            if self.chunks == 1 and transport in ("auto", "ipc"):
+            if transport in ("auto", "ipc"):
                 try:
                     self._full_buf = api.DeviceBuffer(api.num_pairs(self.n_samples), device)
                     self.full = self._full_buf.tensor()
@@ -254,7 +255,7 @@ class ShardedRun:
         self.transport_note = ""
         self.ipc_gbps = None
         self._k = 0
-        if world > 1 and self.chunks == 1 and transport in ("auto", "ipc"):
+        if world > 1 and transport in ("auto", "ipc"):
             if self._setup_ipc():
                 self.transport = "ipc"
             elif transport == "ipc":
@@ -331,6 +332,9 @@ class ShardedRun:
         # bandwidth probe: all peers copy their whole slice at once, as in a step.  A mapping
         # that works but crawls (staged through the host, say) must not beat RCCL to the job.
         gbps = float("inf")
+        # (what a copy of a step moves at once: the rank's first sub-shard -- its whole shard with chunks = 1 --,
+        # which is what self.local holds)
+        a, b = api.shard_slots(self.n_samples, self.rank * self.chunks, self.world * self.chunks)
         try:
             st = torch.cuda.current_stream(self.device).cuda_stream
             if self.rank != self.root and b > a:
@@ -355,33 +359,44 @@ class ShardedRun:
                                            % (gbps, min_gbps))
             return False
         self.side = torch.cuda.Stream(device=self.device)
-        self.locals = [self.local, torch.empty_like(self.local)] if self.rank != self.root else [self.local]
-        self.copy_done = [None, None]
+        if self.chunks == 1:  # two buffers taken in turn: step k + 1's kernels do not wait for step k's copy
+            self.locals = [self.local, torch.empty_like(self.local)] if self.rank != self.root else [self.local]
+        # (chunks > 1: a buffer per sub-shard; sub-shard c of step k + 1 waits for its own copy of step k, which went
+        # out while the sub-shards behind it were still being reduced)
+        self.copy_done = [None] * max(2, self.chunks)
         return True
 
     def _step_ipc(self, timed: bool):
         torch = self.torch
         main = torch.cuda.current_stream(self.device)
-        a, b = api.shard_slots(self.n_samples, self.rank, self.world)
+        C = self.chunks
         if self.rank == self.root:
-            if b > a:  # the root's slice is produced in place
-                self.plan.run(self.full.data_ptr() + 8 * a, main.cuda_stream, timed=timed)
+            for c, p in enumerate(self.plans):  # the root's slice is produced in place
+                a, b = api.shard_slots(self.n_samples, self.rank * C + c, self.world * C)
+                if b > a:
+                    p.run(self.full.data_ptr() + 8 * a, main.cuda_stream, timed=timed)
             return self.full
-        if b <= a:
-            return None
-        q = self._k & 1
-        self._k += 1
-        if self.copy_done[q] is not None:
-            main.wait_event(self.copy_done[q])  # the copy that last read this buffer
-        self.plan.run(self.locals[q].data_ptr(), main.cuda_stream, timed=timed)
-        ready = torch.cuda.Event(enable_timing=True)
-        ready.record(main)
-        self.side.wait_event(ready)
-        api.device_copy_async(self.remote.ptr + 8 * a, self.locals[q].data_ptr(), 8 * (b - a), self.side.cuda_stream)
-        done = torch.cuda.Event(enable_timing=True)
-        done.record(self.side)
-        self.copy_done[q] = done
-        self.gather_events = (ready, done)
+        for c, p in enumerate(self.plans):
+            a, b = api.shard_slots(self.n_samples, self.rank * C + c, self.world * C)
+            if b <= a:
+                continue
+            if C == 1:
+                q = self._k & 1
+                self._k += 1
+            else:
+                q = c
+            if self.copy_done[q] is not None:
+                main.wait_event(self.copy_done[q])  # the copy that last read this buffer
+            p.run(self.locals[q].data_ptr(), main.cuda_stream, timed=timed)
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record(main)
+            self.side.wait_event(ready)
+            # over this rank's own xGMI link, by the copy engines, while its CUs reduce the next sub-shard / step
+            api.device_copy_async(self.remote.ptr + 8 * a, self.locals[q].data_ptr(), 8 * (b - a), self.side.cuda_stream)
+            done = torch.cuda.Event(enable_timing=True)
+            done.record(self.side)
+            self.copy_done[q] = done
+            self.gather_events = (ready, done)
         return None
 
     def sync(self):

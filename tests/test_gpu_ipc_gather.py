@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_samples, transport, q):
+def _worker(rank, world, port, n_samples, transport, q, chunks=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, n_samples, transport, q):
     T = ff.parse_newick(tree.newick())
     nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
     run = ShardedRun(nodes, True, rank, world, precision="fixed32", device=0,
-                     transport=None if transport == "env" else transport)
+                     transport=None if transport == "env" else transport, chunks=chunks)
     if transport in ("auto", "env"):  # fault injected on one rank / switches from the environment: what did every rank take?
         a, b = ff.shard_slots(n_samples, rank, world)
         q.put((rank, run.transport, run.transport_note, run.chunks, run.n_slots == b - a))
@@ -63,14 +63,16 @@ def _worker(rank, world, port, n_samples, transport, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_samples", [(2, 300), (3, 97)])
-def test_ipc_gather_on_one_device(world, n_samples):
+@pytest.mark.parametrize("world,n_samples,chunks", [(2, 300, None), (3, 97, None), (2, 700, 3), (3, 400, 2)])
+def test_ipc_gather_on_one_device(world, n_samples, chunks):
+    """chunks: every rank's shard in that many sub-shards, each copied into the root's array while the next one is
+    reduced (round 4: the ipc transport's own pipelining; until then only the RCCL path had it)."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_samples, "ipc", q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_samples, "ipc", q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -102,7 +104,8 @@ def test_ipc_failure_on_one_rank_makes_every_rank_fall_back(monkeypatch):
     ({"FF_GATHER": "ipc"}, "ipc", 1, ""),
     ({"FF_GATHER": "nccl"}, "nccl", 1, ""),
     ({"FF_GATHER_MIN_GBPS": "1e9"}, "nccl", 1, "too slow"),      # a mapping that crawls must not beat RCCL to the job
-    ({"FF_GATHER_CHUNKS": "3"}, "nccl", 3, ""),                   # sub-shards are the RCCL path's pipelining
+    ({"FF_GATHER_CHUNKS": "3"}, "ipc", 3, ""),                    # sub-shards pipeline either transport
+    ({"FF_GATHER_CHUNKS": "3", "FF_GATHER": "nccl"}, "nccl", 3, ""),
 ])
 def test_gather_switches_from_the_environment(monkeypatch, env, want_transport, want_chunks, note):
     """FF_GATHER / FF_GATHER_MIN_GBPS / FF_GATHER_CHUNKS as a launcher would set them: every rank takes the same

@@ -1011,9 +1011,10 @@ def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
 
 def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
     """A shard that begins at row 0 and holds more than 2.25 pair tiles per workgroup (3,072 samples up on 256 CUs)
-    is scheduled on the 12-wave kernel without any switch being set; a smaller one, and any later row shard (the ranks
-    of a multi-GPU run), on the 8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same
-    distances."""
+    is scheduled on the 12-wave kernel without any switch being set, and so is any shard of 200,000 (tile, branch row)
+    units per workgroup or more; a smaller one, and a later row shard under that size (the ranks of a multi-GPU run on
+    C3's pairs each), on the 8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same
+    distances.  (What each rank of the BASELINE configs takes: test_kernel_choice_per_rank_of_the_baseline_configs.)"""
     small, *_ = synth_problem(2048, 150, 0.2, 79)
     plan = ff.Plan(small, True, precision="fixed32")
     assert plan.info.n_tiles * 4 < 9 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
@@ -1040,6 +1041,34 @@ def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
     for slot in rng.integers(0, len(got), size=50):
         o = O.unifrac_dists(ip, on, ft.dist, True, pair_begin=int(slot), pair_end=int(slot) + 1)[0]
         assert abs(got[slot] - o) <= WEIGHTED_RTOL * o
+
+
+def test_kernel_choice_per_rank_of_the_baseline_configs():
+    """Which weighted pair kernel every rank of a sharded run takes, as measured (tools/shard_balance.py,
+    profiles/r04_shard_balance.txt): the 12-wave kernel for shards of several rounds -- C4 over 2 and 4 GPUs, C5 over
+    2, 4 and 8, first rank or not --, the 8-wave kernel for C4 over 8 and for the weak problem's C3-sized shards
+    (except the first rank's triangle there).  DESIGN 4.1, ff_device.hip schedule_sad and this test say the same."""
+    def waves(nodes, rank, world, plan=None):
+        p = ff.Plan(nodes, True, precision="fixed32", rank=rank, world=world) if plan is None else plan
+        if plan is not None:
+            p.set_shard(rank, world)
+        return p, int(p.info.n_wave_slots // p.info.n_compute_units)
+
+    for name, expect in (("C4", {(2, 0): 12, (2, 1): 12, (4, 3): 12, (8, 0): 12, (8, 5): 8}),
+                         ("C5", {(2, 1): 12, (4, 2): 12, (8, 0): 12, (8, 7): 12})):
+        cfg = synth.CONFIGS[name]
+        nodes, *_ = synth_problem(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+        plan = None
+        for (world, rank), want in expect.items():
+            plan, got = waves(nodes, rank, world, plan)
+            assert got == want, (name, world, rank, got)
+        plan.close()
+    nodes, *_ = synth_problem(11584, 10000, 0.1, synth.CONFIGS["C3"]["seed"])     # the weak problem over 8 GPUs
+    plan = None
+    for rank, want in ((0, 12), (1, 8), (4, 8), (7, 8)):
+        plan, got = waves(nodes, rank, 8, plan)
+        assert got == want, ("weak", rank, got)
+    plan.close()
 
 
 @pytest.mark.parametrize("weighted", [True, False])
