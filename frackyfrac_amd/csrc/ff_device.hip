@@ -178,6 +178,25 @@ template <typename T> struct Scratch {
     hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1)); }
 };
 
+// Makes `device` current for a scope and gives the caller its own device back on every way out.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e == hipSuccess && prev != device) {
+            e = hipSetDevice(device);
+            switched = e == hipSuccess;
+        }
+        return e;
+    }
+    ~DeviceScope()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 int env_int(const char *name, int dflt)
 {
     const auto v = ff::tuning(name);
@@ -1637,9 +1656,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
     const int64_t n_slots = inf.slot_end - inf.slot_begin;
     if (n_slots <= 0) return FF_OK;
     if (!d_out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
-    int cur = -1;
-    FF_HIP(hipGetDevice(&cur));
-    if (cur != pl->device) FF_HIP(hipSetDevice(pl->device));
+    DeviceScope scope;  // (the caller's current device is its own again when this returns: a host that drives several
+    FF_HIP(scope.enter(pl->device));  // plans on several devices from one thread does not find it changed under it)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) {
         if (pl->events_used == pl->events.size()) {

@@ -14,11 +14,12 @@ declare -A ARGS KERN
 ARGS[c3]="--no-cpu-baseline --no-secondary";                         KERN[c3]=pair_sad_kernel
 ARGS[c3_unweighted]="--unweighted --no-cpu-baseline --no-secondary --steps 50"; KERN[c3_unweighted]=pair_common_mfma
 ARGS[c3_unweighted_lognormal]="--unweighted --lengths lognormal --no-cpu-baseline --no-secondary --steps 50"; KERN[c3_unweighted_lognormal]=pair_common_mfma
+ARGS[c3_unweighted_exact]="--unweighted --lengths lognormal --precision auto --no-cpu-baseline --no-secondary --steps 10"; KERN[c3_unweighted_exact]=pair_exact_unw
 ARGS[c3_exact64]="--precision exact64 --steps 5 --no-cpu-baseline --no-secondary"; KERN[c3_exact64]=pair_exact64
 ARGS[c2]="--workload C2 --unweighted --no-cpu-baseline --no-secondary --steps 50"; KERN[c2]=pair_common_small
 ARGS[c4]="--workload C4 --steps 5 --no-cpu-baseline --no-secondary";  KERN[c4]=pair_sad_kernel
 ARGS[c5]="--workload C5 --steps 5 --no-cpu-baseline --no-secondary";  KERN[c5]=pair_sad_kernel
-list=("$@"); [ ${#list[@]} -eq 0 ] && list=(c3 c3_unweighted c3_unweighted_lognormal c3_exact64 c2 c4 c5)
+list=("$@"); [ ${#list[@]} -eq 0 ] && list=(c3 c3_unweighted c3_unweighted_lognormal c3_unweighted_exact c3_exact64 c2 c4 c5)
 cd /tmp && export TMPDIR=/tmp
 for w in "${list[@]}"; do
   echo "== $w: kernel trace"
@@ -27,10 +28,11 @@ for w in "${list[@]}"; do
   cp "$out/$w.trace"/*/*kernel_stats.csv "$out/${w}_kernel_stats.csv"
   if [ "$w" != c3_exact64 ] && [ "$w" != c2 ]; then
     sets=("FETCH_SIZE" "WRITE_SIZE")
-    if [ "$w" = c3 ] || [ "$w" = c3_unweighted ] || [ "$w" = c3_unweighted_lognormal ]; then
+    if [ "$w" = c3 ] || [ "$w" = c3_unweighted ] || [ "$w" = c3_unweighted_lognormal ] || [ "$w" = c3_unweighted_exact ]; then
       sets+=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")
       [ "$w" = c3_unweighted ] || [ "$w" = c3_unweighted_lognormal ] && sets+=("SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MISS_sum")
       [ "$w" = c3 ] && sets+=("SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM TCC_HIT_sum TCC_MISS_sum")
+      [ "$w" = c3_unweighted_exact ] && sets+=("SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVES TCC_HIT_sum TCC_MISS_sum")
     fi
     steps=3; [ "$w" = c4 ] || [ "$w" = c5 ] && steps=2
     a=$(echo "${ARGS[$w]}" | sed -E 's/--steps [0-9]+//')
