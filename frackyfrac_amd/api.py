@@ -5,7 +5,7 @@ Names follow frackyfrac: `unifrac` (frcfrc/unifrac.go:97), `unifrac_dists`
 (parser/parser.go:21,85), `validate_species` (unifrac.go:80), `iter_pairs`
 (common.IterPairs, common/common.go:21).  Everything here is a thin ctypes layer
 over the C ABI (include/frackyfrac_amd.h); the arithmetic happens in the HIP
-kernels of frackyfrac_amd/csrc/ff_device.hip.
+kernels of frackyfrac_amd/csrc/ff_dev_run.hip (C ABI: ff_device.hip).
 """
 from __future__ import annotations
 

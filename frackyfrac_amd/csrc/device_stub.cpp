@@ -1,4 +1,4 @@
-// device_stub.cpp -- stands in for ff_device.hip in the sanitizer build of the HOST code
+// device_stub.cpp -- stands in for ff_device.hip, ff_dev_stage.hip and ff_dev_run.hip in the sanitizer build of the HOST code
 // (make asan): every device entry point fails with FF_ERR_DEVICE.  Never linked into the
 // product library.
 #include "ff_host.hpp"

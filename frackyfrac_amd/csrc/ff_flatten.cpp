@@ -4,7 +4,7 @@
 // per-sample conversion of unifrac() (unifrac.go:99-116): abundanceToFlatNodes
 // (:32-53) followed by normalizeFlatNodes (:56-67).  This is the "post-order
 // accumulation over the tree once on the host" of the design; the pairwise
-// stage B runs on the GPU (ff_device.hip).
+// stage B runs on the GPU (ff_dev_run.hip).
 //
 // The recursion of abundanceToFlatNodes is replaced by one descending-id sweep
 // over the pre-order arrays (children have larger ids than their parent), but

@@ -1,6 +1,7 @@
 // ff_kernels_exact_unw.hpp -- EXACT64 for UNWEIGHTED UniFrac: the reference's two running sums of
 // unifracDistUnweighted (frcfrc/unifrac.go:144-171), bit for bit, from presence BITS.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace.
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 //
 // The reference walks two ascending id lists and does, per id,
 //     result += treeDists[id]    if exactly one sample has it     (:151-152,155-156,163-167)
@@ -158,16 +159,4 @@ void pair_exact_unw_kernel(const uint32_t *__restrict__ Xb, int64_t ldx, const d
     const int i0 = __builtin_amdgcn_readfirstlane(tile.i0), j0 = __builtin_amdgcn_readfirstlane(tile.j0);
     if (__builtin_amdgcn_readfirstlane(tile.jn) == 2) exact_unw_tile<2>(Xb, ldx, len, n_slabs, i0, j0, row_begin, row_end, slot_begin, out);
     else exact_unw_tile<1>(Xb, ldx, len, n_slabs, i0, j0, row_begin, row_end, slot_begin, out);
-}
-
-// Stage the presence bits: one workgroup per sample ORs bit (row & 31) into word [row / 32][s].
-__global__ void stage_xbits_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
-                                   const int32_t *__restrict__ row_of,  // branch id -> staged row (null: identity)
-                                   uint32_t *__restrict__ Xb, int64_t ldx)
-{
-    const int64_t s = blockIdx.x;
-    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
-        const int32_t b = branch_id[t], row = row_of ? row_of[b] : b;
-        atomicOr(&Xb[(int64_t)(row / XU_SLAB) * ldx + s], 1u << (row % XU_SLAB));
-    }
 }

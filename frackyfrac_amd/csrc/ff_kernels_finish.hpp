@@ -1,6 +1,6 @@
 // ff_kernels_finish.hpp -- integer sums -> distances, exact refinement of nearly equal pairs, the EXACT64 pair kernel.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace
-// (one translation unit, so the kernels stay internal and need no relocatable device code).
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
 // Integer sums -> distances: finish_pair (ff_kernels_finish_pair.hpp) for every slot of the shard.  A workgroup
 // takes FINISH_RUN x 256 consecutive slots, thread t of it slots t, t + 256, ...: every access is a wave's

@@ -1,5 +1,5 @@
 // ff_kernels_finish_pair.hpp -- integer sums of ONE pair -> its distance (shared by finish_fixed32_kernel and by the
-// epilogues that finish in place).  A fragment of ff_device.hip: included there, once, inside its anonymous namespace.
+// epilogues that finish in place).  A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace.
 
 // Integer sums -> distances (unifrac.go:169 and :204), IEEE binary64 division.
 //

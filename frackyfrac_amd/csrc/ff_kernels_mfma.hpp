@@ -1,6 +1,6 @@
 // ff_kernels_mfma.hpp -- unweighted UniFrac on the int8 matrix cores: plane staging and the MFMA pair kernel.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace
-// (one translation unit, so the kernels stay internal and need no relocatable device code).
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
 // ---- Unweighted on the matrix cores -------------------------------------------------
 //
@@ -32,7 +32,7 @@
 // and 24+k -- two instructions per dword, no multiply, no dependent chain.  In the MFMA's
 // k-step kt (32 branches: half kt of the slab's word), the lanes of half-wave h hold 16 of them:
 // dword kk, byte q = branch 32*kt + 8*q + 4*h + kk of the slab, and the digit arrays are stored in
-// that order (chunk 2*kt + h, ff_device.hip stage_for_mfma).
+// that order (chunk 2*kt + h, ff_dev_stage.hip stage_for_mfma).
 
 typedef unsigned short mfma_u16x2 __attribute__((ext_vector_type(2)));
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
@@ -56,51 +56,6 @@ constexpr bool M_DIRECT_WORDS = FF_MFMA_DIRECT_WORDS != 0;
 constexpr int M_TABLE_SLABS = 512;  // slabs of digits held in LDS at a time: 64 bytes per plane and slab -- 64 KiB with two
                                     // planes, 96 KiB with the graded sweep's three; a segment's last k-step reads one slab
                                     // past its table (static_assert in the kernel: inside the 128 KiB either way)
-
-// Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,
-// 65,536 branch rows at a time, and stores it slab by slab.  Also W_s = sum of the sample's
-// integer branch lengths (what colsum_kernel gives the SAD path).
-__global__ __launch_bounds__(256)
-void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
-                            const uint32_t *__restrict__ klen, const int32_t *__restrict__ row_of,
-                            const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list,
-                            unsigned long long *__restrict__ Pbits, int64_t n8, int64_t n_slabs,
-                            unsigned long long *__restrict__ W)
-{
-    // a branch's staged rows: row_list[row_ptr[b] .. row_ptr[b + 1]) (graded staging: one or more, anywhere), else
-    // the one row row_of[b], else row b
-    __shared__ uint32_t bm[2048];
-    const int64_t s = blockIdx.x;
-    const int64_t t0 = indptr[s], t1 = indptr[s + 1];
-    unsigned long long w = 0;
-    for (int64_t win = 0; win * 1024 < n_slabs; ++win) {
-        for (int q = threadIdx.x; q < 2048; q += 256) bm[q] = 0;
-        __syncthreads();
-        for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
-            const int32_t b0 = branch_id[t];
-            if (row_ptr) {
-                for (int32_t p = row_ptr[b0]; p < row_ptr[b0 + 1]; ++p) {
-                    const int64_t r = row_list[p];
-                    if ((r >> 16) == win) atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
-                }
-                if (win == 0) w += klen[b0];
-                continue;
-            }
-            const int64_t r = row_of ? row_of[b0] : b0;
-            if ((r >> 16) == win) {
-                atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
-                w += klen[b0];
-            }
-        }
-        __syncthreads();
-        for (int64_t q = threadIdx.x; q < 1024 && win * 1024 + q < n_slabs; q += 256)
-            Pbits[(((win * 1024 + q) >> 1) * n8 + s) * 2 + (q & 1)] =
-                (unsigned long long)bm[2 * q] | ((unsigned long long)bm[2 * q + 1] << 32);
-        __syncthreads();
-    }
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
-}
 
 // Persistent: workgroup g runs items[item_ptr[g] .. item_ptr[g+1]).
 //
@@ -130,7 +85,7 @@ void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *_
 // out is then 16-byte stores of the accumulators in their own order, which reduce_private_kernel reads.
 // An item with a single digit plane runs its own instantiation of everything between the accumulators'
 // declaration and the way out (run_item), without the second plane.
-// GRADED: the rows are staged by descending length with SIGNED digits (ff_device.hip stage_for_mfma; Kd = their
+// GRADED: the rows are staged by descending length with SIGNED digits (ff_dev_stage.hip stage_for_mfma; Kd = their
 // three planes): the sweep runs k-steps of three MFMAs per tile (TRI: X += A d0, X += (A << 7)(-d1), Y += A d2) up
 // to slab duo_from_slab and of two (DUO: X alone) from there on -- kstep3 / kstep2 below; the accumulators meet
 // again as common = X + (Y << 15).  In these k-steps an accumulator tile is written twice, four MFMAs apart, and

@@ -1,6 +1,7 @@
 // ff_kernels_mfma_small.hpp -- unweighted UniFrac on the int8 matrix cores for shards SMALLER THAN ONE ROUND of
 // pair_common_mfma_kernel: one launch does the pair reduction, the sum over the branch ranges and the division.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace.
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 //
 // pair_common_mfma_kernel is built for throughput: 256 x 128 tiles, one persistent workgroup per CU, 8 slabs of
 // prefetch, a prologue and an accumulator write-out of about 10 us per item, partial tiles summed by a second

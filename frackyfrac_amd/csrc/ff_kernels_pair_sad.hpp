@@ -1,7 +1,22 @@
 // ff_kernels_pair_sad.hpp -- the v_sad_u32 pair-tile kernels (register-buffered with two or three waves per SIMD, sparse-aware) and their helpers.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace
-// (one translation unit, so the kernels stay internal and need no relocatable device code).
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
+// D = |a - b| + c on 32-bit unsigned integers, `a` wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t sad_u32(uint32_t s, uint32_t v, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(acc));
+    return r;
+}
+
+// The same in place: the accumulator keeps its register (what a kernel with no VGPR to spare needs).
+__device__ __forceinline__ void sad_u32_acc(uint32_t s, uint32_t v, uint32_t &acc)
+{
+    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "s"(s), "v"(v));
+}
+
+// NC 32-bit values per lane of one branch row: one 16-byte (NC = 4) or 8-byte (NC = 2) load.
 template <int NC> struct RowVec { uint32_t v[NC]; };
 template <int NC> __device__ __forceinline__ RowVec<NC> load_row(const uint32_t *p)
 {
@@ -328,40 +343,6 @@ void pair_sad_sparse_kernel(const uint32_t *__restrict__ QT, int64_t ld,
             run_item_sparse<4>(QT, ld, item, arows, aptr16, aptr_stride, cs16, zero_row, num, plane_stride, row_begin, row_end,
                                slot_begin, lane);
     }
-}
-
-// cs16[t][s] = sum of column s over the rows [0, 16 t): one column per lane, sequential over rows.
-__global__ void prefix16_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
-                                uint32_t *__restrict__ cs16)
-{
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ld) return;
-    uint32_t run = 0;
-    cs16[s] = 0;
-    for (int64_t r = 0; r < rows; ++r) {
-        run += QT[r * ld + s];
-        if ((r & 15) == 15) cs16[((r >> 4) + 1) * ld + s] = run;
-    }
-}
-
-// act64[iblock][w] bit r: branch row 64 w + r has a non-zero value among the 32 samples of
-// i-block `iblock`.  One wave per (i-block, 64 rows), lane = row.
-__global__ void build_activity_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows, int64_t words,
-                                      unsigned long long *__restrict__ act64)
-{
-    const int64_t w = blockIdx.x, iblock = blockIdx.y;
-    const int64_t row = w * 64 + threadIdx.x;
-    uint32_t any = 0;
-    if (row < rows) {
-        const uint4 *p = (const uint4 *)(QT + row * ld + iblock * TILE_I);
-#pragma unroll
-        for (int q = 0; q < TILE_I / 4; ++q) {
-            const uint4 t = p[q];
-            any |= t.x | t.y | t.z | t.w;
-        }
-    }
-    const unsigned long long mask = __ballot(any != 0);
-    if (threadIdx.x == 0) act64[iblock * words + w] = mask;
 }
 
 __device__ __forceinline__ void slot_to_pair(int64_t k, int64_t *pi, int64_t *pj)

@@ -1,21 +1,8 @@
-// ff_kernels_stage.hpp -- staging of the flat nodes into the dense matrices (FIXED32 / EXACT64), column sums, branch marks.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace
-// (one translation unit, so the kernels stay internal and need no relocatable device code).
+// ff_kernels_stage.hpp -- staging of the flat nodes into what the pair kernels read: the dense matrices (FIXED32 / EXACT64), presence
+// words and bits, column sums, activity lists, branch marks.
+// A fragment of ff_dev_stage.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
-
-// D = |a - b| + c on 32-bit unsigned integers, `a` wave-uniform (SGPR).
-__device__ __forceinline__ uint32_t sad_u32(uint32_t s, uint32_t v, uint32_t acc)
-{
-    uint32_t r;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(v), "v"(acc));
-    return r;
-}
-
-// The same in place: the accumulator keeps its register (what a kernel with no VGPR to spare needs).
-__device__ __forceinline__ void sad_u32_acc(uint32_t s, uint32_t v, uint32_t &acc)
-{
-    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "s"(s), "v"(v));
-}
 
 // Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
 // Weighted values are rounded with the branch's shared offset (ff_dither.hpp): q = floor(v + u_b).
@@ -99,4 +86,93 @@ __global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64
     if (acc) atomicAdd(&W[s], acc);
 }
 
-// NC 32-bit values per lane of one branch row: one 16-byte (NC = 4) or 8-byte (NC = 2) load.
+// cs16[t][s] = sum of column s over the rows [0, 16 t): one column per lane, sequential over rows.
+__global__ void prefix16_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
+                                uint32_t *__restrict__ cs16)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ld) return;
+    uint32_t run = 0;
+    cs16[s] = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        run += QT[r * ld + s];
+        if ((r & 15) == 15) cs16[((r >> 4) + 1) * ld + s] = run;
+    }
+}
+
+// act64[iblock][w] bit r: branch row 64 w + r has a non-zero value among the 32 samples of
+// i-block `iblock`.  One wave per (i-block, 64 rows), lane = row.
+__global__ void build_activity_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows, int64_t words,
+                                      unsigned long long *__restrict__ act64)
+{
+    const int64_t w = blockIdx.x, iblock = blockIdx.y;
+    const int64_t row = w * 64 + threadIdx.x;
+    uint32_t any = 0;
+    if (row < rows) {
+        const uint4 *p = (const uint4 *)(QT + row * ld + iblock * TILE_I);
+#pragma unroll
+        for (int q = 0; q < TILE_I / 4; ++q) {
+            const uint4 t = p[q];
+            any |= t.x | t.y | t.z | t.w;
+        }
+    }
+    const unsigned long long mask = __ballot(any != 0);
+    if (threadIdx.x == 0) act64[iblock * words + w] = mask;
+}
+
+// Presence bits from the flat nodes: one workgroup per sample builds the sample's bitmap in LDS,
+// 65,536 branch rows at a time, and stores it slab by slab.  Also W_s = sum of the sample's
+// integer branch lengths (what colsum_kernel gives the SAD path).
+__global__ __launch_bounds__(256)
+void stage_mfma_bits_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                            const uint32_t *__restrict__ klen, const int32_t *__restrict__ row_of,
+                            const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list,
+                            unsigned long long *__restrict__ Pbits, int64_t n8, int64_t n_slabs,
+                            unsigned long long *__restrict__ W)
+{
+    // a branch's staged rows: row_list[row_ptr[b] .. row_ptr[b + 1]) (graded staging: one or more, anywhere), else
+    // the one row row_of[b], else row b
+    __shared__ uint32_t bm[2048];
+    const int64_t s = blockIdx.x;
+    const int64_t t0 = indptr[s], t1 = indptr[s + 1];
+    unsigned long long w = 0;
+    for (int64_t win = 0; win * 1024 < n_slabs; ++win) {
+        for (int q = threadIdx.x; q < 2048; q += 256) bm[q] = 0;
+        __syncthreads();
+        for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+            const int32_t b0 = branch_id[t];
+            if (row_ptr) {
+                for (int32_t p = row_ptr[b0]; p < row_ptr[b0 + 1]; ++p) {
+                    const int64_t r = row_list[p];
+                    if ((r >> 16) == win) atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
+                }
+                if (win == 0) w += klen[b0];
+                continue;
+            }
+            const int64_t r = row_of ? row_of[b0] : b0;
+            if ((r >> 16) == win) {
+                atomicOr(&bm[(r & 65535) >> 5], 1u << (r & 31));
+                w += klen[b0];
+            }
+        }
+        __syncthreads();
+        for (int64_t q = threadIdx.x; q < 1024 && win * 1024 + q < n_slabs; q += 256)
+            Pbits[(((win * 1024 + q) >> 1) * n8 + s) * 2 + (q & 1)] =
+                (unsigned long long)bm[2 * q] | ((unsigned long long)bm[2 * q + 1] << 32);
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&W[s], w);
+}
+
+// Stage the presence bits of pair_exact_unw_kernel (ff_kernels_exact_unw.hpp): one workgroup per sample ORs bit (row & 31) into word [row / 32][s].
+__global__ void stage_xbits_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                                   const int32_t *__restrict__ row_of,  // branch id -> staged row (null: identity)
+                                   uint32_t *__restrict__ Xb, int64_t ldx)
+{
+    const int64_t s = blockIdx.x;
+    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
+        const int32_t b = branch_id[t], row = row_of ? row_of[b] : b;
+        atomicOr(&Xb[(int64_t)(row / XU_SLAB) * ldx + s], 1u << (row % XU_SLAB));
+    }
+}

@@ -1,6 +1,6 @@
 // ff_kernels_stage_a.hpp -- stage A on the device: subtree sums level by level, normaliser, CSR fill.
-// A fragment of ff_device.hip: included there, once, inside its anonymous namespace
-// (one translation unit, so the kernels stay internal and need no relocatable device code).
+// A fragment of ff_dev_stage.hip: included there, once, inside its anonymous namespace
+// (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
 // ---- Stage A on the device (frcfrc/unifrac.go:32-67): subtree sums and normaliser ----
 //

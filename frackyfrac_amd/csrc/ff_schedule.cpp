@@ -627,7 +627,7 @@ extern "C" int64_t ff_debug_schedule(int kernel, int64_t n_samples, int64_t rows
 }
 
 // Diagnostics / tests: the constants that tie the kernels' prefetch depths to the padding of the staged
-// arrays (ff_schedule.hpp), and the allocation sizes ff_device.hip derives from them for R staged rows.
+// arrays (ff_schedule.hpp), and the allocation sizes ff_dev_stage.hip derives from them for R staged rows.
 // out[0..23] = {TILE_I, TILE_J, KSTEP, SLACK_ROWS, SAD_ROWS_AHEAD, SPARSE_LIST_AHEAD, SPARSE_LIST_PAD, M_KSLAB,
 //               M_QUAD_SLABS, M_PAIRS_IN_FLIGHT, M_PAD_SLABS, X_VALUES_PAD, sad_staged_rows(R), sad_alloc_rows(R),
 //               mfma_staged_slabs(R), mfma_alloc_slabs(R),

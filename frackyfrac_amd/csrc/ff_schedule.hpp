@@ -20,7 +20,7 @@ constexpr int SLACK_ROWS = 32;  // zero rows past the matrix, read by the prefet
 constexpr int WAVES_PER_WG = 8; // 512-thread workgroups: two waves per SIMD
 constexpr int L_WAVES_PER_WG = 12;  // 768-thread workgroups of pair_sad_kernel12 (half the vector buffers): three per SIMD
 constexpr int SYNC_TRIPS = 16;      // main-round items: a workgroup barrier every this many loop trips
-// EXACT64 tile: H rows x 64 columns per wave, H one of these (picked per plan: ff_device.hip schedule_exact64)
+// EXACT64 tile: H rows x 64 columns per wave, H one of these (picked per plan: ff_dev_run.hip schedule_exact64)
 constexpr int X_TILE_HEIGHTS[] = {4, 8, 10, 12, 14, 16};
 constexpr int X_TILE_H_DEFAULT = 12;
 constexpr int X_TILE_J = 64;
@@ -29,7 +29,7 @@ constexpr int X_TILE_J = 64;
 // Three kernels over-read BY DESIGN (their prefetches run ahead of the loop's exit test; what they fetch
 // past the end is zero padding or never used).  Every such distance is a constant here, next to the
 // padding that has to cover it, and the two are tied at compile time; the kernels static_assert their own
-// loop shape against the same constants, ff_device.hip sizes the allocations with the functions below, and
+// loop shape against the same constants, ff_dev_stage.hip sizes the allocations with the functions below, and
 // tests/test_schedule_cpu.py replays each kernel's address stream per item against those sizes.
 //   pair_sad_kernel / pair_sad_kernel12: the vector buffer refilled during an item's last trip holds the rows
 //   k1 .. k1 + KS - 1 (KS = KSTEP or KSTEP / 2 rows per buffer); the scalar operands stop at row k1.

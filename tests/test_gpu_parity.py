@@ -521,7 +521,7 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
 
 @pytest.mark.parametrize("tail", ["short", "long"])
 def test_unweighted_mfma_graded_planes_at_the_ends_of_their_ranges(monkeypatch, tail):
-    """Lengths of more than two base-128 digits are staged graded (ff_device.hip stage_for_mfma): rows sorted by
+    """Lengths of more than two base-128 digits are staged graded (ff_dev_stage.hip stage_for_mfma): rows sorted by
     length, signed digits d0 + 128 d1 + 32768 d2, three planes per block where some row has a third digit and two
     behind, and a branch longer than 4,177,983 (ff_schedule.hpp TRI_KMAX) as several rows.  Lengths at every digit's
     ends, one past the three-digit range and one of 2^27 (33 rows), against the oracle, bit for bit
@@ -1047,7 +1047,7 @@ def test_kernel_choice_per_rank_of_the_baseline_configs():
     """Which weighted pair kernel every rank of a sharded run takes, as measured (tools/shard_balance.py,
     profiles/r04_shard_balance.txt): the 12-wave kernel for shards of several rounds -- C4 over 2 and 4 GPUs, C5 over
     2, 4 and 8, first rank or not --, the 8-wave kernel for C4 over 8 and for the weak problem's C3-sized shards
-    (except the first rank's triangle there).  DESIGN 4.1, ff_device.hip schedule_sad and this test say the same."""
+    (except the first rank's triangle there).  DESIGN 4.1, ff_dev_run.hip schedule_sad and this test say the same."""
     def waves(nodes, rank, world, plan=None):
         p = ff.Plan(nodes, True, precision="fixed32", rank=rank, world=world) if plan is None else plan
         if plan is not None:

@@ -185,7 +185,7 @@ def test_mfma_rounds_do_not_mix_digit_groups_and_the_remainder_is_cut_by_cost():
 #
 # Three kernels over-read by design (their prefetches run ahead of the loop's exit test).  Each replay below
 # follows the kernel's own loop -- the order and the distance of its loads, nothing else -- and returns the
-# highest index it touches; the allocation sizes come from the functions ff_device.hip allocates with
+# highest index it touches; the allocation sizes come from the functions ff_dev_stage.hip allocates with
 # (ff_debug_layout), so a change of prefetch depth, padding or item granularity on either side shows up here
 # on the CPU instead of as a page fault on the GPU (round 2: a 32-slab problem read one slab past Pbits).
 
