@@ -66,7 +66,7 @@ func ffDeliver(user unsafe.Pointer, slotBegin C.int64_t, dists *C.double, n C.in
 func unifracDistsGPU(nodes [][]flatNode, treeDists []float64, weighted bool) (iter.Seq[float64], func() error) {
 	var failure error
 	seq := func(yield func(float64) bool) {
-		// [][]flatNode (unifrac.go:137-140) -> CSR; lists are sorted by id (unifrac.go:57-59)
+		// [][]flatNode (unifrac.go:137-140) -> CSR; lists are sorted by id (unifrac.go:57-59) unless -l (below)
 		n := len(nodes)
 		indptr := make([]C.int64_t, n+1)
 		nnz := 0
@@ -91,6 +91,13 @@ func unifracDistsGPU(nodes [][]flatNode, treeDists []float64, weighted bool) (it
 		C.ff_options_default(&o)
 		if weighted {
 			o.weighted = 1
+		}
+		if *nnorm {
+			// Under -l the reference hands unifracDists the lists as the recursion left them: normalizeFlatNodes
+			// is skipped and with it the sort (unifrac.go:57-59,108-110).  The flag makes the library walk them
+			// as they stand, which is what unifracDists does -- a drop-in changes no value, quirks included.
+			// (A maintainer who wants the intended -l sorts the lists before this call and drops the flag.)
+			o.flags = C.FF_FLAG_UNSORTED_WALK
 		}
 		errbuf := make([]C.char, 1024)
 		h := cgo.NewHandle(&gpuSeq{yield: yield})

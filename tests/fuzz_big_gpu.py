@@ -1,7 +1,8 @@
 """Randomised parity sweep at sizes where the main rounds of the schedules are in play (3,000 to
 9,000 samples): random shapes, densities, shard counts, weighted and unweighted, FIXED32 against
 the oracle on 200,000 sampled pairs per case (1e-6 relative / bit-exact for exact-length unweighted); a third of
-the cases with log-normal or digit-edge integer branch lengths.
+the cases with log-normal or digit-edge integer branch lengths; unweighted cases with log-normal lengths also under
+precision auto (EXACT64 on pair_exact_unw_kernel), bit for bit.
 Usage: python tests/fuzz_big_gpu.py SEED CASES   (a script, not collected by pytest)"""
 import os, sys, time
 import numpy as np
@@ -49,6 +50,13 @@ for case in range(ncase):
             print("case", case, "n", n, lengths, "FIXED32 not applicable", flush=True)
             continue
         raise
+    # unweighted with lengths off the binary grid: what the engine does by itself (auto -> EXACT64 on
+    # pair_exact_unw_kernel), compared bit for bit
+    exact = None
+    if not weighted and lengths == "lognormal":
+        exact = np.full(P, np.nan)
+        for r in range(world):
+            ff.unifrac_dists(nodes, False, precision="auto", rank=r, world=world, out=exact)
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     ok = not np.isnan(got).any()
@@ -56,6 +64,8 @@ for case in range(ncase):
         a = int((P - 50_000) * q // 3)
         want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=16, pair_begin=a, pair_end=a + 50_000)
         g = got[a:a + 50_000]
+        if exact is not None:
+            ok = ok and bool(np.array_equal(exact[a:a + 50_000], want, equal_nan=True))
         if weighted or lengths == "lognormal":
             rel = np.abs(g - want) / np.where(want == 0, 1, np.abs(want))
             ok = ok and bool(np.nanmax(rel) <= 1e-6) and bool(np.array_equal(np.isnan(g), np.isnan(want)))
