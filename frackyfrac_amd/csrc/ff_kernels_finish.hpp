@@ -12,6 +12,7 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
                            int n_planes, int64_t plane_stride,  // the ranges of a split tile own a plane each
                            const FinishArgs f, int64_t slot_begin, int64_t n_slots)
 {
+    float h2min = INFINITY;  // smallest squared headroom over this thread's pairs (finish_note_headroom)
     // grid-stride: a launch carries at most 2^32 - 1 threads, a shard can have more slots
     for (int64_t t = (int64_t)blockIdx.x * (256 * FINISH_RUN) + threadIdx.x; t < n_slots;
          t += ((int64_t)gridDim.x - 1) * (256 * FINISH_RUN)) {
@@ -34,7 +35,7 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         }
 #pragma unroll
         for (int e = 0; e < FINISH_RUN; ++e, t += 256) {
-            if (t < n_slots) finish_pair(f, t, i, j, u32[e]);
+            if (t < n_slots) finish_pair(f, t, i, j, u32[e], h2min);
             j += 256;
             while (j >= i) {  // (rows are shorter than 256 only at the top of the triangle)
                 j -= i;
@@ -42,6 +43,7 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
             }
         }
     }
+    finish_note_headroom(f, h2min);
 }
 
 // Flat nodes per sample (what the refinement rule of finish_pair_w wants of a pair's two samples).

@@ -37,8 +37,11 @@ struct FinishArgs {
 };
 
 // Local slot t = pair (i, j), integer numerator u, w = W[i] + W[j] (the caller has loaded them).
+// h2min: the caller's running minimum of the squared headroom over the pairs it finishes (a register; the caller hands
+// it to finish_note_headroom once, when it is done: a memory operation per PAIR on the one word all threads share cost
+// finish_fixed32_kernel 100 of its 148 us at C3).
 __device__ __forceinline__ void finish_pair_w(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u,
-                                              unsigned long long w)
+                                              unsigned long long w, float &h2min)
 {
     double d;
     if (u == w || !f.wex) {
@@ -70,16 +73,23 @@ __device__ __forceinline__ void finish_pair_w(const FinishArgs &f, int64_t t, in
                 const unsigned long long at = atomicAdd(&f.refine_count[CNT_RISK_FOUND], 1ull);
                 if (at < RISK_CAP) f.risk_list[at] = (unsigned long long)t;
             }
-            // the run's smallest: an atomic only from a pair below what is there already (a stale read costs an
-            // atomic too many, never a wrong minimum); non-negative floats order like their bit patterns
-            const unsigned long long bits = (unsigned long long)__float_as_uint(h2);
-            if (bits < *(volatile unsigned long long *)&f.refine_count[CNT_MIN_HEADROOM2]) atomicMin(&f.refine_count[CNT_MIN_HEADROOM2], bits);
+            h2min = fminf(h2min, h2);
         }
     }
 }
 
 // Local slot t = pair (i, j), integer numerator u.
-__device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u)
+__device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int64_t i, int64_t j, unsigned long long u, float &h2min)
 {
-    finish_pair_w(f, t, i, j, u, f.W[i] + f.W[j]);
+    finish_pair_w(f, t, i, j, u, f.W[i] + f.W[j], h2min);
+}
+
+// Once per thread, behind its last pair: the run's smallest headroom.  An atomic only from a thread below what is there
+// already (a stale read costs an atomic too many, never a wrong minimum); non-negative floats order like their bit
+// patterns.
+__device__ __forceinline__ void finish_note_headroom(const FinishArgs &f, float h2min)
+{
+    if (!f.risk_list || !(h2min < INFINITY)) return;
+    const unsigned long long bits = (unsigned long long)__float_as_uint(h2min);
+    if (bits < *(volatile unsigned long long *)&f.refine_count[CNT_MIN_HEADROOM2]) atomicMin(&f.refine_count[CNT_MIN_HEADROOM2], bits);
 }

@@ -591,6 +591,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                             wj0 = (uint32_t)W[j];
                             wj1 = (uint32_t)W[j + 64];
                         }
+                        float h2min = INFINITY;
         #pragma unroll 4
                         for (int trip = 0; trip < M_TILE_I / NW; ++trip) {
                             const int row = wave + NW * trip;
@@ -601,8 +602,8 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                             if (i < row_begin || i >= row_end) continue;
                             const int64_t t0 = i * (i - 1) / 2 - slot_begin + j;
                             if (item.pad < 0 && fin.out) {  // the tile's only item: finish in place
-                                if (j < i) finish_pair(fin, t0, i, j, v0);
-                                if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1);
+                                if (j < i) finish_pair(fin, t0, i, j, v0, h2min);
+                                if (j + 64 < i) finish_pair(fin, t0 + 64, i, j + 64, v1, h2min);
                                 continue;
                             }
                             uint32_t *dst = num + t0;
@@ -614,6 +615,7 @@ void pair_common_mfma_kernel(const uint4 *__restrict__ Pbits, int64_t n8,
                                 if (j + 64 < i && v1) atomicAdd(dst + 64, v1);
                             }
                         }
+                        finish_note_headroom(fin, h2min);
                     }
                 }
             }
@@ -656,12 +658,14 @@ void reduce_partials_kernel(const uint32_t *__restrict__ partial, const int32_t 
     }
     const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
     const uint32_t sums[4] = {s.x, s.y, s.z, s.w};
+    float h2min = INFINITY;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (j + e < i) {
-            if (fin.out) finish_pair(fin, slot + e, i, j + e, sums[e]);
+            if (fin.out) finish_pair(fin, slot + e, i, j + e, sums[e], h2min);
             else num[slot + e] = sums[e];
         }
+    finish_note_headroom(fin, h2min);
 }
 
 // The same for a schedule whose every item has a private tile in the accumulators' own order
@@ -691,14 +695,16 @@ void reduce_private_kernel(const uint32_t *__restrict__ partial, const int32_t *
     }
     const uint32_t sums[4] = {s.x, s.y, s.z, s.w};
     const uint32_t wj = (uint32_t)W[j];
+    float h2min = INFINITY;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int64_t i = i0 + e;
         if (i < row_begin || i >= row_end || j >= i) continue;
         const uint32_t u = (uint32_t)W[i] + wj - 2u * sums[e];
         const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
-        if (fin.out) finish_pair(fin, slot, i, j, u);
+        if (fin.out) finish_pair(fin, slot, i, j, u, h2min);
         else num[slot] = u;
     }
+    finish_note_headroom(fin, h2min);
 }
 

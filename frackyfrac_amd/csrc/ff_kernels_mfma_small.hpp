@@ -165,6 +165,7 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
     }
     __syncthreads();
     FF_SSTAMP(3);
+    float h2min = INFINITY;
 #pragma unroll
     for (int e = tid; e < S_TILE * S_TILE; e += S_THREADS) {
         const int64_t i = tile.i0 + (e >> 5), j = tile.j0 + (e & 31);
@@ -175,9 +176,10 @@ void pair_common_small_kernel(const uint4 *__restrict__ Pbits, int64_t n8, const
         const unsigned long long w_i = e < S_THREADS ? w_i0 : w_i1;
         const uint32_t u = (uint32_t)w_i + (uint32_t)w_j - 2u * c;  // result = W_i + W_j - 2 common
         const int64_t slot = i * (i - 1) / 2 - slot_begin + j;
-        if (fin.out) finish_pair_w(fin, slot, i, j, u, w_i + w_j);
+        if (fin.out) finish_pair_w(fin, slot, i, j, u, w_i + w_j, h2min);
         else num[slot] = u;
     }
+    finish_note_headroom(fin, h2min);
     FF_SSTAMP(4);
 }
 #undef FF_SSTAMP

@@ -1,6 +1,7 @@
 """Randomised parity sweep on a GPU box: random shapes (1..700 samples, 2..4000 leaves), densities,
 leaf subsets (compaction), empty and duplicated samples, -l, shards, every precision -- each case
-against the oracle (bit-exact for EXACT64 and unweighted, 1e-6 relative for weighted FIXED32).
+against the oracle (bit-exact for EXACT64 and unweighted, 1e-6 relative for weighted FIXED32); -l cases also as
+the reference computes them (unsorted lists, FF_L_REFERENCE), bit for bit.
 Usage: python tests/fuzz_gpu.py SEED CASES  (a script, not collected by pytest)   (14,800 cases ran clean at the end of round 1, 2,500 of them with arbitrary branch lengths)"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,6 +39,18 @@ for case in range(ncase):
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     unnorm = bool(rng.random() < 0.3)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 2 if unnorm else 0)
+    if unnorm:   # the reference's own -l: unsorted post-order lists, the literal walk (pair_walk_kernel), bit for bit
+        ipq, onq = O.flatten_samples(ft, ptr, idx, val, 1)
+        wantq = O.unifrac_dists(ipq, onq, ft.dist, True, nthreads=8)
+        world = int(rng.choice([1, 2, 3]))
+        gotq = np.full(ff.num_pairs(n), np.nan)
+        for r in range(world):
+            plan = ff.Plan.from_leaves(T, ptr, idx, val, True, leave_unnormalized="reference", rank=r, world=world)
+            a, b = ff.shard_slots(n, r, world)
+            if plan.n_slots: gotq[a:b] = plan.run_host()
+            plan.close()
+        if not np.array_equal(gotq, wantq, equal_nan=True):
+            bad += 1; print("CASE", seed0 + case, "n", n, "leaves", leaves, "reference -l MISMATCH", flush=True)
     for weighted in (True, False):
         if unnorm and not weighted: continue
         want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=8)
