@@ -356,8 +356,10 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                             "pairs": P, "precision": {1: "fixed32", 2: "exact64"}[info.precision],
                             "parallelism": "pair-tile row shards x%d, gather to rank 0 (%s)" % (ctx.world, run.transport)},
                  "roofline": roofline_of(info, B, n_samples, run.n_slots, kernel_ms, launches, weighted,
-                                         # (the counters in profiles/traffic.json are the generator-length runs')
-                                         None if cfg.get("lengths") == "lognormal" else traffic_of(cfg["name"], ctx.world, info, weighted))}
+                                         # (the counters in profiles/traffic.json are the generator-length runs', except
+                                         # the exact unweighted kernel's, whose traffic does not depend on the lengths)
+                                         None if cfg.get("lengths") == "lognormal" and int(info.kernel) != 5
+                                         else traffic_of(cfg["name"], ctx.world, info, weighted))}
         entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region
         entry["roofline"]["kernel_ms_between_events"] = kernel_ms_events
         if n_audit:

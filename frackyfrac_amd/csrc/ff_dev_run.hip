@@ -467,7 +467,7 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
     pl->n_audit = 0;
     pl->refine_cap = (unsigned long long)std::min<int64_t>(n_slots, std::max<int64_t>(1 << 20, n_slots / 8));
     FF_HIP(hipMalloc(&pl->d_refine_list, sizeof(unsigned long long) * (size_t)std::max<unsigned long long>(pl->refine_cap, 1)));
-    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * CNT_N));
+    if (!pl->d_refine_count) FF_HIP(hipMalloc(&pl->d_refine_count, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * HEADROOM_SLOTS));
     if (!pl->d_risk_list && env_int("FF_AUDIT", 1) != 0) FF_HIP(hipMalloc(&pl->d_risk_list, sizeof(unsigned long long) * RISK_CAP));
     if (!pl->d_n_nodes) {
         const int64_t ns = pl->info.n_samples;
@@ -476,7 +476,7 @@ int alloc_refine_queue(ff_plan *pl, char *err, size_t errlen)
         FF_HIP(hipGetLastError());
         FF_HIP(hipDeviceSynchronize());  // (runs may come on any stream)
     }
-    reset_counters_kernel<<<dim3(1), dim3(64)>>>(pl->d_refine_count);
+    reset_counters_kernel<<<dim3(1), dim3(HEADROOM_SLOTS)>>>(pl->d_refine_count);
     FF_HIP(hipGetLastError());
     if (n_slots > 0 && env_int("FF_AUDIT", 1) != 0) {
         // the uniform sample grows with the shard: AUDIT_PAIRS per 2^23 pairs of it (C3 as a whole: 4,096; C4: 65,536)
@@ -555,7 +555,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         fin.scale_log2 = inf.scale_log2;
         fin.weighted = pl->weighted;
         const bool fused = pl->mfma && pl->m_fused;  // (decided when the shard was scheduled: schedule_mfma)
-        if (pl->refine) reset_counters_kernel<<<dim3(1), dim3(64), 0, st>>>(pl->d_refine_count);
+        if (pl->refine) reset_counters_kernel<<<dim3(1), dim3(HEADROOM_SLOTS), 0, st>>>(pl->d_refine_count);
         if (!fused && (!pl->mfma || pl->m_any_atomic))
             FF_HIP(hipMemsetAsync(pl->d_num, 0, sizeof(uint32_t) * (size_t)n_slots, st));
         if (timed) FF_HIP(hipEventRecord(ev0, st));
@@ -718,7 +718,10 @@ int ff_plan_audit_detail(ff_plan *pl, int64_t *uniform_checked, int64_t *risk_fo
     *uniform_checked = pl->n_audit;
     *risk_found = (int64_t)c[CNT_RISK_FOUND];
     *risk_checked = (int64_t)c[CNT_RISK_CHECKED];
-    const uint32_t bits = (uint32_t)c[CNT_MIN_HEADROOM2];
+    std::vector<uint32_t> slots(HEADROOM_SLOTS);
+    if (hipMemcpy(slots.data(), pl->d_refine_count + CNT_N, sizeof(uint32_t) * HEADROOM_SLOTS, hipMemcpyDeviceToHost) != hipSuccess)
+        return FF_ERR_DEVICE;
+    const uint32_t bits = *std::min_element(slots.begin(), slots.end());
     float h2;
     memcpy(&h2, &bits, sizeof h2);
     *min_headroom = pl->d_risk_list ? std::sqrt((double)h2) : INFINITY;

@@ -171,10 +171,11 @@ void audit_risk_kernel(const unsigned long long *__restrict__ risk_list, unsigne
     atomicAdd(&counters[CNT_RISK_CHECKED], 1ull);
 }
 
-// Before every run of a plan that refines: counters to zero, the smallest headroom to +infinity.
+// Before every run of a plan that refines: counters to zero, the headroom slots to +infinity (HEADROOM_SLOTS threads).
 __global__ void reset_counters_kernel(unsigned long long *__restrict__ counters)
 {
-    if (threadIdx.x < CNT_N) counters[threadIdx.x] = threadIdx.x == CNT_MIN_HEADROOM2 ? 0x7F800000ull : 0ull;
+    if (threadIdx.x < CNT_N) counters[threadIdx.x] = 0ull;
+    reinterpret_cast<uint32_t *>(counters + CNT_N)[threadIdx.x] = 0x7F800000u;
 }
 
 // The reference's merge walk (unifrac.go:144-205) for the queued pairs, in binary64 and in the reference's

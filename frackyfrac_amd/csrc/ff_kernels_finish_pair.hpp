@@ -23,7 +23,11 @@ constexpr double REFINE_C = 5.0;
 constexpr float RISK_HEADROOM = 1.25f;
 constexpr unsigned long long RISK_CAP = 4096;
 // slots of FinishArgs::refine_count (one allocation, reset before every run by reset_counters_kernel)
-enum { CNT_QUEUED = 0, CNT_AUDIT_FAILED = 1, CNT_AUDIT_WORST = 2, CNT_RISK_FOUND = 3, CNT_MIN_HEADROOM2 = 4, CNT_RISK_CHECKED = 5, CNT_N = 6 };
+enum { CNT_QUEUED = 0, CNT_AUDIT_FAILED = 1, CNT_AUDIT_WORST = 2, CNT_RISK_FOUND = 3, CNT_RISK_CHECKED = 4, CNT_N = 5 };
+// behind the counters: HEADROOM_SLOTS 32-bit words, the smallest squared headroom (float bits) seen by the waves that
+// hash to each -- ONE word for all waves made finish_fixed32_kernel three times as long (every wave's request to the
+// same address queues at its memory channel: 148 us instead of 45 at C3); the reader takes the minimum over the slots
+constexpr int HEADROOM_SLOTS = 1024;
 
 struct FinishArgs {
     const unsigned long long *W;   // integer column sums
@@ -84,12 +88,24 @@ __device__ __forceinline__ void finish_pair(const FinishArgs &f, int64_t t, int6
     finish_pair_w(f, t, i, j, u, f.W[i] + f.W[j], h2min);
 }
 
-// Once per thread, behind its last pair: the run's smallest headroom.  An atomic only from a thread below what is there
-// already (a stale read costs an atomic too many, never a wrong minimum); non-negative floats order like their bit
-// patterns.
+// Once per thread, behind its last pair: the smallest squared headroom of the wave's lanes that are still here into
+// the wave's slot (non-negative floats order like their bit patterns).  h2min starts at +infinity, so a lane that
+// finished no pair takes no part in the minimum.
 __device__ __forceinline__ void finish_note_headroom(const FinishArgs &f, float h2min)
 {
-    if (!f.risk_list || !(h2min < INFINITY)) return;
-    const unsigned long long bits = (unsigned long long)__float_as_uint(h2min);
-    if (bits < *(volatile unsigned long long *)&f.refine_count[CNT_MIN_HEADROOM2]) atomicMin(&f.refine_count[CNT_MIN_HEADROOM2], bits);
+    if (!f.risk_list) return;
+    // (lanes that left the kernel earlier are not here: their registers hold anything)
+    const unsigned long long here = __ballot(1);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const float other = __shfl_xor(h2min, m);
+        h2min = fminf(h2min, ((here >> (lane ^ m)) & 1ull) ? other : INFINITY);
+    }
+    if (lane == __ffsll((long long)here) - 1 && h2min < INFINITY) {
+        uint32_t *slots = reinterpret_cast<uint32_t *>(f.refine_count + CNT_N);
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        atomicMin(&slots[(wave * 2654435761u) >> 22], __float_as_uint(h2min));  // (top 10 bits: HEADROOM_SLOTS = 1024)
+    }
 }
+static_assert(HEADROOM_SLOTS == 1024, "finish_note_headroom: ten bits of the hash");
