@@ -221,7 +221,7 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,072 samples)
     common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
     # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
-    peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2,
+    peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2, 7: VALU_PEAK_TLANEOPS / 2,
                 5: VALU_PEAK_TLANEOPS / 2}.get(kernel, VALU_PEAK_TLANEOPS) * 1e12
     common["floor_ms"] = 2.0 * B * shard_pairs / peak_ops * 1e3
     common.update(traffic or {"traffic": None})
@@ -232,8 +232,9 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         return dict({"bound": "mfma", "achieved": achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                      "frac": achieved / MFMA_I8_PEAK_TOPS, "digits": int(info.n_digits),
                      "algorithmic": "2*B int8 MAC-ops per pair, B=%d, %d pairs per launch" % (B, shard_pairs)}, **common)
-    if kernel == 1:
-        # EXACT64 weighted.  SURVEY 8(d) prices the f64 variant like the f32 one: 2*B lane-ops per pair, at the FP64
+    if kernel in (1, 7):
+        # EXACT64 weighted (7: pair_exact64_skip_kernel, which issues 1 / H + 2 (1 - d) + 6 d operations per term at row
+        # density d -- 3.3 at C3 -- for the same bits).  SURVEY 8(d) prices the f64 variant like the f32 one: 2*B lane-ops per pair, at the FP64
         # vector peak (MI355X: 78.6 TFLOP/s FP64 vector = 39.3e12 ops/s) -> `frac`.  The reference's ROUNDINGS need
         # six unfused binary64 operations per branch and pair (numer: sub, mul by |.|, add; denom: add, mul, add;
         # unifrac.go:191-192), which no bit-exact kernel can go under -> `frac_unfused6`, the builder's count.
@@ -241,8 +242,10 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         achieved = 2.0 * B * shard_pairs / sec / 1e12
         return dict({"bound": "valu", "achieved": achieved, "peak": peak, "unit": "T f64 op/s", "frac": achieved / peak,
                      "achieved_unfused6": 3.0 * achieved, "frac_unfused6": 3.0 * achieved / peak,
-                     "algorithmic": "2*B binary64 lane-ops per pair (SURVEY 8d; frac_unfused6: the 6*B unfused operations "
-                                    "the reference's roundings need), B=%d, %d pairs per launch" % (B, shard_pairs)},
+                     "algorithmic": "2*B binary64 lane-ops per pair (SURVEY 8d; frac_unfused6: against the 6*B unfused operations of "
+                                    "the reference's both-present case, unifrac.go:191-192, for every term -- "
+                                    "pair_exact64_skip_kernel issues fewer, so it may pass 1), B=%d, %d pairs per launch"
+                                    % (B, shard_pairs)},
                     **common)
     if kernel == 5:
         # EXACT64 unweighted: the reference's two running sums are two binary64 ADDITIONS per branch and pair
@@ -347,7 +350,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
         n_audit, bad, worst = run.plan.audit()
         entry = {"value": P / (elapsed / steps), "unit": "pairs/s", "steps": steps, "warmup": warmup,
                  "ms_per_step": elapsed / steps * 1e3,
-                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8", 5: "f64"}[int(info.kernel)],
+                 "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8", 5: "f64", 6: "f64", 7: "f64"}[int(info.kernel)],
                  "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
                                         "leaf density %.2f, seed 0x%X%s" %
                                         (cfg["name"], n_samples, cfg["n_leaves"], B,

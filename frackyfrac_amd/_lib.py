@@ -56,7 +56,7 @@ class ff_plan_info(ctypes.Structure):
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
 
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
-                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel", 6: "pair_walk_kernel"}
+                3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel", 6: "pair_walk_kernel", 7: "pair_exact64_skip_kernel"}
 FLAG_UNSORTED_WALK = 1
 L_REFERENCE = 2
 

@@ -29,6 +29,7 @@ using namespace ff::sched;
 #include "ff_kernels_mfma_small.hpp"
 #include "ff_kernels_finish.hpp"
 #include "ff_kernels_exact_unw.hpp"
+#include "ff_kernels_exact_w.hpp"
 
 }  // namespace
 
@@ -279,6 +280,21 @@ int launch_exact64(ff_plan *pl, hipStream_t st, double *d_out, char *err, size_t
     if (pl->n_xtiles <= 0) return FF_OK;
     const unsigned nb = (unsigned)((pl->n_xtiles + 3) / 4);
     const double *len = pl->d_len_rows ? pl->d_len_rows : pl->d_len;
+    // weighted: the kernel that takes the reference's shortcut for branches a row has not (heights 8, 12, 16;
+    // FF_X_SKIP=0: pair_exact64_kernel, six operations for every term; same bits)
+    if (pl->x_skip) {
+        if (pl->x_tile_h == 8)
+            pair_exact64_skip_kernel<8><<<dim3(nb), dim3(256), 0, st>>>(pl->d_DT, inf.ld, len, inf.n_rows, pl->d_xtiles, pl->n_xtiles,
+                                                                      inf.row_begin, inf.row_end, inf.slot_begin, d_out);
+        else if (pl->x_tile_h == 12)
+            pair_exact64_skip_kernel<12><<<dim3(nb), dim3(256), 0, st>>>(pl->d_DT, inf.ld, len, inf.n_rows, pl->d_xtiles, pl->n_xtiles,
+                                                                       inf.row_begin, inf.row_end, inf.slot_begin, d_out);
+        else
+            pair_exact64_skip_kernel<16><<<dim3(nb), dim3(256), 0, st>>>(pl->d_DT, inf.ld, len, inf.n_rows, pl->d_xtiles, pl->n_xtiles,
+                                                                       inf.row_begin, inf.row_end, inf.slot_begin, d_out);
+        FF_HIP(hipGetLastError());
+        return FF_OK;
+    }
 #define FF_X_CASE(H)                                                                                              \
     case H:                                                                                                       \
         if (pl->weighted)                                                                                         \
@@ -321,6 +337,8 @@ int upload_exact64_tiles(ff_plan *pl, int h, char *err, size_t errlen)
                         xt.size(), ((size_t)1 << 26) - 1);
     pl->n_xtiles = (int)xt.size();
     pl->x_tile_h = h;
+    pl->x_skip = pl->weighted && env_int("FF_X_SKIP", 1) != 0 && (h == 8 || h == 12 || h == 16);
+    inf.kernel = pl->x_skip ? FF_KERNEL_EXACT_F64_SKIP : FF_KERNEL_EXACT_F64;
     FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
     if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));
     inf.n_wave_slots = (int64_t)xt.size();
@@ -395,11 +413,16 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         if (!small) {
             const double simds = (double)inf.n_compute_units * 4.0;
             double best_score = 0;
+            // (weighted: pair_exact64_skip_kernel has the heights 8, 12 and 16; at C3's shape 25.5 / 21.2 / 22.4 ms with
+            // 16.25 / 10.9 / 8.1 tiles per SIMD, i.e. per tile-round worth 0.83 / 0.96 / 1)
+            const bool skip = pl->weighted && env_int("FF_X_SKIP", 1) != 0;
             for (int cand : {8, 10, 12, 14, 16}) {
+                if (skip && cand != 8 && cand != 12 && cand != 16) continue;
                 std::vector<Tile> count;
                 build_tiles(inf.n_samples, inf.row_begin, inf.row_end, cand, X_TILE_J, false, &count);
                 const double avg = (double)count.size() / simds;
-                const double worth = cand == 8 ? 0.95 : cand == 10 ? 0.97 : cand == 16 ? 0.985 : 1.0;
+                const double worth = skip ? (cand == 8 ? 0.83 : cand == 12 ? 0.96 : 1.0)
+                                          : cand == 8 ? 0.95 : cand == 10 ? 0.97 : cand == 16 ? 0.985 : 1.0;
                 const double score = worth * avg / std::ceil(avg);
                 if (score > best_score + 1e-12) {
                     best_score = score;

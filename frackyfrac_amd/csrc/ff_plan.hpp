@@ -93,6 +93,7 @@ struct ff_plan {
     ff::sched::XTile *d_xtiles = nullptr;
     int n_xtiles = 0;
     int x_tile_h = 0;  // EXACT64 tile height in use (0: not chosen yet)
+    bool x_skip = false;  // weighted EXACT64 on pair_exact64_skip_kernel (heights 8, 12, 16; read once per schedule)
     bool walk = false;  // FF_FLAG_UNSORTED_WALK: no staging at all, pair_walk_kernel over the flat nodes as they stand
     // EXACT64 unweighted (pair_exact_unw_kernel): presence bits, lengths by staged row, tiles
     bool xu = false;

@@ -79,7 +79,7 @@ typedef enum ff_precision {
                                  weighted runs on the vector ALU (v_sad_u32), unweighted on
                                  the int8 matrix cores (same integers, same results)          */
     FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
-                                 the reference for any finite input; weighted about 6x slower
+                                 the reference for any finite input; weighted about 4x slower
                                  than FIXED32, unweighted about 2x slower than the vector-ALU
                                  FIXED32 path (40x slower than the matrix cores)              */
 } ff_precision;
@@ -224,8 +224,11 @@ typedef enum ff_kernel {
     FF_KERNEL_EXACT_F64_UNW = 5,  /* pair_exact_unw_kernel: EXACT64 unweighted from presence bits -- the
                                      reference's two chains of binary64 additions per pair and no other
                                      arithmetic (unifrac.go:144-171)                                      */
-    FF_KERNEL_WALK_F64 = 6        /* pair_walk_kernel: the reference's merge walk itself, a thread per pair,
+    FF_KERNEL_WALK_F64 = 6,       /* pair_walk_kernel: the reference's merge walk itself, a thread per pair,
                                      over lists as they stand (FF_FLAG_UNSORTED_WALK)                     */
+    FF_KERNEL_EXACT_F64_SKIP = 7  /* pair_exact64_skip_kernel: EXACT64 weighted; a branch a row has not adds
+                                     l * y twice (unifrac.go:186-187) instead of the six operations of
+                                     :191-192 on a zero -- same bits as FF_KERNEL_EXACT_F64               */
 } ff_kernel;
 
 /* Stage: quantise / densify the flat nodes into the branch-major matrix in HBM

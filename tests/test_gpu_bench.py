@@ -74,14 +74,14 @@ def test_single_gpu_line_carries_the_secondary_entries():
     assert sec[6]["roofline"]["kernel"] == "pair_exact_unw_kernel" and "audit" not in sec[6]
     # the reference-width figure sits in the primary record too, with both operation counts
     rw = out["reference_width"]
-    assert rw["dtype"] == "f64" and rw["value"] == sec[0]["value"] and rw["roofline"]["kernel"] == "pair_exact64_kernel"
+    assert rw["dtype"] == "f64" and rw["value"] == sec[0]["value"] and rw["roofline"]["kernel"] == "pair_exact64_skip_kernel"
     assert abs(rw["roofline"]["frac_unfused6"] - 3.0 * rw["roofline"]["frac"]) < 1e-9
     # the rocprof-reported rate: counter bytes of the profiled build over this run's kernel time
     hbm = out["roofline"]["hbm"]
     if out["roofline"]["traffic"]:
         assert hbm["measured_GBps"] > hbm["achieved"] and 0 < hbm["measured_frac_of_8000"] < hbm["measured_frac_of_6290"] < 1
         assert hbm["traffic_ratio"] > 1.0
-    assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_kernel"
+    assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_skip_kernel"
     assert sec[1]["roofline"]["bound"] == "mfma" and "unweighted" in sec[1]["config"]["workload"]
     assert sec[1]["roofline"]["kernel"] == "pair_common_mfma_kernel" and sec[2]["roofline"]["kernel"] == "pair_common_small_kernel"
     assert sec[3]["config"]["pairs"] == 16384 * 16383 // 2 and sec[4]["config"]["pairs"] == 8192 * 8191 // 2

@@ -577,8 +577,15 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     want = O.unifrac_dists(ip, on, ft.dist, weighted, nthreads=8)
+    # (weighted, heights 8 / 12 / 16: pair_exact64_skip_kernel, which adds l * y twice for a branch a row has not instead of
+    # running the six operations on a zero; FF_X_SKIP=0: pair_exact64_kernel at every height; unweighted here runs the
+    # same kernel's presence arithmetic -- FF_EXACT_UNW=0 --, the heights being its only user left)
+    if not weighted:
+        monkeypatch.setenv("FF_EXACT_UNW", "0")
     for env in ({"FF_X_TILE_H": "4"}, {"FF_X_TILE_H": "8"}, {"FF_X_TILE_H": "10"}, {},
-                {"FF_X_TILE_H": "12"}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"}, {"FF_X_CALIBRATE": "1"}):
+                {"FF_X_TILE_H": "12"}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"}, {"FF_X_CALIBRATE": "1"},
+                {"FF_X_TILE_H": "8", "FF_X_SKIP": "0"}, {"FF_X_TILE_H": "12", "FF_X_SKIP": "0"},
+                {"FF_X_TILE_H": "16", "FF_X_SKIP": "0"}, {"FF_X_SKIP": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for rank, world in ((0, 1), (1, 3)):

@@ -16,8 +16,8 @@ def test_c2_pass_takes_microseconds_not_tens_of_them():
     assert out["ms_per_step"] <= out["roofline"]["kernel_ms_between_events"] + 0.005
 
 
-def test_graded_planes_cost_less_than_two_sweeps_and_exact_unweighted_a_third_of_the_weighted_walk():
+def test_graded_planes_cost_less_than_two_sweeps_and_exact_unweighted_half_of_the_weighted_walk():
     out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--no-cpu-baseline")
     sec = out["secondary"]
     assert sec[1]["ms_per_step"] < sec[5]["ms_per_step"] < 2.0 * sec[1]["ms_per_step"]   # (two sweeps cost 1.85 x)
-    assert sec[6]["ms_per_step"] < 0.5 * sec[0]["ms_per_step"]       # pair_exact_unw_kernel 10 ms, pair_exact64_kernel 30
+    assert sec[6]["ms_per_step"] < 0.7 * sec[0]["ms_per_step"]       # pair_exact_unw_kernel 10 ms, pair_exact64_skip_kernel 21
