@@ -2,7 +2,8 @@
 9,000 samples): random shapes, densities, shard counts, weighted and unweighted, FIXED32 against
 the oracle on 200,000 sampled pairs per case (1e-6 relative / bit-exact for exact-length unweighted); a third of
 the cases with log-normal or digit-edge integer branch lengths; unweighted cases with log-normal lengths also under
-precision auto (EXACT64 on pair_exact_unw_kernel), bit for bit.
+precision auto (EXACT64 on pair_exact_unw_kernel) and every weighted case also in EXACT64
+(pair_exact64_skip_kernel), bit for bit.
 Usage: python tests/fuzz_big_gpu.py SEED CASES   (a script, not collected by pytest)"""
 import os, sys, time
 import numpy as np
@@ -52,11 +53,12 @@ for case in range(ncase):
         raise
     # unweighted with lengths off the binary grid: what the engine does by itself (auto -> EXACT64 on
     # pair_exact_unw_kernel), compared bit for bit
+    # weighted: EXACT64 as well (pair_exact64_skip_kernel at the height the plan picks for each shard), bit for bit
     exact = None
-    if not weighted and lengths == "lognormal":
+    if weighted or lengths == "lognormal":
         exact = np.full(P, np.nan)
         for r in range(world):
-            ff.unifrac_dists(nodes, False, precision="auto", rank=r, world=world, out=exact)
+            ff.unifrac_dists(nodes, weighted, precision="exact64" if weighted else "auto", rank=r, world=world, out=exact)
     ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     ok = not np.isnan(got).any()
