@@ -600,6 +600,28 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_weighted_exact64_full_size_bit_exact(name):
+    """BASELINE configs at stated size, weighted, EXACT64 -- the `reference_width` figure of the bench line -- on
+    pair_exact64_skip_kernel (a branch a row has not adds l * y to both sums, unifrac.go:186-187; one both have runs
+    :191-192): 400,000 pairs in four ranges spread over the triangle are the oracle's bits."""
+    cfg = synth.CONFIGS[name]
+    n = cfg["n_samples"]
+    tree, ptr, idx, val = synth.make(n, cfg["n_leaves"], cfg["density"], cfg["seed"])
+    nodes = ff.flatten_leaf_csr(ff.parse_newick(tree.newick()), ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    plan = ff.Plan(nodes, True, precision="exact64")
+    assert plan.info.kernel == 7 and L.KERNEL_NAMES[7] == "pair_exact64_skip_kernel"
+    got = plan.run_host()
+    plan.close()
+    assert not np.isnan(got).any() and got.min() >= 0.0 and got.max() <= 1.0
+    P = ff.num_pairs(n)
+    for a in (0, P // 3, 2 * P // 3, P - 100_000):
+        want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS, pair_begin=a, pair_end=a + 100_000)
+        assert np.array_equal(got[a:a + 100_000], want), (name, a)
+
+
 def test_unweighted_mfma_graded_accumulator_wraps(monkeypatch):
     """The graded sweep relies on v_mfma_i32 adding in two's complement (tools/microbench/mfma_i8_wrap.hip): with signed
     digits an accumulator may pass 2^31 on the way to a sum that fits.  Here it does: 131,071 branches of integer
