@@ -209,8 +209,9 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     hbm = {"bound": "hbm", "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes}
     if traffic and traffic.get("traffic"):
-        # what the counters saw move (2*FETCH_SIZE + WRITE_SIZE of the profiled build, per launch) over THIS run's
-        # kernel time: the rocprof-reported rate SURVEY 8(d) asks for, against the spec and the measured-copy ceiling
+        # what the counters saw move (2*FETCH_SIZE + WRITE_SIZE per launch: of the profiled build here; main() replaces
+        # the primary record's by a measurement of this box, live_traffic) over THIS run's kernel time: the
+        # rocprof-reported rate SURVEY 8(d) asks for, against the spec and the measured-copy ceiling
         gbps = traffic["traffic"] / sec / 1e9
         hbm["measured_GBps"] = gbps
         hbm["measured_frac_of_8000"] = gbps / HBM_PEAK_GBPS
@@ -277,6 +278,81 @@ def traffic_of(name, world, info, weighted):
     except Exception:
         pass
     return None
+
+
+def under_a_profiler():
+    """True when this process already runs under rocprofv3 / rocprof (tools/profile_round.sh, tools/pmc.sh, or whoever
+    runs the bench that way): no second profiler is started from inside one."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    return "rocprof" in pre or any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def live_traffic(args, kernel, timeout_s=150.0):
+    """Fabric bytes per launch of `kernel` (the primary record's dominant kernel) measured ON THIS BOX, now:
+    two child runs of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes, counters
+    only besides the kernel trace that names the dispatches, the program directly behind `--` -- on the primary
+    workload with 3 timed launches, the per-launch averages combined as MI355X_MICROARCH.md prescribes for gfx950:
+    (2 * FETCH_SIZE + WRITE_SIZE) KiB (wide streaming reads are tallied at half their bytes; Infinity-Cache hits are
+    counted, so this is traffic beyond L2, not DRAM traffic alone).  Called last, when every timing of the line
+    is done; any failure (no rocprofv3, a refused counter, a timeout) returns None and the line falls back on the
+    committed constants of profiles/traffic.json, saying so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "no rocprofv3 on this box"
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--precision", args.precision,
+             "--lengths", args.lengths, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+             "--no-live-traffic"] + (["--unweighted"] if args.unweighted else [])
+    got = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="ff_pmc_", dir="/tmp") as d:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 10:
+                return None, "time budget spent before the %s pass" % counter
+            out = os.path.join(d, counter)
+            try:
+                r = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child,
+                                   cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass did not finish in %.0f s" % (counter, left)
+            except OSError as e:
+                return None, "rocprofv3 did not start: %s" % e
+            if r.returncode != 0:
+                return None, "the %s pass ended with code %d: %s" % (counter, r.returncode,
+                                                                     r.stderr.decode(errors="replace").strip().splitlines()[-1:])
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for %s in the counter file" % (counter, kernel)
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    fetch, nf = got["FETCH_SIZE"]
+    write, nw = got["WRITE_SIZE"]
+    return {"traffic": (2.0 * fetch + write) * 1024.0,
+            "traffic_source": "live on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of "
+                              "`bench.py --steps 3`, averages over %d and %d launches of %s), (2*FETCH_SIZE + WRITE_SIZE) KiB; "
+                              "%.0f s" % (nf, nw, kernel, time.perf_counter() - t0),
+            "fetch_size_kib": fetch, "write_size_kib": write}, None
+
+
+def with_traffic(roofline, traffic):
+    """The hbm.measured_* figures of a roofline record, for `traffic` bytes per launch (see roofline_of)."""
+    sec = max(roofline["kernel_ms"], 1e-9) * 1e-3
+    gbps = traffic["traffic"] / sec / 1e9
+    roofline["hbm"].update({"measured_GBps": gbps, "measured_frac_of_8000": gbps / HBM_PEAK_GBPS,
+                            "measured_frac_of_6290": gbps / HBM_COPY_GBPS,
+                            "traffic_ratio": traffic["traffic"] / roofline["hbm"]["algorithmic_bytes"]})
+    roofline.update(traffic)
+    return roofline
 
 
 def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
@@ -397,6 +473,9 @@ def main():
                     help="branch lengths: the generator's multiples of 1/1024, or log-normal (sigma 1.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the primary line")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/traffic.json only (default at N = 1: two child runs under "
+                         "rocprofv3 --pmc measure it on this box once the timings are done)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--end-to-end", action="store_true", help="also time ff_unifrac_dists through host buffers")
@@ -537,6 +616,26 @@ def main():
             del n2
         if rank == 0:
             out["secondary"] = sec
+    if rank == 0 and world == 1 and not args.no_live_traffic and not ctx.rehearse:
+        # last, with every timing of the line done: the primary kernel's traffic beyond L2 as this box's counters see it
+        if under_a_profiler():
+            out["roofline"]["traffic_note"] = "run under a profiler: no live counter passes"
+        else:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            t, why = None, None
+            try:
+                t, why = live_traffic(args, out["roofline"]["kernel"])
+            except Exception as e:  # (the line must come out whatever happens to the counter passes)
+                why = "%s: %s" % (type(e).__name__, e)
+            if t:
+                committed = out["roofline"].get("traffic")
+                with_traffic(out["roofline"], t)
+                if committed:
+                    out["roofline"]["traffic_committed"] = committed  # (profiles/traffic.json's figure, for comparison)
+            else:
+                out["roofline"]["traffic_note"] = "live counter passes failed (%s): the figure is the committed one" % why
+                log("live traffic: %s" % why)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -11,13 +11,13 @@ pytestmark = pytest.mark.perf
 
 def test_c2_pass_takes_microseconds_not_tens_of_them():
     """25 us per pass of two launches in round 2; 6.2-8.6 us measured since round 3 (one launch)."""
-    out, _ = run_bench("--workload", "C2", "--steps", "400", "--warmup", "20", "--no-cpu-baseline", "--no-secondary")
+    out, _ = run_bench("--workload", "C2", "--steps", "400", "--warmup", "20", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic")
     assert out["ms_per_step"] <= 0.020, out["ms_per_step"]
     assert out["ms_per_step"] <= out["roofline"]["kernel_ms_between_events"] + 0.005
 
 
 def test_graded_planes_cost_less_than_two_sweeps_and_exact_unweighted_half_of_the_weighted_walk():
-    out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--no-cpu-baseline")
+    out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--no-cpu-baseline", "--no-live-traffic")
     sec = out["secondary"]
     assert sec[1]["ms_per_step"] < sec[5]["ms_per_step"] < 2.0 * sec[1]["ms_per_step"]   # (two sweeps cost 1.85 x)
     assert sec[6]["ms_per_step"] < 0.7 * sec[0]["ms_per_step"]       # pair_exact_unw_kernel 10 ms, pair_exact64_skip_kernel 21
