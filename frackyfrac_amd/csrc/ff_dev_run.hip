@@ -390,14 +390,16 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         const int forced = env_int("FF_X_TILE_H", 0);
         int h = X_TILE_H_DEFAULT;
         // A shard whose waves all fit the device at once is bound by one wave's chain of trips, not by the
-        // vector ALU: the lowest tile that still keeps them all resident (C2: 1.31 ms with 16 rows, 0.84 with 8,
-        // 0.56 with 4; 2 rows and 16 two-value scalar loads per trip are slower again: 0.75).
+        // vector ALU: the lowest tile that still leaves the device about half empty (C2: 1.31 ms with 16 rows, 0.84
+        // with 8, 0.56 with 4; 2 rows and 16 two-value scalar loads per trip are slower again: 0.75).  Weighted, 10,000
+        // leaves, ms with 4 / 8 / 12 rows: 1,280 samples 5.02 / 5.09 / 6.10, 1,536: 6.09 / 5.86 / 6.08, 1,792: 8.95 / 7.41 /
+        // 7.68, 2,048: 12.08 / 8.15 / 7.41 -- 4 rows up to 0.55 of the wave slots, 8 rows up to 0.45 of them.
         const int64_t resident = (int64_t)inf.n_compute_units * 4 * 8;
         bool small = false;
         for (int cand : {4, 8}) {
             std::vector<Tile> count;
             build_tiles(inf.n_samples, inf.row_begin, inf.row_end, cand, X_TILE_J, false, &count);
-            if ((int64_t)count.size() <= resident) {
+            if ((int64_t)count.size() * 100 <= resident * (cand == 4 ? 55 : 45)) {
                 h = cand;
                 small = true;
                 break;

@@ -21,7 +21,7 @@
 #define XW_X(R, N) ".Lx" #R "_%=:\n" "v_add_f64 %[a" #R "], %[a" #R "], %[p]\n" "v_add_f64 %[c" #R "], %[c" #R "], %[p]\n" \
                    "s_cmp_eq_u64 %[x" #N "], 0\n" "s_cbranch_scc0 .Ly" #N "_%=\n"
 #define XW_BOTH(R) "v_add_f64 %[t], %[x" #R "], -%[y]\n" "v_mul_f64 %[t], %[l], |%[t]|\n" "v_add_f64 %[a" #R "], %[a" #R "], %[t]\n" \
-                   "v_add_f64 %[s], %[x" #R "], %[y]\n" "v_mul_f64 %[s], %[l], %[s]\n" "v_add_f64 %[c" #R "], %[c" #R "], %[s]\n"
+                   "v_add_f64 %[t], %[x" #R "], %[y]\n" "v_mul_f64 %[t], %[l], %[t]\n" "v_add_f64 %[c" #R "], %[c" #R "], %[t]\n"
 #define XW_Y(R, N) ".Ly" #R "_%=:\n" XW_BOTH(R) "s_cmp_eq_u64 %[x" #N "], 0\n" "s_cbranch_scc1 .Lx" #N "_%=\n"
 #define XW_XLAST(R) ".Lx" #R "_%=:\n" "v_add_f64 %[a" #R "], %[a" #R "], %[p]\n" "v_add_f64 %[c" #R "], %[c" #R "], %[p]\n" "s_branch .Lend_%=\n"
 #define XW_YLAST(R) ".Ly" #R "_%=:\n" XW_BOTH(R)
@@ -45,8 +45,8 @@ template <int H> struct XwBranch;
         static __device__ __forceinline__ void run(double (&a)[H], double (&c)[H], const double (&x)[H], double y, double l, \
                                                    double p)                                                               \
         {                                                                                                                 \
-            double t, s;                                                                                                  \
-            asm volatile(XW_BLOCK(H) : [t] "=&v"(t), [s] "=&v"(s) XW_ROWS##H(XW_ACC)                                       \
+            double t;  /* (one temporary for both products: 64 registers at 12 rows, eight waves per SIMD) */               \
+            asm volatile(XW_BLOCK(H) : [t] "=&v"(t) XW_ROWS##H(XW_ACC)                                                     \
                          : [y] "v"(y), [l] "s"(l), [p] "v"(p) XW_ROWS##H(XW_XS) : "scc", "memory");                        \
         }                                                                                                                 \
     };
