@@ -22,7 +22,7 @@ SWITCHES = [
     ("FF_REFINE", "1", "tuning", "FIXED32: exact re-computation of nearly equal pairs (0: tests of what it protects against)"),
     ("FF_AUDIT", "1", "tuning", "FIXED32: the run-time audit -- the uniform sample of a shard's pairs and the run's pairs just above the refinement bound, against binary64"),
     ("FF_EXACT_UNW", "1", "tuning", "EXACT64 unweighted on pair_exact_unw_kernel (0: the weighted kernel's arithmetic on presence as 1.0 / 0.0; same bits, three times the time)"),
-    ("FF_XU_JMAX", "unset", "tuning", "1 / 2 forces the width of pair_exact_unw_kernel's tiles in 64-sample column groups (unset: 2, 1 for shards of fewer tiles than SIMDs)"),
+    ("FF_XU_JMAX", "unset", "tuning", "1 / 2 forces the width of pair_exact_unw_kernel's tiles in 64-sample column groups (unset: 2, 1 for shards of fewer than six such tiles per CU)"),
     ("FF_X_SKIP", "1", "tuning", "EXACT64 weighted on pair_exact64_skip_kernel, which takes the reference's shortcut for branches a row has not (0: pair_exact64_kernel, six operations for every term; same bits)"),
     ("FF_X_TILE_H", "by size", "tuning", "rows of a weighted EXACT64 pair tile: 4, 8, 10, 12, 14 or 16 (any height: same bits)"),
     ("FF_X_CALIBRATE", "0", "tuning", "1: a weighted EXACT64 plan that will run many times times the tile heights when it is scheduled"),
