@@ -219,7 +219,7 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         hbm["traffic_ratio"] = traffic["traffic"] / alg_bytes   # counter bytes / algorithmic bytes: re-reads
     kname = KERNEL_NAMES[kernel]
     if kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
-        kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,072 samples)
+        kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,300 samples)
     common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
     # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2, 7: VALU_PEAK_TLANEOPS / 2,

@@ -57,8 +57,9 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     // paid for with half the vector prefetch) for pair_sad_kernel12.  FF_WAVES_PER_WG = 8 / 12 forces one; otherwise
     // the 12-wave variant takes
     //   * a shard that BEGINS AT ROW 0 -- a whole problem, the first rank's shard: a triangle -- and holds more than
-    //     2.25 tiles per workgroup (3,072 samples up on 256 CUs): tools/shape_sweep.py, 4,096 samples 4.98 -> 4.91 ms,
-    //     8,192 19.9 -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9; it ties at 2,560 and loses below 2,048;
+    //     2.75 tiles per workgroup (3,300 samples up on 256 CUs): tools/shape_sweep.py, 4,096 samples 4.98 -> 4.91 ms,
+    //     8,192 19.9 -> 19.2, 8,192 x 50k leaves 100.3 -> 95.9; 3,584: 3.94 -> 3.80; it ties at 3,328, loses 1.7 % at 3,072
+    //     (2.44 tiles per workgroup) and 10 % at 2,816;
     //   * ANY shard with 200,000 or more (tile, branch row) units per workgroup -- about 11 ms of kernel: on the
     //     trapezoid of a later row shard the third wave pays once a shard is several rounds long, and not before
     //     (tools/shard_balance.py at HEAD, profiles/r04_shard_balance.txt, max over ranks in ms, 8 waves / 12 waves:
@@ -68,7 +69,7 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     //     size, and said otherwise in this comment.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
     if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() &&
-        ((inf.row_begin == 0 && inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 9) ||
+        ((inf.row_begin == 0 && inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 11) ||
          (double)inf.n_tiles * (double)rows >= 200000.0 * (double)pl->n_workgroups))
         pl->waves_per_wg = L_WAVES_PER_WG;
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU

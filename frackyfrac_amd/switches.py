@@ -13,7 +13,7 @@ SWITCHES = [
     ("FF_MFMA_GRADED", "1", "tuning", "lengths of more than two base-128 digits: rows staged by length with signed digits, one sweep of three planes then two (0: base-128 digits in branch order, two planes per sweep, two or three sweeps; same integers)"),
     ("FF_MFMA_PRIVATE_MB", "2048", "tuning", "memory up to which every item of the matrix-core schedule owns a partial tile (0: only the remainder's ranges)"),
     ("FF_MFMA_FUSED_FINISH", "unset", "tuning", "0 keeps the separate finish launch where a kernel could write the distances itself"),
-    ("FF_WAVES_PER_WG", "unset", "tuning", "8 / 12 forces the two- / three-waves-per-SIMD weighted pair kernel (unset: 12 for a shard that begins at row 0 and holds 2.25 or more tiles per CU, about 3,072 samples up, and for any shard of 200,000 or more (tile, branch row) units per CU; else 8)"),
+    ("FF_WAVES_PER_WG", "unset", "tuning", "8 / 12 forces the two- / three-waves-per-SIMD weighted pair kernel (unset: 12 for a shard that begins at row 0 and holds 2.75 or more tiles per CU, about 3,300 samples up, and for any shard of 200,000 or more (tile, branch row) units per CU; else 8)"),
     ("FF_XCD_SLICES", "unset", "tuning", "unset: the schedule builds the plain rounds and the XCD-sliced ones with 2, 4, 8 slices and keeps the best by estimated makespan; 0 forbids sliced rounds, 2 / 4 / 8 asks for that slicing wherever it applies"),
     ("FF_PLANES", "255", "tuning", "accumulator planes for split tiles (1: atomics only)"),
     ("FF_COMPACT", "1", "tuning", "stage only the branches some sample touches"),
