@@ -36,3 +36,57 @@ def test_self_launch_relays_the_ranks_exit_code_and_keeps_the_parent_off_the_gpu
     assert "must be launched with" not in r.stderr
     assert "bench.py needs a GPU" in r.stderr          # said by the ranks
     assert "parent imported torch: False" in r.stderr
+
+
+def _fake_rocprofv3(tmp_path, body):
+    """A stand-in for rocprofv3 on PATH: parses `--pmc NAME` and `-d DIR` and runs `body` (python source with NAME and
+    DIR in scope) instead of profiling anything."""
+    d = tmp_path / "bin"
+    d.mkdir()
+    exe = d / "rocprofv3"
+    exe.write_text("#!%s\nimport os, sys\na = sys.argv\nNAME = a[a.index('--pmc') + 1]\nDIR = a[a.index('-d') + 1]\n%s\n"
+                   % (sys.executable, body))
+    exe.chmod(0o755)
+    return str(d)
+
+
+def test_live_traffic_reads_the_counter_files_and_falls_back_with_a_reason(tmp_path, monkeypatch):
+    """bench.py's live_traffic without a GPU: the two counter passes (FETCH_SIZE, WRITE_SIZE) are child runs of rocprofv3;
+    here a stand-in writes the counter file a pass would leave.  Per-launch averages of the named kernel's rows only,
+    (2 * FETCH_SIZE + WRITE_SIZE) KiB; a pass that fails, finds no rows or cannot start gives None and the reason."""
+    import argparse
+    import bench
+
+    args = argparse.Namespace(workload="C3", precision="fixed32", lengths="generator", unweighted=False)
+    ok = '''
+os.makedirs(os.path.join(DIR, "host"), exist_ok=True)
+v = {"FETCH_SIZE": (1000.0, 3000.0), "WRITE_SIZE": (10.0, 30.0)}[NAME]
+with open(os.path.join(DIR, "host", "77_counter_collection.csv"), "w") as f:
+    f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\\n")
+    f.write("1,void pair_sad_kernel12(unsigned int const*),%s,%r\\n" % (NAME, v[0]))
+    f.write("2,void pair_sad_kernel12(unsigned int const*),%s,%r\\n" % (NAME, v[1]))
+    f.write("3,finish_fixed32_kernel(),%s,999999.0\\n" % NAME)
+    f.write("4,void pair_sad_kernel12(unsigned int const*),SOMETHING_ELSE,5.0\\n")
+'''
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, ok) + os.pathsep + os.environ["PATH"])
+    t, why = bench.live_traffic(args, "pair_sad_kernel12")
+    assert why is None and t["fetch_size_kib"] == 2000.0 and t["write_size_kib"] == 20.0
+    assert t["traffic"] == (2 * 2000.0 + 20.0) * 1024.0 and t["traffic_source"].startswith("live on this box")
+    # merged into a roofline record: the measured rate and the ratio to the algorithmic bytes
+    rl = {"kernel_ms": 2.0, "hbm": {"algorithmic_bytes": 1024.0 * 1005.0}}
+    bench.with_traffic(rl, t)
+    assert abs(rl["hbm"]["traffic_ratio"] - 4.0) < 1e-12 and abs(rl["hbm"]["measured_GBps"] - t["traffic"] / 2e-3 / 1e9) < 1e-12
+    # no rows for the kernel asked for
+    t, why = bench.live_traffic(args, "pair_exact_unw_kernel")
+    assert t is None and "no FETCH_SIZE rows" in why
+    # a pass that fails
+    (tmp_path / "bin" / "rocprofv3").unlink()
+    (tmp_path / "bin").rmdir()
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, "sys.stderr.write('counter refused\\\\n'); sys.exit(3)") + os.pathsep + os.environ["PATH"])
+    t, why = bench.live_traffic(args, "pair_sad_kernel12")
+    assert t is None and "code 3" in why and "counter refused" in why
+    # inside a profiler nothing is started at all
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.under_a_profiler()
+    monkeypatch.delenv("LD_PRELOAD")
+    assert not bench.under_a_profiler()
