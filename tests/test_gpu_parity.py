@@ -1255,6 +1255,47 @@ def test_out_of_device_memory_is_an_error_not_a_crash():
             assert rel_err(got, want) <= (0 if prec == "exact64" else WEIGHTED_RTOL)
 
 
+def test_plans_give_their_device_memory_back():
+    """A service creates and destroys plans all day: every kernel family's plan -- weighted and unweighted FIXED32,
+    EXACT64 (both kernels), the exact unweighted kernel on lengths off the grid, the literal walk, a re-targeted shard,
+    the streaming entry point -- run and closed forty times leaves the device's free memory where it was."""
+    import torch
+
+    tree, ptr, idx, val = synth.make(1500, 600, 0.15, 31)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    tree_ln, *_ = synth.make(1500, 600, 0.15, 31)
+    rng = np.random.default_rng(2)
+    bl = rng.lognormal(-3.0, 1.5, len(tree_ln.branch_len))
+    bl[0] = 0.0
+    tree_ln.branch_len = bl
+    nodes_ln = ff.flatten_leaf_csr(ff.parse_newick(tree_ln.newick()), ptr, idx, val)
+
+    def cycle():
+        for nd, weighted, prec in ((nodes, True, "fixed32"), (nodes, False, "fixed32"), (nodes, True, "exact64"),
+                                   (nodes_ln, False, "auto"), (nodes_ln, False, "fixed32")):
+            plan = ff.Plan(nd, weighted, precision=prec, rank=0, world=2)
+            plan.run_host()
+            plan.set_shard(1, 2)
+            plan.run_host()
+            plan.close()
+        plan = ff.Plan.from_leaves(T, ptr, idx, val, True, leave_unnormalized="reference")
+        plan.run_host()
+        plan.close()
+        gen = ff.api.unifrac_dists_stream(nodes, True, max_pairs_per_chunk=200_000)
+        next(gen)
+        gen.close()                                          # (a consumer that stops early)
+
+    cycle()                                                  # (code objects, pools: before the baseline)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (32 << 20), "device memory lost over 40 cycles: %.1f MB" % ((free0 - free1) / 1e6)
+
+
 @pytest.mark.parametrize("weighted", [True, False])
 def test_more_than_2_to_the_32_pairs(weighted):
     """Maximum sizes: 93,000 samples = 4.3e9 pairs (35 GB of results) on a 16-leaf tree.
