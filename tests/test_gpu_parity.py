@@ -1258,7 +1258,7 @@ def test_out_of_device_memory_is_an_error_not_a_crash():
 def test_plans_give_their_device_memory_back():
     """A service creates and destroys plans all day: every kernel family's plan -- weighted and unweighted FIXED32,
     EXACT64 (both kernels), the exact unweighted kernel on lengths off the grid, the literal walk, a re-targeted shard,
-    the streaming entry point -- run and closed forty times leaves the device's free memory where it was."""
+    the streaming entry point -- run and closed forty times leaves the device's free memory, and the process's, where it was."""
     import torch
 
     tree, ptr, idx, val = synth.make(1500, 600, 0.15, 31)
@@ -1286,14 +1286,20 @@ def test_plans_give_their_device_memory_back():
         next(gen)
         gen.close()                                          # (a consumer that stops early)
 
-    cycle()                                                  # (code objects, pools: before the baseline)
+    import psutil
+
+    for _ in range(3):
+        cycle()                                              # (code objects, pools, the allocator's arenas: before the baseline)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
+    rss0 = psutil.Process().memory_info().rss
     for _ in range(40):
         cycle()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
+    rss1 = psutil.Process().memory_info().rss
     assert free0 - free1 < (32 << 20), "device memory lost over 40 cycles: %.1f MB" % ((free0 - free1) / 1e6)
+    assert rss1 - rss0 < (96 << 20), "host memory grown over 40 cycles: %.1f MB" % ((rss1 - rss0) / 1e6)
 
 
 @pytest.mark.parametrize("weighted", [True, False])
