@@ -19,6 +19,11 @@
  *     a usable GPU the compute entry points fail with FF_ERR_DEVICE.
  *   - Pair order everywhere is common.IterPairs (common/common.go:21-31): slot
  *     k = i*(i-1)/2 + j for sample indices i > j >= 0, i.e. numpy.tril_indices(N,-1).
+ *   - Threads: the library keeps no state outside the objects it hands out (ff_tune's
+ *     switches apart, which a lock guards).  Different plans, trees, tables and one-call
+ *     entry points may be used from different host threads at the same time -- a Go
+ *     host's goroutines --; ONE object is used by one thread at a time.  A call leaves
+ *     the calling thread's current HIP device as it found it.
  */
 #ifndef FRACKYFRAC_AMD_H
 #define FRACKYFRAC_AMD_H

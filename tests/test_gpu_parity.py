@@ -1302,6 +1302,41 @@ def test_plans_give_their_device_memory_back():
     assert rss1 - rss0 < (96 << 20), "host memory grown over 40 cycles: %.1f MB" % ((rss1 - rss0) / 1e6)
 
 
+def test_plans_of_different_host_threads_run_side_by_side():
+    """The library keeps no state outside its plans (the tuning switches apart, which a lock guards): a host may create,
+    run and destroy plans from several threads at once -- one thread per plan at a time --, as a Go host's goroutines
+    would.  Six threads, each with its own problem, metric and precision, twelve passes each (ctypes drops the GIL for
+    the length of a call): every pass gives the bits of the same plan run alone."""
+    import threading
+
+    jobs = []
+    for k, (n, nl, weighted, prec) in enumerate([(900, 400, True, "fixed32"), (1100, 300, False, "fixed32"),
+                                                 (700, 500, True, "exact64"), (1300, 200, False, "exact64"),
+                                                 (2300, 150, True, "fixed32"), (600, 900, True, "auto")]):
+        nodes, *_ = synth_problem(n, nl, 0.2, 100 + k)
+        jobs.append((nodes, weighted, prec, ff.unifrac_dists(nodes, weighted, precision=prec)))
+    errors = []
+
+    def work(nodes, weighted, prec, want):
+        try:
+            for rep in range(12):
+                plan = ff.Plan(nodes, weighted, precision=prec, rank=rep % 2, world=2)
+                a, b = ff.shard_slots(nodes.n_samples, rep % 2, 2)
+                got = plan.run_host()
+                plan.close()
+                if not np.array_equal(got, want[a:b], equal_nan=True):
+                    errors.append("mismatch %s %s pass %d" % (weighted, prec, rep))
+        except Exception as e:  # noqa: BLE001 (reported below, from the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+
+
 @pytest.mark.parametrize("weighted", [True, False])
 def test_more_than_2_to_the_32_pairs(weighted):
     """Maximum sizes: 93,000 samples = 4.3e9 pairs (35 GB of results) on a 16-leaf tree.
