@@ -1100,6 +1100,38 @@ def test_kernel_choice_per_rank_of_the_baseline_configs():
     plan.close()
 
 
+def test_tile_shapes_of_the_exact_kernels_by_shard_size():
+    """What the plans take for the two EXACT64 kernels, as swept over sample counts in round 4 (ff_dev_run.hip
+    schedule_exact64 / schedule_exact_unw hold the measurements): weighted 4-row tiles while they fill at most 0.55 of the
+    device's wave slots, 8-row tiles up to 0.45, then 12 or 16 rows by the tile count; unweighted single column groups
+    below six double-width tiles per CU.  Read off the plan's tile count."""
+    def tiles(n, h, width):
+        return sum(-(-(min(i0 + h, n) - 1) // width) for i0 in range(0, n, h) if min(i0 + h, n) - 1 > 0)   # (build_tiles: columns j < w)
+
+    probe = ff.Plan(synth_problem(64, 20, 0.5, 1)[0], True, precision="exact64")
+    cus = probe.info.n_compute_units
+    probe.close()
+    slots = cus * 4 * 8
+    for n, want_h in ((1024, 4), (1280, 4), (1536, 8), (1792, 8), (2048, 12), (2560, 12), (4096, 12)):
+        nodes, *_ = synth_problem(n, 200, 0.2, 5)
+        plan = ff.Plan(nodes, True, precision="exact64")
+        got = plan.info.n_tiles
+        plan.close()
+        assert got == tiles(n, want_h, 64), (n, want_h, got, {h: tiles(n, h, 64) for h in (4, 8, 12, 16)})
+        if want_h == 4:
+            assert tiles(n, 4, 64) * 100 <= slots * 55
+        elif want_h == 8:
+            assert tiles(n, 4, 64) * 100 > slots * 55 and tiles(n, 8, 64) * 100 <= slots * 45
+    for n, want_j in ((1024, 1), (1536, 1), (2048, 2), (4096, 2)):
+        nodes, *_ = synth_problem(n, 200, 0.2, 5)
+        plan = ff.Plan(nodes, False, precision="exact64")
+        assert plan.info.kernel == 5
+        got = plan.info.n_tiles
+        plan.close()
+        per_group_single = tiles(n, 8, 64)
+        assert (got == per_group_single) == (want_j == 1), (n, want_j, got, per_group_single)
+
+
 @pytest.mark.parametrize("weighted", [True, False])
 def test_branch_compaction_on_a_reference_tree_larger_than_the_data(monkeypatch, weighted):
     """A 20,000-leaf tree of which the samples touch 4 % of the leaves: only the branches
