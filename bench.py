@@ -2,7 +2,7 @@
 """bench.py -- throughput of the UniFrac pair reduction (the hot path) on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--precision fixed32]
-                    [--scaling weak|strong] [--no-secondary] [--no-cpu-baseline]
+                    [--scaling weak|strong] [--no-secondary] [--no-cpu-baseline] [--no-live-traffic]
 
 A "step" is one pass of the hot path over one batch of synthetic input: the pair
 kernels over this rank's row shard of the staged matrix (already resident in HBM)
@@ -30,7 +30,11 @@ all ranks' pairs / max-over-ranks time.
 
 Prints ONE JSON line on rank 0; `roofline` describes the dominant kernel, timed with HIP
 events around every launch of the timed region on the stream it is launched on
-(ff_plan_run_timed / ff_plan_timing_collect).
+(ff_plan_run_timed / ff_plan_timing_collect).  At N = 1 the primary record's `roofline.traffic`
+-- the dominant kernel's bytes beyond L2 per launch -- is counted on the box the bench runs on:
+with every timing done, two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE,
+WRITE_SIZE: separate passes, counters only); `--no-live-traffic`, a bench that is itself under a
+profiler, or a failed pass fall back on the committed counts of profiles/traffic.json and say so.
 """
 import argparse
 import json
