@@ -124,6 +124,9 @@ SIGNATURES = {
     "ff_unifrac": (c_int, [c_void_p, c_void_p, POINTER(ff_options), c_int, c_void_p, c_char_p, c_size_t]),
     "ff_format_float": (c_int, [c_double, c_char_p]),
     "ff_write_distances": (c_int, [c_char_p, c_void_p, c_int64, c_int, c_char_p, c_size_t]),
+    "ff_cpu_quota": (c_int, []),
+    "ff_text_bound": (c_size_t, [c_int64]),
+    "ff_format_distances_device": (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_size_t), c_void_p, c_char_p, c_size_t]),
     "ff_frcfrc_main": (c_int, [c_int, POINTER(c_char_p)]),
     "ff_tune": (c_int, [c_char_p, c_char_p]),
     "ff_synth_counts": (c_int, [c_int64, c_double, ctypes.c_uint64, c_int64, c_int64, c_int, c_void_p]),

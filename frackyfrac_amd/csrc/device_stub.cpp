@@ -27,8 +27,25 @@ int ShardRunner::run(int32_t, int32_t, double *, ff_plan_info *, char *err, size
 {
     return fail(FF_ERR_DEVICE, err, errlen, "device stub");
 }
+int ShardRunner::run_device(int32_t, int32_t, const double **, int64_t *, ff_plan_info *, char *err, size_t errlen)
+{
+    return fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
+int ShardRunner::prepare(int32_t, int32_t, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
+int ShardRunner::device() const { return 0; }
+struct TextPipeline::Impl {};
+TextPipeline::TextPipeline(DistWriter *) : impl_(nullptr) {}
+TextPipeline::~TextPipeline() {}
+int TextPipeline::prepare(int64_t, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
+int TextPipeline::submit(int, const double *, int64_t, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
+int TextPipeline::drain(char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
 }  // namespace ff
 
+extern "C" size_t ff_text_bound(int64_t n) { return n > 0 ? (size_t)n * 25 : 0; }
+extern "C" int ff_format_distances_device(const double *, int64_t, char *, size_t *, void *, char *err, size_t errlen)
+{
+    return ff::fail(FF_ERR_DEVICE, err, errlen, "device stub");
+}
 extern "C" int ff_unifrac_dists(const ff_problem *, const ff_options *, double *, char *err, size_t errlen)
 {
     return ff::fail(FF_ERR_DEVICE, err, errlen, "device stub");

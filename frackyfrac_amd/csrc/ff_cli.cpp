@@ -32,7 +32,7 @@ void usage()
     fputs("  -l\tLeave abundance values unnormalized (default normalize each sample to sum up to 1)\n", stderr);
     fputs("  -l-compat\n    \tWith -l: the reference's own -l, whose lists stay unsorted (its values, bit for bit)\n", stderr);
     fputs("  -o string\n    \tPath to output file (default stdout)\n", stderr);
-    fputs("  -p int\n    \tNumber of threads (default 1)\n", stderr);
+    fputs("  -p int\n    \tNumber of threads (default 1: here, the CPUs the process may use)\n", stderr);
     fputs("  -precision string\n    \tDevice arithmetic: auto, fixed32 or exact64 (default \"auto\")\n", stderr);
     fputs("  -s\tInput is in sparse format\n", stderr);
     fputs("  -stats\n    \tPrint device statistics to stderr\n", stderr);
@@ -50,6 +50,7 @@ struct Flags {
     std::string in, out, tree, precision = "auto";
     bool weighted = false, sparse = false, nnorm = false, stats = false, lcompat = false;
     long nt = 1, gpus = 1;
+    bool nt_given = false;
 };
 
 bool parse_bool(const std::string &v, bool *out)
@@ -138,6 +139,7 @@ int parse_flags(int argc, char **argv, Flags *f)
                 return 2;
             }
             (name == "p" ? f->nt : f->gpus) = v;
+            if (name == "p") f->nt_given = true;
         }
     }
     return -1;
@@ -194,10 +196,14 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     else if (f.precision == "exact64") opt.precision = FF_PRECISION_EXACT64;
     else return die("bad -precision: want auto, fixed32 or exact64");
 
+    // -p: the reference's default is ONE thread, for a program whose every phase runs on the CPU.  Here the pair space
+    // is the device's, and what is left for the host -- parsing the table, writing the file -- takes the CPUs the
+    // process is allowed (its cgroup quota / affinity mask) unless -p says fewer or more.
+    const int nt = f.nt_given ? (int)std::min<long>(f.nt, 256) : (int)ff::cpu_quota();
     char err[1024];
     auto t0 = std::chrono::steady_clock::now();
     auto last = t0;
-    double phase[6] = {0, 0, 0, 0, 0, 0};  // tree, load, validate, convert, distances, write
+    double phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tree, load, validate, open, convert, distances, write, close
     auto lap = [&](int k) {
         auto now = std::chrono::steady_clock::now();
         phase[k] = std::chrono::duration<double>(now - last).count();
@@ -216,7 +222,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
 
     fputs("Loading abundances\n", stderr);
     ff_table *table = nullptr;
-    if (ff_table_read_file_mt(f.in.empty() ? nullptr : f.in.c_str(), f.sparse, (int)f.nt, &table, err, sizeof err)) {
+    if (ff_table_read_file_mt(f.in.empty() ? nullptr : f.in.c_str(), f.sparse, nt, &table, err, sizeof err)) {
         ff_tree_free(tree);
         return die(err);
     }
@@ -230,35 +236,41 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     }
     lap(2);
 
+    // frcfrc.go:55: the output is opened once the input is known to be good
+    ff::DistWriter writer;
+    if (writer.open(f.out.empty() ? nullptr : f.out.c_str(), nt, err, sizeof err)) {
+        ff_table_free(table);
+        ff_tree_free(tree);
+        return die(err);
+    }
+    lap(3);
+
     fputs("Converting abundances\n", stderr);  // unifrac.go:101
     std::vector<int64_t> leaf_ptr, leaf_idx;
     std::vector<double> leaf_val;
-    ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val, (int)f.nt);
+    ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val, nt);
     const int64_t n = ff_table_num_samples(table);
     ff_table_free(table);
-    lap(3);
-
     warm.join();
-    fputs("Calculating distances\n", stderr);  // unifrac.go:122
     // The pair space is cut into equal-pair row shards (ff_shard_rows).  -gpus G runs G of them
     // at a time, one host thread per shard, shard g of a pass on device g modulo the devices
     // present.  (Across processes the same shards are gathered: frackyfrac_amd/distributed.py.)
     // Shards hold at most 2^25 pairs (fewer when the device is short of memory): larger
-    // problems run in several passes, and a pass is formatted and appended to the output
-    // by a writer thread while the next one is reduced (two sets of result buffers).  Like the
-    // reference, which streams pair by pair (unifrac.go:209-228), memory does not grow with
-    // the square of the samples.
+    // problems run in several passes.  The distances of a pass never come to the host as numbers: they are
+    // formatted where they are (ff_kernels_fmt.hpp) and the text goes to the file through a ring of pinned
+    // slots while the next pass is reduced (ff::TextPipeline).  Like the reference, which streams pair by
+    // pair (unifrac.go:209-228), memory does not grow with the square of the samples.
     const int ndev = ff::device_count();
     if (ndev <= 0) {
         ff_tree_free(tree);
         return die("no HIP device available; this engine has no CPU path");
     }
     const int64_t P = ff_num_pairs(n);
-    int64_t budget = (int64_t)1 << 25;  // pairs per shard: 256 MB of results, written while the next shard runs
+    int64_t budget = (int64_t)1 << 25;  // pairs per shard: 256 MB of results + up to 0.8 GB of their text, twice
     {
         const size_t free_b = ff::device_free_bytes(0);
-        // 4 B accumulator + 8 B result per pair, the staged matrix and the rest in the other 40 %
-        if (free_b > 0) budget = std::min<int64_t>(budget, (int64_t)((double)free_b * 0.6 / 12.0));
+        // 4 B accumulator + 8 B result + 2 x 25 B of text per pair, the staged matrix and the rest in the other 40 %
+        if (free_b > 0) budget = std::min<int64_t>(budget, (int64_t)((double)free_b * 0.6 / 62.0));
         if (const char *e = getenv("FF_CLI_MAX_PAIRS"))  // (tests)
             if (atoll(e) > 0) budget = atoll(e);
         budget = std::max<int64_t>(budget, 1);
@@ -271,53 +283,71 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         ff_tree_free(tree);
         return die("too many samples");
     }
-    ff::DistWriter writer;
-    if (writer.open(f.out.empty() ? nullptr : f.out.c_str(), (int)f.nt, err, sizeof err)) {
+    // the ring's pinned memory is made ready while the plan is built (about 20 bytes of text per pair)
+    ff::TextPipeline pipe(&writer);
+    char ring_err[1024] = {0};
+    int ring_rc = 0;
+    std::thread ring([&] { ring_rc = pipe.prepare(std::min<int64_t>(P, budget * G) * 20, ring_err, sizeof ring_err); });
+    struct Joiner2 {
+        std::thread &t;
+        ~Joiner2() { if (t.joinable()) t.join(); }
+    } joiner2{ring};
+    ff_plan_info info{};
+    // one runner per device slot: stage A and the staging happen once -- here, under "Converting abundances", where the
+    // reference does the same work (abundanceToFlatNodes + normalizeFlatNodes, unifrac.go:101-116); later passes
+    // re-target the plan
+    std::vector<std::unique_ptr<ff::ShardRunner>> runners;
+    rc = 0;
+    {
+        std::vector<int> rcs((size_t)G, 0);
+        std::vector<std::string> errs((size_t)G);
+        for (int64_t g = 0; g < G; ++g) {
+            ff_options o = opt;
+            o.device = (int32_t)(g % ndev);
+            runners.emplace_back(new ff::ShardRunner(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
+                                                     f.nnorm ? (f.lcompat ? FF_L_REFERENCE : 1) : 0, o));
+        }
+        auto prep = [&](int64_t g) {
+            char e[1024] = {0};
+            rcs[(size_t)g] = P > 0 ? runners[(size_t)g]->prepare((int32_t)g, (int32_t)world, e, sizeof e) : 0;
+            errs[(size_t)g] = e;
+        };
+        if (G == 1) {
+            prep(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int64_t g = 0; g < G; ++g) th.emplace_back(prep, g);
+            for (auto &t : th) t.join();
+        }
+        for (int64_t g = 0; g < G && rc == 0; ++g)
+            if (rcs[(size_t)g]) {
+                rc = rcs[(size_t)g];
+                snprintf(err, sizeof err, "%s", errs[(size_t)g].c_str());
+            }
+    }
+    ring.join();
+    if (rc == 0 && ring_rc != 0) {
+        rc = ring_rc;
+        snprintf(err, sizeof err, "%s", ring_err);
+    }
+    if (rc) {
+        runners.clear();
         ff_tree_free(tree);
         return die(err);
     }
-    ff_plan_info info{};
-    // one runner per device slot: stage A and the staging happen once, later passes re-target the plan
-    std::vector<std::unique_ptr<ff::ShardRunner>> runners;
-    for (int64_t g = 0; g < G; ++g) {
-        ff_options o = opt;
-        o.device = (int32_t)(g % ndev);
-        runners.emplace_back(new ff::ShardRunner(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
-                                                 f.nnorm ? (f.lcompat ? FF_L_REFERENCE : 1) : 0, o));
-    }
-    std::vector<std::vector<double>> sets[2] = {std::vector<std::vector<double>>((size_t)G),
-                                                std::vector<std::vector<double>>((size_t)G)};
-    double t_dist = 0, t_write = 0;  // time the main thread computed / waited for the writer
-    std::thread wr;
-    int wr_rc = 0;
-    char wr_err[1024] = {0};
-    rc = 0;
+    lap(4);
+
+    fputs("Calculating distances\n", stderr);  // unifrac.go:122
     for (int64_t pass = 0; pass < passes && rc == 0; ++pass) {
-        auto p0 = std::chrono::steady_clock::now();
-        std::vector<std::vector<double>> &bufs = sets[pass & 1];
         std::vector<int> rcs((size_t)G, 0);
         std::vector<std::string> errs((size_t)G);
         std::vector<ff_plan_info> infos((size_t)G);
+        std::vector<const double *> d_out((size_t)G, nullptr);
+        std::vector<int64_t> n_out((size_t)G, 0);
         auto one = [&](int64_t g) {
-            ff_options o = opt;
-            o.device = (int32_t)(g % ndev);
-            o.rank = (int32_t)(pass * G + g);
-            o.world = (int32_t)world;
             char e[1024] = {0};
-            int64_t rb = 0, re = 0;
-            int r = ff_shard_rows(n, o.rank, o.world, &rb, &re);
-            if (r == 0) {
-                const int64_t a = rb * (rb - 1) / 2, b = re * (re - 1) / 2;  // IterPairs slots of rows [rb, re)
-                try {
-                    bufs[(size_t)g].resize((size_t)std::max<int64_t>(b - a, 0));
-                } catch (const std::bad_alloc &) {
-                    r = ff::fail(FF_ERR_INTERNAL, e, sizeof e, "out of host memory for %lld distances", (long long)(b - a));
-                }
-                if (r == 0) r = runners[(size_t)g]->run(o.rank, o.world, bufs[(size_t)g].data(), &infos[(size_t)g], e, sizeof e);
-            } else {
-                snprintf(e, sizeof e, "bad shard %d of %d", o.rank, o.world);
-            }
-            rcs[(size_t)g] = r;
+            rcs[(size_t)g] = runners[(size_t)g]->run_device((int32_t)(pass * G + g), (int32_t)world, &d_out[(size_t)g], &n_out[(size_t)g],
+                                                            &infos[(size_t)g], e, sizeof e);
             errs[(size_t)g] = e;
         };
         if (G == 1) {
@@ -341,36 +371,21 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
                 info.audit_min_headroom = std::min(info.audit_min_headroom, infos[(size_t)g].audit_min_headroom);
             }
         }
-        auto p1 = std::chrono::steady_clock::now();
-        t_dist += std::chrono::duration<double>(p1 - p0).count();
-        if (wr.joinable()) wr.join();  // the previous pass is on its way out: its buffers are the next ones
-        if (rc == 0 && wr_rc != 0) {
-            rc = wr_rc;
-            snprintf(err, sizeof err, "%s", wr_err);
-        }
-        if (rc == 0)
-            wr = std::thread([&writer, &bufs, &wr_rc, &wr_err, G] {
-                for (int64_t g = 0; g < G && wr_rc == 0; ++g)
-                    wr_rc = writer.write(bufs[(size_t)g].data(), (int64_t)bufs[(size_t)g].size(), wr_err, sizeof wr_err);
-            });
-        t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - p1).count();
+        // in IterPairs order: shard g of the pass behind shard g - 1
+        for (int64_t g = 0; g < G && rc == 0; ++g)
+            rc = pipe.submit(runners[(size_t)g]->device(), d_out[(size_t)g], n_out[(size_t)g], err, sizeof err);
     }
-    {
-        auto p1 = std::chrono::steady_clock::now();
-        if (wr.joinable()) wr.join();
-        t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - p1).count();
-    }
-    if (rc == 0 && wr_rc != 0) {
-        rc = wr_rc;
-        snprintf(err, sizeof err, "%s", wr_err);
-    }
+    lap(5);
+    if (rc == 0) rc = pipe.drain(err, sizeof err);
+    lap(6);
+    const double det[5] = {runners[0]->t_create, runners[0]->t_retarget, runners[0]->t_kernels, runners[0]->t_copy, pipe.t_submit};
+    const long long text_bytes = (long long)pipe.bytes;
+    const double pipe_copy = pipe.t_copy, pipe_write = pipe.t_write;
     runners.clear();
     ff_tree_free(tree);
     if (rc == 0) rc = writer.close(err, sizeof err);
     if (rc) return die(err);
-    phase[4] = t_dist;
-    phase[5] = t_write;
-    last = std::chrono::steady_clock::now();
+    lap(7);
     // Unweighted in fixed point is the reference bit for bit only when every branch length is a
     // multiple of 2^-scale; say so when it was not (the values are then within 1e-6, like weighted)
     if (!f.weighted && info.precision == FF_PRECISION_FIXED32 && !info.lengths_exact)
@@ -378,19 +393,23 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
               "within 1e-6 (relative) of the reference's, not bit-identical; -precision exact64 gives the reference's bits\n",
               stderr);
     if (f.stats)
+        // seconds: the reference's own phases (its stderr lines); convert holds stage A and the staging on the device, as
+        // the reference's "Converting abundances" holds abundanceToFlatNodes; write is what was left of the output once
+        // the last pass was reduced (the rest went out under the passes).  detail: where the device side spent its time.
         fprintf(stderr,
                 "{\"precision\": \"%s\", \"scale_log2\": %d, \"lengths_exact\": %d, \"bit_exact\": %s, \"tiles\": %lld, "
-                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"audit\": {\"checked\": %lld, "
+                "\"items\": %lld, \"wave_slots\": %lld, \"staged_bytes\": %.0f, \"passes\": %lld, \"threads\": %d, \"audit\": {\"checked\": %lld, "
                 "\"failed\": %lld, \"worst_rel_err\": %.3g, \"min_headroom\": %s}, \"seconds\": {\"tree\": %.3f, "
-                "\"load\": %.3f, \"validate\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f}}\n",
+                "\"load\": %.3f, \"validate\": %.3f, \"open\": %.3f, \"convert\": %.3f, \"distances\": %.3f, \"write\": %.3f, \"close\": %.3f}, "
+                "\"detail\": {\"plan\": %.3f, \"retarget\": %.3f, \"kernels\": %.3f, \"format\": %.3f, \"text_copy\": %.3f, \"text_write\": %.3f, \"text_bytes\": %lld}}\n",
                 info.precision == FF_PRECISION_FIXED32 ? "fixed32" : "exact64", info.scale_log2,
                 info.lengths_exact,
                 info.precision == FF_PRECISION_EXACT64 || (!f.weighted && info.lengths_exact) ? "true" : "false",
                 (long long)info.n_tiles, (long long)info.n_items,
-                (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, (long long)info.audit_checked,
+                (long long)info.n_wave_slots, info.staged_bytes, (long long)passes, nt, (long long)info.audit_checked,
                 (long long)info.audit_failed, info.audit_worst_rel_err,
                 std::isfinite(info.audit_min_headroom) ? std::to_string(info.audit_min_headroom).c_str() : "null", phase[0],
-                phase[1], phase[2], phase[3], phase[4], phase[5]);
+                phase[1], phase[2], phase[3], phase[4], phase[5], phase[6], phase[7], det[0], det[1], det[2], det[4], pipe_copy, pipe_write, text_bytes);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Took %s\n", go_duration(sec).c_str());
     fputs("Done\n", stderr);

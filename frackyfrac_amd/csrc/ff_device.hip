@@ -2,6 +2,8 @@
 // plans (create / set shard / run / destroy), unifracDists as one call and as a lazy ordered sequence, device buffers
 // shared between the processes of one node, and the C++ helpers of the frcfrc command.  One of the three translation
 // units of the device path (ff_plan.hpp); no kernel is launched from here.
+#include <chrono>
+
 #include "ff_plan.hpp"
 
 #include <functional>
@@ -737,15 +739,38 @@ int ff::ShardRunner::create(int32_t rank, int32_t world, int precision, char *er
     return ff_plan_create_from_leaves(tree_, n_, lp_, li_, lv_, unnorm_, &o, &pl_, err, errlen);
 }
 
-int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info *info, char *err, size_t errlen)
+int ff::ShardRunner::device() const { return pl_ ? pl_->device : opt_.device; }
+
+int ff::ShardRunner::prepare(int32_t rank, int32_t world, char *err, size_t errlen)
 {
-    int rc = pl_ ? ff_plan_set_shard(pl_, rank, world, err, errlen) : create(rank, world, opt_.precision, err, errlen);
+    if (pl_) return FF_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = create(rank, world, opt_.precision, err, errlen);
+    t_create += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int ff::ShardRunner::run_device(int32_t rank, int32_t world, const double **d_out, int64_t *n, ff_plan_info *info, char *err,
+                                size_t errlen)
+{
+    using clk = std::chrono::steady_clock;
+    auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+    *d_out = nullptr;
+    *n = 0;
+    auto t0 = clk::now();
+    int rc = FF_OK;
+    if (!pl_) {
+        rc = create(rank, world, opt_.precision, err, errlen);
+        t_create += since(t0);
+    } else if (pl_->shard_rank != rank || pl_->shard_world != world) {
+        rc = ff_plan_set_shard(pl_, rank, world, err, errlen);
+        t_retarget += since(t0);
+    }
     if (rc) return rc;
     // (a pass runs on a thread of its own: the buffers below belong on the plan's device)
     if (hipSetDevice(pl_->device) != hipSuccess) return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot select device %d", pl_->device);
     const int64_t n_slots = pl_->info.slot_end - pl_->info.slot_begin;
     if (n_slots > 0) {
-        if (!out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
         if (n_slots > d_out_cap_) {
             (void)hipFree(d_out_);
             d_out_ = nullptr;
@@ -758,6 +783,7 @@ int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info 
             }
             d_out_cap_ = n_slots;
         }
+        t0 = clk::now();
         rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);
         bool ok = true;
         if (rc == FF_OK && plan_fixed32_verdict(pl_, &ok, nullptr) == FF_OK && !ok) {
@@ -767,15 +793,33 @@ int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info 
             if (rc == FF_OK) rc = ff_plan_run(pl_, nullptr, d_out_, err, errlen);
         }
         if (rc) return rc;
-        hipError_t he = hipMemcpy(out, d_out_, sizeof(double) * (size_t)n_slots, hipMemcpyDeviceToHost);
-        if (he != hipSuccess) {
-            (void)hipGetLastError();
-            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
-        }
+        if (hipStreamSynchronize(nullptr) != hipSuccess) (void)hipGetLastError();  // (an error surfaces in the caller's next call)
+        t_kernels += since(t0);
     }
     if (info) {
         *info = pl_->info;
         fill_audit_info(pl_, info);
+    }
+    *d_out = d_out_;
+    *n = std::max<int64_t>(n_slots, 0);
+    return FF_OK;
+}
+
+int ff::ShardRunner::run(int32_t rank, int32_t world, double *out, ff_plan_info *info, char *err, size_t errlen)
+{
+    const double *d = nullptr;
+    int64_t n = 0;
+    const int rc = run_device(rank, world, &d, &n, info, err, errlen);
+    if (rc) return rc;
+    if (n > 0) {
+        if (!out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t he = hipMemcpy(out, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+        t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (he != hipSuccess) {
+            (void)hipGetLastError();
+            return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: copy of results failed: %s", hipGetErrorString(he));
+        }
     }
     return FF_OK;
 }

@@ -34,6 +34,9 @@ bool go_parse_float(const char *b, const char *e, double *out, const char **why)
 int read_all(const char *path, std::string *out, char *err, size_t errlen);
 
 unsigned clamp_threads(int requested);
+// CPUs this process may use: the smallest of the hardware's count, the scheduler affinity mask and the cgroup's
+// CPU quota (cpu.max / cfs_quota_us, rounded up) -- what a container is really given, not what the machine has.
+unsigned cpu_quota();
 
 // A tuning switch (the FF_* names of INTEGRATION.md): the value given through ff_tune, else the
 // environment variable of that name, else nothing.  A copy: a concurrent ff_tune cannot invalidate it.
@@ -69,6 +72,15 @@ public:
     ShardRunner &operator=(const ShardRunner &) = delete;
     // distances of shard `rank` of `world` into out[0 .. slot_end - slot_begin) (host memory)
     int run(int32_t rank, int32_t world, double *out, ff_plan_info *info, char *err, size_t errlen);
+    // the same, the distances left on the device: *d_out (valid until the next call) holds *n of them
+    int run_device(int32_t rank, int32_t world, const double **d_out, int64_t *n, ff_plan_info *info, char *err, size_t errlen);
+    // builds the plan for the first shard ahead of its run (stage A, staging): what the reference's "Converting
+    // abundances" phase is (unifrac.go:101-116); the first run()/run_device() of that shard then only launches
+    int prepare(int32_t rank, int32_t world, char *err, size_t errlen);
+    int device() const;
+    // seconds the calls of run() spent: building the plan (stage A, staging), re-targeting it, in the kernels
+    // (launch to the verdict's counters), copying the results out
+    double t_create = 0, t_retarget = 0, t_kernels = 0, t_copy = 0;
 
 private:
     int create(int32_t rank, int32_t world, int precision, char *err, size_t errlen);
@@ -96,6 +108,8 @@ public:
     ~DistWriter();
     int open(const char *path /* null: stdout */, int threads, char *err, size_t errlen);
     int write(const double *d, int64_t n, char *err, size_t errlen);
+    // n bytes of finished text (whole lines: TextPipeline, formatted on the device)
+    int write_text(const char *text, size_t n, char *err, size_t errlen);
     int close(char *err, size_t errlen);
 
 private:
@@ -106,6 +120,33 @@ private:
     std::string name_;
     std::vector<std::string> bufs_, zbufs_;
 };
+
+// The output path of frcfrc with the formatter on the device (ff_kernels_fmt.hpp): the distances of a pass are
+// turned into text in HBM, the text is copied out through a ring of pinned host slots on a stream of its own and
+// appended to the file, all of it behind the main thread's back -- pass k + 1 is reduced while pass k is on its
+// way out.  One copier thread (device -> slot) and one writer thread (slot -> file, DistWriter::write_text).
+class TextPipeline {
+public:
+    explicit TextPipeline(DistWriter *writer);
+    ~TextPipeline();
+    TextPipeline(const TextPipeline &) = delete;
+    TextPipeline &operator=(const TextPipeline &) = delete;
+    // Allocates the ring for an output of about expected_bytes (any thread; optional: submit does it otherwise).
+    int prepare(int64_t expected_bytes, char *err, size_t errlen);
+    // d_vals[0 .. n) on `device`: formats them there (legacy stream: ordered behind the pass that produced them) and
+    // queues the text for the file.  Returns when the format kernels are done -- d_vals may be overwritten then.
+    int submit(int device, const double *d_vals, int64_t n, char *err, size_t errlen);
+    // Waits until everything submitted is in the file; the first error of the background threads.
+    int drain(char *err, size_t errlen);
+    double t_submit = 0;  // seconds the callers of submit() spent in it
+    int64_t bytes = 0;    // text bytes produced so far
+    double t_copy = 0, t_write = 0;  // after drain(): seconds the copier spent in device-to-host copies, the writer in the file
+
+private:
+    struct Impl;
+    Impl *impl_;
+};
+
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
 void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
                     std::vector<int64_t> *idx, std::vector<double> *val, int threads = 1);

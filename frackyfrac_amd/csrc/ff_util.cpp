@@ -1,10 +1,12 @@
 // ff_util.cpp -- error plumbing, Go-compatible number formatting/parsing, threads.
+#include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <functional>
 #include <thread>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <dlfcn.h>
@@ -13,6 +15,7 @@
 #include <mutex>
 #include <unordered_map>
 
+#include "ff_fmt_core.hpp"
 #include "ff_host.hpp"
 
 namespace ff {
@@ -371,6 +374,43 @@ unsigned clamp_threads(int requested)
     return (unsigned)requested;
 }
 
+// The CPUs this process may really use.  A container on a large host sees every core of the machine in
+// hardware_concurrency() while its cgroup grants a fraction of them (the GPU boxes of this project: 256 visible, 16
+// granted): threads beyond the grant only take turns.
+unsigned cpu_quota()
+{
+    static const unsigned q = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+            const int c = CPU_COUNT(&set);
+            if (c > 0) n = std::min(n, (unsigned)c);
+        }
+        auto read_file = [](const char *path, char *buf, size_t len) {
+            FILE *f = fopen(path, "r");
+            if (!f) return false;
+            const size_t r = fread(buf, 1, len - 1, f);
+            fclose(f);
+            buf[r] = 0;
+            return r > 0;
+        };
+        char b[128];
+        double quota = 0;
+        if (read_file("/sys/fs/cgroup/cpu.max", b, sizeof b)) {  // cgroup v2: "<quota|max> <period>"
+            long long qv = 0, pv = 0;
+            if (sscanf(b, "%lld %lld", &qv, &pv) == 2 && qv > 0 && pv > 0) quota = (double)qv / (double)pv;
+        } else if (read_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", b, sizeof b)) {  // v1
+            const long long qv = atoll(b);
+            if (qv > 0 && read_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us", b, sizeof b) && atoll(b) > 0)
+                quota = (double)qv / (double)atoll(b);
+        }
+        if (quota > 0) n = std::min(n, (unsigned)std::max(1.0, std::ceil(quota)));
+        return std::min(n, 256u);
+    }();
+    return q;
+}
+
 void parallel_for(int64_t n, unsigned threads,
                   const std::function<void(unsigned, int64_t, int64_t)> &fn)
 {
@@ -513,6 +553,50 @@ int DistWriter::write(const double *d, int64_t n, char *err, size_t errlen)
     return FF_OK;
 }
 
+// Finished text (whole lines, formatted on the device): the parts of a call go to a regular file in parallel at
+// their byte offsets; compressed output makes every part a gzip member / zstd frame of its own, as write() does.
+int DistWriter::write_text(const char *text, size_t n, char *err, size_t errlen)
+{
+    if (n == 0) return FF_OK;
+    auto io_fail = [&] { return fail(FF_ERR_IO, err, errlen, "write %s: %s", name_.c_str(), strerror(errno)); };
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt_, n >> 20));  // a part is a megabyte or more
+    if (gz_) {
+        std::vector<int> ok(nt, 1);
+        for (auto &s : zbufs_) s.clear();
+        std::vector<std::string> parts(nt);
+        parallel_for((int64_t)n, nt, [&](unsigned t, int64_t b, int64_t e) {
+            parts[t].assign(text + b, text + e);
+            ok[t] = (zst_ ? zstd_frame(parts[t], &zbufs_[t]) : gzip_member(parts[t], &zbufs_[t])) ? 1 : 0;
+        });
+        for (unsigned t = 0; t < nt; ++t) {
+            if (!ok[t]) return fail(FF_ERR_IO, err, errlen, "write %s: %s error", name_.c_str(), zst_ ? "zstd" : "gzip");
+            if (zbufs_[t].empty()) continue;
+            if (!write_fully(fd_, zbufs_[t].data(), zbufs_[t].size(), seekable_ ? off_ : -1)) return io_fail();
+            off_ += (int64_t)zbufs_[t].size();
+        }
+        return FF_OK;
+    }
+    if (seekable_ && nt > 1) {
+        std::vector<int> ok(nt, 1);
+        int first_errno = 0;
+        parallel_for((int64_t)n, nt, [&](unsigned t, int64_t b, int64_t e) {
+            if (!write_fully(fd_, text + b, (size_t)(e - b), off_ + b)) {
+                ok[t] = 0;
+                first_errno = errno;
+            }
+        });
+        for (unsigned t = 0; t < nt; ++t)
+            if (!ok[t]) {
+                errno = first_errno;
+                return io_fail();
+            }
+    } else if (!write_fully(fd_, text, n, seekable_ ? off_ : -1)) {
+        return io_fail();
+    }
+    off_ += (int64_t)n;
+    return FF_OK;
+}
+
 int DistWriter::close(char *err, size_t errlen)
 {
     int rc = FF_OK;
@@ -539,6 +623,8 @@ void ff_options_default(ff_options *o)
     o->world = 1;
 }
 
+int ff_cpu_quota(void) { return (int)ff::cpu_quota(); }
+
 int64_t ff_num_pairs(int64_t n) { return n < 2 ? 0 : n * (n - 1) / 2; }
 
 // Equal-pairs contiguous row shards: rows [0, r) hold r(r-1)/2 pairs, so shard
@@ -561,78 +647,13 @@ int ff_shard_rows(int64_t n, int32_t rank, int32_t world, int64_t *rb, int64_t *
     return FF_OK;
 }
 
-// fmt.Fprintln(w, f) without the newline: strconv.FormatFloat(f, 'g', -1, 64).
+// fmt.Fprintln(w, f) without the newline: strconv.FormatFloat(f, 'g', -1, 64).  The digits and the layout are
+// ff_fmt_core.hpp's -- the code the device formatter runs (ff_kernels_fmt.hpp), so host and device print the same text.
 int ff_format_float(double f, char *buf)
 {
-    if (std::isnan(f)) {
-        memcpy(buf, "NaN", 3);
-        return 3;
-    }
-    if (std::isinf(f)) {
-        memcpy(buf, f > 0 ? "+Inf" : "-Inf", 4);
-        return 4;
-    }
-    char *o = buf;
-    if (std::signbit(f)) {
-        *o++ = '-';
-        f = -f;
-    }
-    if (f == 0) {
-        *o++ = '0';
-        return (int)(o - buf);
-    }
-    // shortest round-trip digits: d[.ddd]e[+-]XX
-    char s[40];
-    auto r = std::to_chars(s, s + sizeof s - 1, f, std::chars_format::scientific);
-    *r.ptr = 0;
-    const char *epos = s;
-    while (epos < r.ptr && *epos != 'e') ++epos;
-    char digs[24];
-    int nd = 0;
-    for (const char *p = s; p < epos; ++p)
-        if (*p != '.') digs[nd++] = *p;
-    int x = atoi(epos + 1);  // decimal exponent of the first digit
-    while (nd > 1 && digs[nd - 1] == '0') --nd;
-    if (x < -4 || x >= 6) {  // %e: strconv's shortest-%g rule (eprec = 6)
-        *o++ = digs[0];
-        if (nd > 1) {
-            *o++ = '.';
-            memcpy(o, digs + 1, (size_t)nd - 1);
-            o += nd - 1;
-        }
-        *o++ = 'e';
-        *o++ = x < 0 ? '-' : '+';
-        int ax = x < 0 ? -x : x;
-        if (ax < 10) {
-            *o++ = '0';
-            *o++ = (char)('0' + ax);
-        } else {
-            char t[8];
-            int n = snprintf(t, sizeof t, "%d", ax);
-            memcpy(o, t, (size_t)n);
-            o += n;
-        }
-        return (int)(o - buf);
-    }
-    int dp = x + 1;  // digits before the decimal point
-    if (dp <= 0) {
-        *o++ = '0';
-        *o++ = '.';
-        for (int i = 0; i < -dp; ++i) *o++ = '0';
-        memcpy(o, digs, (size_t)nd);
-        o += nd;
-    } else if (dp >= nd) {
-        memcpy(o, digs, (size_t)nd);
-        o += nd;
-        for (int i = nd; i < dp; ++i) *o++ = '0';
-    } else {
-        memcpy(o, digs, (size_t)dp);
-        o += dp;
-        *o++ = '.';
-        memcpy(o, digs + dp, (size_t)(nd - dp));
-        o += nd - dp;
-    }
-    return (int)(o - buf);
+    uint64_t bits;
+    memcpy(&bits, &f, sizeof bits);
+    return ff::fmt::format_bits(bits, buf);
 }
 
 // frcfrc.go:58-62: one fmt.Fprintln(fout, f) per value.  Rounds of `threads` parts: every

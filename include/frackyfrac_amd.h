@@ -437,6 +437,20 @@ int ff_format_float(double f, char *buf);
 int ff_write_distances(const char *path, const double *d, int64_t n, int threads,
                        char *err, size_t errlen);
 
+/* CPUs this process may use: the smallest of the machine's count, the scheduler affinity mask and the cgroup CPU
+ * quota (rounded up).  What the frcfrc command gives its loaders and its writer when -p is not given. */
+int ff_cpu_quota(void);
+
+/* The same formatter ON THE DEVICE (the loop of frcfrc/frcfrc.go:58-62 for distances that are still in HBM): the
+ * n values at d_values (device memory) become the lines the reference prints, in order, at d_text (device memory,
+ * at least ff_text_bound(n) bytes = 25 per value); *n_bytes = the length of the text.  Same digits and layout as
+ * ff_format_float, byte for byte (one implementation, csrc/ff_fmt_core.hpp).  The launches go to `stream` (NULL: the
+ * legacy stream); the call returns once the text is complete.  The frcfrc command uses this path: a pass's distances
+ * never reach the host as numbers. */
+size_t ff_text_bound(int64_t n);
+int ff_format_distances_device(const double *d_values, int64_t n, char *d_text, size_t *n_bytes, void *stream,
+                               char *err, size_t errlen);
+
 /* Whole `frcfrc` command (frcfrc/frcfrc.go:29-67): argv as the reference's flags
  * -i -o -t -w -s -p -l.  Returns the process exit code (0, or 2 after printing
  * "ERROR: ..." to stderr). */

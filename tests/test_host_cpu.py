@@ -15,6 +15,8 @@ from frackyfrac_amd import _lib as L
 from frackyfrac_amd import synth
 from oracle import oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def oracle_tree_arrays(text):
     ft = O.flatten_tree(O.parse_newick(text))
@@ -281,6 +283,36 @@ def test_format_float_matches_oracle():
     vals += [float(np.float32(x)) for x in rng.random(200)]
     for v in vals:
         assert ff.format_float(v) == O.format_go_float(v), repr(v)
+
+
+def test_format_float_matches_oracle_on_random_bit_patterns():
+    """ff_format_float is ff_fmt_core.hpp -- the code the device formatter runs."""
+    rng = np.random.default_rng(15)
+    for v in rng.integers(0, 2 ** 64, size=20000, dtype=np.uint64).view(np.float64):
+        assert ff.format_float(float(v)) == O.format_go_float(float(v)), float(v).hex()
+
+
+def test_formatter_core_against_to_chars():
+    """csrc/fmt_selftest.cpp: the formatter core against std::to_chars' shortest digits under Go's layout rule --
+    every power of two and its neighbours, short decimals, integers, quotients, 3 M random bit patterns (1.5e9 were
+    run once: DESIGN.md)."""
+    import subprocess
+    exe = os.path.join(ROOT, "frackyfrac_amd", "lib", "fmt_selftest")
+    r = subprocess.run([exe, "3000000", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fmt selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cpu_quota_is_what_the_cgroup_grants():
+    """The frcfrc command's default thread count: never more than the affinity mask or the cgroup's quota."""
+    import ctypes
+    n = L.lib().ff_cpu_quota()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            assert n <= -(-int(q) // int(p))
+    except OSError:
+        pass
 
 
 def test_write_distances(tmp_path):

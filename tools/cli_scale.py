@@ -14,12 +14,21 @@ open(d + "/t.tree", "w").write(tree.newick())
 text = synth.dense_text(tree, ptr, idx, val) if dense else synth.sparse_text(tree, ptr, idx, val)
 open(d + "/t.tab", "w").write(text)
 print("generated %d samples, table %.1f MB in %.1fs" % (ns, len(text) / 1e6, time.time() - t0), flush=True)
-for p in (1, 16):
+sums = set()
+for p in (None, 1, 16, None):
+    out = d + "/out_%s.txt" % p
+    if os.path.exists(out):
+        os.unlink(out)
     t0 = time.time()
-    args = [L.FRCFRC_PATH, "-w", "-t", d + "/t.tree", "-i", d + "/t.tab", "-o", d + "/out.txt", "-p", str(p), "-stats"]
+    args = [L.FRCFRC_PATH, "-w", "-t", d + "/t.tree", "-i", d + "/t.tab", "-o", out, "-stats"]
+    if p:
+        args += ["-p", str(p)]
     if not dense:
         args.insert(1, "-s")
     r = subprocess.run(args, capture_output=True, text=True)
     dt = time.time() - t0
-    print("-p %d: rc=%d wall %.2fs; output %.1f MB" % (p, r.returncode, dt, os.path.getsize(d + "/out.txt") / 1e6))
-    print("   " + r.stderr.strip().replace("\n", " | ")[-400:])
+    print("-p %s: rc=%d wall %.2fs; output %.1f MB" % (p, r.returncode, dt, os.path.getsize(out) / 1e6))
+    print("   " + r.stderr.strip().replace("\n", " | ")[-700:], flush=True)
+    sums.add(subprocess.run(["md5sum", out], capture_output=True, text=True).stdout.split()[0])
+    os.unlink(out)
+print("outputs identical:", len(sums) == 1)
