@@ -115,6 +115,73 @@ def cpu_baseline(nodes, weighted, budget_s=18.0):
                                         % (c1, P, r1[0], r1[1], r1[2])}}
 
 
+# ---- end to end: the command a user runs ---------------------------------------------------
+
+def frcfrc_end_to_end(workload, cores):
+    """The `frcfrc` executable on the workload as FILES: synthetic table as sparse text + Newick in, one distance per
+    line out (frcfrc/frcfrc.go:29-67), timed from outside (wall) and by the command's own phase table (-stats), with
+    the reference's default flags (no -p), with -p 1 and with -p <cores>.  SURVEY 8(d): "report end-to-end and host
+    prep separately" -- this is the whole of it, never `value`."""
+    import hashlib
+    import shutil
+    import tempfile
+
+    from frackyfrac_amd import _lib as L
+    from frackyfrac_amd import synth
+
+    cfg = synth.CONFIGS[workload]
+    t0 = time.perf_counter()
+    tree, ptr, idx, val = synth.make(cfg["n_samples"], cfg["n_leaves"], cfg["density"], cfg["seed"])
+    d = tempfile.mkdtemp(prefix="ff_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        with open(os.path.join(d, "t.tree"), "w") as f:
+            f.write(tree.newick())
+        text = synth.sparse_text(tree, ptr, idx, val)
+        with open(os.path.join(d, "t.tab"), "w") as f:
+            f.write(text)
+        entry = {"workload": workload, "samples": cfg["n_samples"], "leaves": cfg["n_leaves"],
+                 "pairs": cfg["n_samples"] * (cfg["n_samples"] - 1) // 2,
+                 "input": "sparse text, %.1f MB (+ Newick), generated in %.1f s" % (len(text) / 1e6, time.perf_counter() - t0),
+                 "runs": []}
+        del text
+        digests = set()
+        for flags in ([], ["-p", "1"], ["-p", str(cores)]):
+            out = os.path.join(d, "out.txt")
+            if os.path.exists(out):
+                os.unlink(out)  # (truncating the previous run's gigabytes is not part of a run)
+            cmd = [L.FRCFRC_PATH, "-s", "-w" if cfg["weighted"] else "-w=false", "-t", os.path.join(d, "t.tree"),
+                   "-i", os.path.join(d, "t.tab"), "-o", out, "-stats"] + flags
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.perf_counter() - t0
+            run = {"flags": " ".join(flags) or "(default)", "rc": r.returncode, "wall_s": wall}
+            stats = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and stats:
+                st = json.loads(stats[-1])
+                run.update({"threads": st.get("threads"), "passes": st.get("passes"), "seconds": st["seconds"],
+                            "detail": st.get("detail"), "precision": st.get("precision")})
+                k = (st.get("detail") or {}).get("kernels")
+                if k:
+                    run["distances_over_kernels"] = st["seconds"]["distances"] / k
+                h = hashlib.md5()
+                n_lines = 0
+                with open(out, "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        h.update(blk)
+                        n_lines += blk.count(b"\n")
+                digests.add(h.hexdigest())
+                run["output_MB"] = os.path.getsize(out) / 1e6
+                run["lines"] = n_lines
+            else:
+                run["stderr"] = r.stderr[-400:]
+            entry["runs"].append(run)
+        entry["outputs_identical"] = len(digests) == 1
+        entry["lines_ok"] = all(r.get("lines") == entry["pairs"] for r in entry["runs"])
+        return entry
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ---- self-launch ------------------------------------------------------------------------
 
 def launch_command(n_gpus, argv, port):
@@ -451,7 +518,13 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                               "risk_pairs_found": found, "risk_pairs_checked": chk,
                               "min_headroom": None if math.isinf(headroom) else headroom}
         if ctx.world > 1:
+            # which transport this line did NOT exercise across GPUs (neither has ever crossed an xGMI link before the
+            # first real N > 1 run; a rehearsal on one GPU runs the send / receive fallback over gloo, never over RCCL,
+            # which refuses two ranks on one device)
+            untested = ("nccl (send/recv fallback): RCCL refuses two ranks on one device, the rehearsal ran it over gloo at most"
+                        if ctx.rehearse else ("nccl (send/recv fallback)" if run.transport == "ipc" else "ipc (copy engines into the root's mapped array)"))
             entry["gather"] = {"transport": run.transport, "fallback_reason": run.transport_note or None,
+                               "untested_transport": untested,
                                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                "chunks": run.chunks, "ipc_probe_GBps_rank1": per_rank[1]["ipc_probe_GBps"],
                                "exposed_ms_last_step_max": max(r["exposed_gather_ms_last_step"] for r in per_rank)}
@@ -482,7 +555,10 @@ def main():
                          "rocprofv3 --pmc measure it on this box once the timings are done)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--cpu-budget", type=float, default=18.0)
-    ap.add_argument("--end-to-end", action="store_true", help="also time ff_unifrac_dists through host buffers")
+    ap.add_argument("--end-to-end", action="store_true", help="(kept for old command lines: end to end is in the default line)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip `end_to_end` (default at N = 1 on the default workload: ff_unifrac_dists through host buffers, "
+                         "and the frcfrc executable on C3 and C4 as files)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks that all use GPU 0 with gloo as control plane (RCCL refuses two ranks on "
                          "one device): exercises the sharded code path on a one-GPU box; not a measurement")
@@ -541,7 +617,22 @@ def main():
     primary = measure(ctx, cfg, nodes, weighted, args.precision, args.steps, args.warmup,
                       event_every=1 if weighted or args.precision == "exact64" else 8)
     weak_entry = None
+    strong_base = None
     if lead_c4:
+        # the honest base of the strong curve: the SAME problem (C4) on ONE GPU of this node, this build, this run --
+        # rank 0 alone reduces the whole triangle while the others wait at the barrier below (C3's pairs cost 1.6 %
+        # more each than C4's on one GPU, so value(N) / (N * value(1)) with the N = 1 line's C3 would flatter the curve)
+        if rank == 0:
+            solo = Ctx()
+            solo.torch, solo.dist, solo.world, solo.rank, solo.local_rank, solo.rehearse = torch, dist, 1, 0, ctx.local_rank, ctx.rehearse
+            k1 = max(1, min(args.secondary_steps, args.steps))
+            e1 = measure(solo, cfg, nodes, True, "fixed32", k1, 1)
+            strong_base = {"workload": e1["config"]["workload"], "n_gpus": 1, "value": e1["value"], "unit": "pairs/s",
+                           "ms_per_step": e1["ms_per_step"], "steps": k1, "kernel": e1["roofline"]["kernel"],
+                           "frac": e1["roofline"]["frac"],
+                           "note": "the line's own problem on one GPU of this node (rank 0, the other ranks idle): "
+                                   "efficiency of the strong curve = value / (n_gpus * strong_base.value)"}
+        barrier(ctx)
         del nodes
         n_weak = int(round(synth.CONFIGS["C3"]["n_samples"] * math.sqrt(world) / 32.0)) * 32
         cfg_w, nodes = make_problem(ctx, "C3", n_weak)
@@ -550,7 +641,8 @@ def main():
             weak_entry["scaling"] = "weak"
 
     e2e = None
-    if rank == 0 and world == 1 and args.end_to_end:
+    want_e2e = rank == 0 and world == 1 and not args.no_end_to_end and not ctx.rehearse
+    if want_e2e:
         # Host-buffer entry point (ff_unifrac_dists): upload of the flat nodes over PCIe,
         # staging, the pair kernels and the download of the distances.  Never `value`.
         P = ff.num_pairs(nodes.n_samples)
@@ -574,13 +666,19 @@ def main():
         for k in ("audit", "gather", "ranks"):
             if k in primary:
                 out[k] = primary[k]
+        if strong_base is not None:
+            out["strong_base"] = strong_base
         if weak_entry is not None:
             out["weak_scaling"] = weak_entry
             out["scaling_note"] = ("N > 1: value = BASELINE configs[3] (C4, 16,384 samples) over the N GPUs, total work fixed; the "
                                    "N = 1 point is BASELINE's headline C3 (4,096 samples, same tree: the same cost per pair); "
                                    "weak_scaling = C3 grown to 4096*sqrt(N) samples, per-GPU pairs fixed")
         if e2e is not None:
-            out["host_buffers_ms"] = e2e * 1e3  # PCIe-inclusive, informational
+            # PCIe-inclusive, informational -- never `value`
+            out["end_to_end"] = {"host_buffers_ms": e2e * 1e3,
+                                 "host_buffers_note": "ff_unifrac_dists on host arrays: H2D of the flat nodes (%d MB) + staging + "
+                                                      "kernels + D2H of the distances (%d MB), second call in this process"
+                                                      % ((len(nodes.branch_id) * 12) >> 20, (ff.num_pairs(nodes.n_samples) * 8) >> 20)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
 
@@ -620,6 +718,20 @@ def main():
             del n2
         if rank == 0:
             out["secondary"] = sec
+    if (want_e2e and args.workload == "C3" and not args.unweighted and args.precision == "fixed32" and
+            args.lengths == "generator" and not under_a_profiler()):
+        # the command a user runs, on files: C3 and BASELINE configs[3]'s size on this one GPU
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        e2e_runs = []
+        for wl in ("C3", "C4"):
+            try:
+                e2e_runs.append(frcfrc_end_to_end(wl, host_cores()))
+                for r in e2e_runs[-1]["runs"]:
+                    log("frcfrc %s %s: wall %.2f s, phases %s" % (wl, r["flags"], r["wall_s"], r.get("seconds")))
+            except Exception as e:  # (the line must come out)
+                e2e_runs.append({"workload": wl, "error": "%s: %s" % (type(e).__name__, e)})
+        out.setdefault("end_to_end", {})["frcfrc"] = e2e_runs
     if rank == 0 and world == 1 and not args.no_live_traffic and not ctx.rehearse:
         # last, with every timing of the line done: the primary kernel's traffic beyond L2 as this box's counters see it
         if under_a_profiler():

@@ -30,7 +30,7 @@ void usage()
     fputs("  -gpus int\n    \tNumber of GPUs to shard the pair space over (default 1)\n", stderr);
     fputs("  -i string\n    \tPath to input file (default stdin)\n", stderr);
     fputs("  -l\tLeave abundance values unnormalized (default normalize each sample to sum up to 1)\n", stderr);
-    fputs("  -l-compat\n    \tWith -l: the reference's own -l, whose lists stay unsorted (its values, bit for bit)\n", stderr);
+    fputs("  -l-sorted\n    \tWith -l: merge SORTED lists (what -l evidently means; the reference leaves them unsorted, and so does -l alone)\n", stderr);
     fputs("  -o string\n    \tPath to output file (default stdout)\n", stderr);
     fputs("  -p int\n    \tNumber of threads (default 1: here, the CPUs the process may use)\n", stderr);
     fputs("  -precision string\n    \tDevice arithmetic: auto, fixed32 or exact64 (default \"auto\")\n", stderr);
@@ -48,7 +48,7 @@ int die(const char *msg)
 
 struct Flags {
     std::string in, out, tree, precision = "auto";
-    bool weighted = false, sparse = false, nnorm = false, stats = false, lcompat = false;
+    bool weighted = false, sparse = false, nnorm = false, stats = false, lcompat = false, lsorted = false;
     long nt = 1, gpus = 1;
     bool nt_given = false;
 };
@@ -95,7 +95,7 @@ int parse_flags(int argc, char **argv, Flags *f)
             return 2;
         }
         bool *bp = name == "w" ? &f->weighted : name == "s" ? &f->sparse : name == "l" ? &f->nnorm
-                   : name == "stats" ? &f->stats : name == "l-compat" ? &f->lcompat : nullptr;
+                   : name == "stats" ? &f->stats : name == "l-compat" ? &f->lcompat : name == "l-sorted" ? &f->lsorted : nullptr;
         if (bp) {
             if (has_value) {
                 if (!parse_bool(value, bp)) {
@@ -180,9 +180,13 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     }
     if (f.nnorm && !f.weighted) return die("-l can only be used with weighted unifrac");  // :84-86
     // The reference's -l skips normalizeFlatNodes and with it the SORT of the lists (unifrac.go:57-59,108-110), so its
-    // merge walk mis-pairs branches.  -l alone gives the evidently intended values (sorted lists, raw
-    // abundances); -l -l-compat the reference's own, bit for bit (FF_L_REFERENCE: unsorted lists, the literal walk).
+    // merge walk mis-pairs branches.  A drop-in prints what the reference prints: -l gives the reference's own
+    // values, bit for bit (FF_L_REFERENCE: unsorted lists, the literal walk -- what the cgo shim does under -l too);
+    // -l -l-sorted the evidently intended ones (sorted lists, raw abundances; every kernel of the engine applies).
+    // (-l-compat, round 4's name for what is now the default, is still accepted.)
     if (f.lcompat && !f.nnorm) return die("-l-compat can only be used with -l");
+    if (f.lsorted && !f.nnorm) return die("-l-sorted can only be used with -l");
+    if (f.lsorted && f.lcompat) return die("-l-sorted and -l-compat exclude each other");
     if (f.gpus < 1 || f.gpus > 64) {
         char m[64];
         snprintf(m, sizeof m, "bad number of GPUs: %ld", f.gpus);
@@ -305,7 +309,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
             ff_options o = opt;
             o.device = (int32_t)(g % ndev);
             runners.emplace_back(new ff::ShardRunner(tree, n, leaf_ptr.data(), leaf_idx.data(), leaf_val.data(),
-                                                     f.nnorm ? (f.lcompat ? FF_L_REFERENCE : 1) : 0, o));
+                                                     f.nnorm ? (f.lsorted ? 1 : FF_L_REFERENCE) : 0, o));
         }
         auto prep = [&](int64_t g) {
             char e[1024] = {0};

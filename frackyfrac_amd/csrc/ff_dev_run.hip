@@ -338,7 +338,7 @@ int upload_exact64_tiles(ff_plan *pl, int h, char *err, size_t errlen)
                         xt.size(), ((size_t)1 << 26) - 1);
     pl->n_xtiles = (int)xt.size();
     pl->x_tile_h = h;
-    pl->x_skip = pl->weighted && env_int("FF_X_SKIP", 1) != 0 && (h == 8 || h == 12 || h == 16);
+    pl->x_skip = pl->weighted && inf.n_rows > 0 && env_int("FF_X_SKIP", 1) != 0 && (h == 8 || h == 12 || h == 16);
     inf.kernel = pl->x_skip ? FF_KERNEL_EXACT_F64_SKIP : FF_KERNEL_EXACT_F64;
     FF_HIP(hipMalloc(&pl->d_xtiles, sizeof(XTile) * std::max<size_t>(xt.size(), 1)));
     if (!xt.empty()) FF_HIP(hipMemcpy(pl->d_xtiles, xt.data(), sizeof(XTile) * xt.size(), hipMemcpyHostToDevice));

@@ -716,7 +716,17 @@ int plan_build(const ff_options *o, DeviceCsr *c, const hipDeviceProp_t &prop, f
     c->d_ids = nullptr;
     c->d_abnd = nullptr;
 
-    if (o->flags & FF_FLAG_UNSORTED_WALK) {
+    // A branch length that is not a finite number (the Newick reader takes "inf" and "nan" as strconv.ParseFloat does):
+    // the reference's walk never touches a branch NEITHER sample of a pair has (unifrac.go:178-203), so such a pair keeps
+    // a finite distance, while every dense reformulation multiplies the length by the pair's absent / absent zeros --
+    // Inf * 0 = NaN.  pair_exact_unw_kernel forms its operands by masking the length's bits and is safe; the weighted
+    // EXACT64 kernels (and the unweighted one on the weighted kernel's arithmetic, FF_EXACT_UNW=0) are not: such a tree
+    // goes to the literal walk, the reference's own operations on the pairs' own lists.  (FIXED32 refuses it: choose_quant.)
+    bool nonfinite_len = false;
+    for (int64_t b = 0; b < B; ++b) nonfinite_len = nonfinite_len || !std::isfinite(c->h_len[(size_t)b]);
+    const bool dense_unsafe = nonfinite_len && o->precision != FF_PRECISION_FIXED32 && N > 0 &&
+                              (weighted || env_int("FF_EXACT_UNW", 1) == 0);
+    if ((o->flags & FF_FLAG_UNSORTED_WALK) || dense_unsafe) {
         // nothing to stage: the walk reads the flat nodes as they stand, and every reformulation above (dense rows,
         // integer sums, presence bits) assumes lists a merge pairs up correctly
         pl->walk = true;

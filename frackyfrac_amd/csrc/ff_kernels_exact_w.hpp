@@ -88,7 +88,7 @@ void pair_exact64_skip_kernel(const double *__restrict__ DT, int64_t ld, const d
 #pragma unroll
         for (int r = 0; r < H; ++r) x[r] = pi[kk * ld + r];
     };
-    request(0, xa, la, ya);
+    request(0, xa, la, ya);  // (n_branches >= 1: a problem without branches never takes this kernel, upload_exact64_tiles)
     // (pairs of branches in ONE basic block -- an exit test between the two halves lets the compiler sink the first
     // half's requests behind its work, into the block that uses them --; an odd last branch behind the loop)
     const int64_t n_even = n_branches & ~(int64_t)1;

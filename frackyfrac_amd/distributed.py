@@ -49,19 +49,32 @@ def bounded_barrier(group=None, what: str = "a barrier", timeout_s: float = 120.
     work.wait()
 
 
-def wait_requests(reqs, what: str, timeout_s: Optional[float] = None) -> None:
+def wait_requests(reqs, what: str, timeout_s: Optional[float] = None, group=None) -> None:
     """Waits for point-to-point requests, but not for ever: a peer that never posts its side (it died, or left the
     exchange through an exception of its own) makes this rank raise after timeout_s (FF_GATHER_TIMEOUT_S, 600 s)
-    instead of sitting in the wait until the process group's own timeout.  (gloo honours the timeout of Work.wait;
-    with RCCL a wait only orders the current stream behind the transfer and the process group's watchdog bounds it.)"""
+    instead of sitting in the wait until the process group's own timeout.  The bound is this function's own clock on
+    BOTH backends.  gloo: Work.wait(timeout) honours it (its send / receive requests complete only inside a wait, so
+    they cannot be polled).  RCCL: Work.wait(timeout) only orders the current stream behind the transfer and returns at
+    once, so the requests are POLLED -- Work.is_completed, a query of the transfer's event that never blocks -- against
+    the deadline, and only a completed request is waited for."""
     import datetime
     import os
     import time
 
+    import torch.distributed as dist
+
     if timeout_s is None:
         timeout_s = float(os.environ.get("FF_GATHER_TIMEOUT_S", "600"))
+    polled = dist.get_backend(group) == "nccl"
     t0 = time.monotonic()
+    pause = 0.0002
     for q in reqs:
+        while polled and not q.is_completed():
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError("frackyfrac_amd: waited %.0f s for %s; a peer is gone or never entered the exchange"
+                                   % (timeout_s, what))
+            time.sleep(pause)
+            pause = min(pause * 1.5, 0.005)
         left = max(0.05, timeout_s - (time.monotonic() - t0))
         try:
             ok = q.wait(datetime.timedelta(seconds=left))
@@ -107,10 +120,10 @@ def gather_slices(local, n_samples: int, rank: int, world: int, root: int = 0, f
             if b > a:
                 ops.append(dist.P2POp(dist.irecv, full[a:b], r, group))
         # one group call: the 7 incoming transfers run concurrently, one per xGMI link
-        wait_requests(dist.batch_isend_irecv(ops) if ops else [], "the peers' slices (root)")
+        wait_requests(dist.batch_isend_irecv(ops) if ops else [], "the peers' slices (root)", group=group)
         return full
     if local.numel() > 0:
-        wait_requests(dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]), "the root to take this rank's slice")
+        wait_requests(dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]), "the root to take this rank's slice", group=group)
     return None
 
 
@@ -191,7 +204,7 @@ def gather_slices_chunked(produce: Callable, n_samples: int, rank: int, world: i
             # enqueued behind sub-shard c's kernels on the communication stream; sub-shard c + 1 is
             # launched right after and overlaps with the transfer
             reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, part, root, group)])
-    wait_requests(reqs, "the sub-shards' transfers")
+    wait_requests(reqs, "the sub-shards' transfers", group=group)
     return full if rank == root else None
 
 

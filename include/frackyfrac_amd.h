@@ -84,7 +84,11 @@ typedef enum ff_precision {
                                  weighted runs on the vector ALU (v_sad_u32), unweighted on
                                  the int8 matrix cores (same integers, same results)          */
     FF_PRECISION_EXACT64 = 2  /* binary64 in the reference's own summation order: bit-for-bit
-                                 the reference for any finite input; weighted about 4x slower
+                                 the reference for every input it accepts (negative, infinite
+                                 and NaN branch lengths included: a tree with a non-finite
+                                 length is reduced by the literal merge walk, which like the
+                                 reference never touches a branch neither sample of a pair
+                                 has); weighted about 4x slower
                                  than FIXED32, unweighted about 2x slower than the vector-ALU
                                  FIXED32 path (40x slower than the matrix cores)              */
 } ff_precision;

@@ -29,7 +29,7 @@ for case in range(ncase):
     open(d + "/t.tab", "w").write(text)
     otree = O.parse_newick(nwk)
     abnd = O.parse_sparse_abundance(text) if sparse else O.parse_abundance(text)
-    want = O.format_output(O.unifrac(abnd, otree, weighted, nnorm=unnorm))
+    want = O.format_output(O.unifrac(abnd, otree, weighted, nnorm=unnorm, reference_l_quirk=True))
     args = [L.FRCFRC_PATH, "-t", d + "/t.tree", "-i", d + "/t.tab", "-p", str(int(rng.choice([1, 3])))]
     if sparse: args.append("-s")
     if weighted: args.append("-w")

@@ -46,6 +46,10 @@ def test_self_launch_runs_two_ranks_and_prints_one_line():
         assert r["transport"] == g["transport"] and r["device"] and r["local_rank"] == 0
     assert ranks[0]["exposed_gather_ms_last_step"] == 0 or g["transport"] == "nccl"
     assert out["roofline"]["floor_ms"] > 0 and out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"]
+    # value = all ranks' pairs over the MAX-over-ranks time of the timed steps
+    assert abs(out["value"] - sum(r["pairs"] for r in ranks) / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert out["ms_per_step"] >= max(r["elapsed_ms_per_step"] for r in ranks) * (1 - 1e-9)
+    assert "nccl" in g["untested_transport"] and "gloo" in g["untested_transport"]
     # weak scaling: the sample count grows as sqrt(N), rounded to 32
     out, _ = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--workload",
                        "768x1500", "--no-cpu-baseline", "--no-secondary")
@@ -76,16 +80,36 @@ def test_single_gpu_line_carries_the_secondary_entries():
     rw = out["reference_width"]
     assert rw["dtype"] == "f64" and rw["value"] == sec[0]["value"] and rw["roofline"]["kernel"] == "pair_exact64_skip_kernel"
     assert abs(rw["roofline"]["frac_unfused6"] - 3.0 * rw["roofline"]["frac"]) < 1e-9
-    # the rocprof-reported rate: the primary kernel's counter bytes per launch, measured on THIS box by two child runs
-    # under rocprofv3 --pmc once the timings are done (bench.py live_traffic), over this run's kernel time; the committed
-    # figure of profiles/traffic.json beside it -- same build, same schedule: the same traffic within the counters' noise
+    # the rocprof-reported rate: the primary kernel's counter bytes per launch over this run's kernel time.  Either
+    # measured on THIS box (two child runs under rocprofv3 --pmc, bench.py live_traffic) or -- a box whose profiler is
+    # absent, refuses a counter or runs out of time -- the committed figure of profiles/traffic.json with a
+    # `traffic_note` saying so: both are valid outcomes of the line.  (That the live figure agrees with the committed
+    # one is asserted under `-m perf`, tests/test_gpu_perf.py: no profiler can fail the parity gate.)
     rl, hbm = out["roofline"], out["roofline"]["hbm"]
-    assert rl["traffic_source"].startswith("live on this box"), rl.get("traffic_note")
-    assert rl["fetch_size_kib"] > 0 and rl["write_size_kib"] > 0
-    assert abs(rl["traffic"] - (2 * rl["fetch_size_kib"] + rl["write_size_kib"]) * 1024) < 1.0
-    assert 0.7 < rl["traffic"] / rl["traffic_committed"] < 1.4
+    assert rl["traffic"] > 0 and rl["traffic_source"]
+    if "traffic_note" in rl:
+        assert "committed" in rl["traffic_note"] or "profiler" in rl["traffic_note"]
+        assert "fetch_size_kib" not in rl
+    else:
+        assert rl["traffic_source"].startswith("live on this box")
+        assert abs(rl["traffic"] - (2 * rl["fetch_size_kib"] + rl["write_size_kib"]) * 1024) < 1.0
+        assert rl["traffic_committed"] > 0
     assert hbm["measured_GBps"] > hbm["achieved"] and 0 < hbm["measured_frac_of_8000"] < hbm["measured_frac_of_6290"] < 1
     assert hbm["traffic_ratio"] > 1.0 and abs(hbm["traffic_ratio"] - rl["traffic"] / hbm["algorithmic_bytes"]) < 1e-9
+    # end to end: host buffers, and the frcfrc executable on C3 and C4 as files -- default flags, -p 1,
+    # -p <cores>: every run ends well, writes one line per pair, and the three outputs are the same bytes
+    e2e = out["end_to_end"]
+    assert e2e["host_buffers_ms"] > 0
+    assert [e["workload"] for e in e2e["frcfrc"]] == ["C3", "C4"]
+    for e in e2e["frcfrc"]:
+        assert "error" not in e, e
+        assert e["outputs_identical"] and e["lines_ok"], e
+        assert [r["flags"] for r in e["runs"]] == ["(default)", "-p 1", "-p %d" % cb["cores"]]
+        for r in e["runs"]:
+            assert r["rc"] == 0 and r["lines"] == e["pairs"] and r["precision"] == "fixed32"
+            assert set(r["seconds"]) == {"tree", "load", "validate", "open", "convert", "distances", "write", "close"}
+            assert r["detail"]["kernels"] > 0 and r["detail"]["text_bytes"] == int(round(r["output_MB"] * 1e6))
+        assert e["runs"][0]["threads"] == cb["cores"] and e["runs"][1]["threads"] == 1
     assert sec[0]["config"]["precision"] == "exact64" and sec[0]["roofline"]["kernel"] == "pair_exact64_skip_kernel"
     assert sec[1]["roofline"]["bound"] == "mfma" and "unweighted" in sec[1]["config"]["workload"]
     assert sec[1]["roofline"]["kernel"] == "pair_common_mfma_kernel" and sec[2]["roofline"]["kernel"] == "pair_common_small_kernel"
@@ -116,7 +140,12 @@ def test_default_multi_gpu_line_leads_with_c4_strong_and_carries_the_weak_one():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert out["config"]["workload"].startswith("C4:") and out["config"]["pairs"] == 16384 * 16383 // 2
     assert sum(r["pairs"] for r in out["ranks"]) == 16384 * 16383 // 2
+    assert abs(out["value"] - 16384 * 16383 // 2 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
     assert 0 < out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"]
+    # the base of the strong curve: the same problem on one GPU, same build, same run
+    sb = out["strong_base"]
+    assert sb["n_gpus"] == 1 and sb["workload"].startswith("C4:") and sb["value"] > 0 and sb["kernel"].startswith("pair_sad_kernel")
+    assert abs(sb["value"] - 16384 * 16383 // 2 / (sb["ms_per_step"] * 1e-3)) <= 1e-6 * sb["value"]
     weak = out["weak_scaling"]
     assert weak["scaling"] == "weak" and weak["config"]["workload"].startswith("C3:") and weak["config"]["pairs"] == 5792 * 5791 // 2
     assert [r["rank"] for r in weak["ranks"]] == [0, 1] and "C3" in out["scaling_note"]

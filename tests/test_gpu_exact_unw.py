@@ -182,6 +182,99 @@ def test_lengths_no_arithmetic_may_touch(kind):
         assert np.isnan(want).any() and not np.isnan(want).all()   # (the case bites, and not everywhere)
 
 
+@pytest.mark.parametrize("precision", ["auto", "exact64"])
+@pytest.mark.parametrize("kind", ["negative", "inf", "nan", "huge_and_tiny", "minus_zero"])
+def test_weighted_lengths_no_arithmetic_may_touch(kind, precision, monkeypatch):
+    """The same for WEIGHTED (unifrac.go:178-203 never touches a branch neither sample has): the dense EXACT64 kernels
+    would add l * |0 - 0| or l * 0 for it -- NaN for an infinite or NaN length where the reference prints a finite
+    distance.  Such a tree goes to the literal walk (plan_build); negative, huge, subnormal and -0 lengths stay on the
+    dense kernel, whose operations are the reference's.  Big enough for the skip kernel's tile heights."""
+    monkeypatch.setenv("FF_X_TILE_H", "12")   # (a shard this small would take 4-row tiles of pair_exact64_kernel)
+    tree, ptr, idx, val = synth.make(700, 300, 0.15, 78)
+    rng = np.random.default_rng(4)
+    bl = rng.lognormal(-2.0, 1.0, len(tree.branch_len))
+    bl[0] = 0.0
+    pick = rng.choice(np.arange(1, len(bl)), 6, replace=False)
+    if kind == "negative":
+        bl[pick] = -bl[pick]
+    elif kind == "inf":
+        bl[pick[:2]] = [np.inf, -np.inf]
+    elif kind == "nan":
+        bl[pick[:2]] = np.nan
+    elif kind == "huge_and_tiny":
+        bl[pick[:3]] = [1e300, 5e-324, 1e-310]
+    else:
+        bl[pick] = -0.0
+    T = ff.parse_newick(tree.newick())
+    nodes0 = ff.flatten_leaf_csr(T, ptr, idx, val)
+    nodes = ff.FlatNodes(nodes0.indptr, nodes0.branch_id, nodes0.abnd, bl)
+    ft = O.FlatTree(tree.names, bl, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, bl, True, nthreads=HOST_THREADS)
+    plan = ff.Plan(nodes, True, precision=precision)
+    assert plan.info.precision == L.PRECISION_EXACT64
+    assert L.KERNEL_NAMES[plan.info.kernel] == ("pair_walk_kernel" if kind in ("inf", "nan") else "pair_exact64_skip_kernel")
+    got = plan.run_host()
+    plan.close()
+    assert same_bits(got, want)
+    if kind in ("inf", "nan"):
+        assert np.isnan(want).any() and np.isfinite(want).any()   # (the case bites, and not everywhere)
+        # sharded, and through the one-call entry point
+        parts = []
+        for r in range(3):
+            p = ff.Plan(nodes, True, precision=precision, rank=r, world=3)
+            parts.append(p.run_host())
+            p.close()
+        assert same_bits(np.concatenate(parts), want)
+        assert same_bits(ff.unifrac_dists(nodes, True, precision=precision), want)
+        with pytest.raises(L.FFError):
+            ff.Plan(nodes, True, precision="fixed32")
+
+
+@pytest.mark.parametrize("n", [2055, 4097])
+def test_all_zero_presence_matrix_and_row_counts_the_tile_height_does_not_divide(n):
+    """The two shapes round 4's microbench faulted next to: a presence matrix without a single bit (every
+    sample empty: all distances 0 / 0; then half of them empty), and a sample count the tile height does not divide
+    (the last tile's rows past the end must neither be written nor counted)."""
+    tree, ptr, idx, val = synth.make(n, 400, 0.1, 5)
+    T = ff.parse_newick(tree.newick())
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    empty_ptr = np.zeros(n + 1, dtype=np.int64)
+    nodes = ff.flatten_leaf_csr(T, empty_ptr, idx[:0], val[:0])
+    plan = ff.Plan(nodes, False, precision="exact64")
+    assert plan.info.kernel == K_EXACT_UNW
+    got = plan.run_host()
+    plan.close()
+    assert got.shape == (n * (n - 1) // 2,) and np.isnan(got).all()
+    # every other sample empty
+    keep = np.arange(n) % 2 == 0
+    cnt = np.where(keep, np.diff(ptr), 0)
+    p2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    sel = np.concatenate([np.arange(ptr[s], ptr[s + 1]) for s in range(n) if keep[s]])
+    nodes = ff.flatten_leaf_csr(T, p2, idx[sel], val[sel])
+    ip, on = O.flatten_samples(ft, p2, idx[sel], val[sel], 0)
+    want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
+    for world in (1, 3):
+        parts = []
+        for r in range(world):
+            plan = ff.Plan(nodes, False, precision="exact64", rank=r, world=world)
+            assert plan.info.kernel == K_EXACT_UNW
+            parts.append(plan.run_host())
+            plan.close()
+        assert same_bits(np.concatenate(parts), want)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_a_problem_without_branches(weighted):
+    """n_branches == 0 (validate_problem accepts it): every distance is 0 / 0; no kernel may read a branch.  Large
+    enough for the weighted skip kernel's tile heights, which read one branch ahead."""
+    n = 2100
+    nodes = ff.FlatNodes(np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0))
+    for precision in ("exact64", "auto"):
+        got = ff.unifrac_dists(nodes, weighted, precision=precision)
+        assert got.shape == (n * (n - 1) // 2,) and np.isnan(got).all()
+
+
 def test_cli_prints_the_reference_bits_for_decimal_lengths(tmp_path):
     """The frcfrc command on a table past the small-problem threshold, unweighted, a tree with decimal branch
     lengths: no "-precision" given, the output is the oracle's text byte for byte and -stats says bit_exact."""

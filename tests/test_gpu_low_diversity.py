@@ -88,7 +88,7 @@ def test_fixed32_low_diversity_through_the_cli(tmp_path, case):
     for leave in (False, True):
         nodes, ip, on, ft = both_sides(tree, ptr, idx, val, leave)
         want = O.unifrac_dists(ip, on, ft.dist, True)
-        r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", *(["-l"] if leave else []), "-precision", "fixed32", "-stats",
+        r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", *(["-l", "-l-sorted"] if leave else []), "-precision", "fixed32", "-stats",
                             "-i", str(tmp_path / "t.sparse"), "-t", str(tmp_path / "t.tree")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr

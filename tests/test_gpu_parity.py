@@ -386,8 +386,8 @@ def test_leave_unnormalized_flag():
 
 def test_l_as_the_reference_computes_it(tmp_path):
     """The reference's own -l: lists neither divided NOR SORTED (unifrac.go:57-59,108-110), so its merge
-    walk mis-pairs branches.  The engine's -l sorts; behind a switch -- leave_unnormalized="reference" /
-    FF_FLAG_UNSORTED_WALK / `frcfrc -w -l -l-compat` -- it reproduces the reference instead, bit for bit: the lists
+    walk mis-pairs branches.  `frcfrc -w -l` (like leave_unnormalized="reference" / FF_FLAG_UNSORTED_WALK and the cgo
+    shim under -l) reproduces the reference, bit for bit; `-l -l-sorted` and leave_unnormalized=True sort: the lists
     as the recursion leaves them and the literal two-pointer walk (pair_walk_kernel).  Checked against the oracle's
     restatement of that quirk; the two -l's differ (the switch bites); shards tile the result; the command prints it."""
     tree, ptr, idx, val = synth.make(90, 400, 0.15, 23)
@@ -419,7 +419,7 @@ def test_l_as_the_reference_computes_it(tmp_path):
     lines = [" ".join("%s:%s" % (tree.names[idx[k]], repr(float(val[k]))) for k in range(ptr[s], ptr[s + 1]))
              for s in range(len(ptr) - 1)]
     (tmp_path / "t.sparse").write_text("\n".join(lines) + "\n")
-    for flags, expect in ((["-l", "-l-compat"], want), (["-l"], sorted_l)):
+    for flags, expect in ((["-l"], want), (["-l", "-l-compat"], want), (["-l", "-l-sorted"], sorted_l)):
         out = tmp_path / "out.txt"
         r = subprocess.run([L.FRCFRC_PATH, "-w", "-s", *flags, "-i", str(tmp_path / "t.sparse"), "-t", str(tmp_path / "t.tree"),
                             "-o", str(out), "-precision", "exact64"], capture_output=True, text=True)
@@ -427,6 +427,8 @@ def test_l_as_the_reference_computes_it(tmp_path):
         assert out.read_text() == O.format_output(expect), flags
     r = subprocess.run([L.FRCFRC_PATH, "-w", "-l-compat", "-t", str(tmp_path / "t.tree")], capture_output=True, text=True)
     assert r.returncode == 2 and "-l-compat can only be used with -l" in r.stderr
+    r = subprocess.run([L.FRCFRC_PATH, "-w", "-l-sorted", "-t", str(tmp_path / "t.tree")], capture_output=True, text=True)
+    assert r.returncode == 2 and "-l-sorted can only be used with -l" in r.stderr
 
 
 def test_bad_problems_are_rejected():
