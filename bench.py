@@ -54,6 +54,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
+SPARSE_REGIME = ("8192x50000@0.01", "8192x50000@0.002")   # C5's tree and sample count at real-table densities
 HBM_PEAK_GBPS = 8000.0            # HBM3E spec
 HBM_COPY_GBPS = 6290.0            # measured copy ceiling (same guide)
 VALU_PEAK_TLANEOPS = 78.65        # 157.3 TFLOP/s FP32 vector / 2 flops per lane-op
@@ -227,9 +228,12 @@ def make_problem(ctx, workload, n_samples=None):
         cfg = dict(synth.CONFIGS[workload])
         name = workload
     else:
-        ns, nl = workload.lower().split("x")
-        cfg = dict(n_samples=int(ns), n_leaves=int(nl), density=0.10, weighted=True, seed=synth.SEED_BASE + 77)
-        name = "custom"
+        # SAMPLESxLEAVES[@DENSITY], e.g. 2048x5000 or 8192x50000@0.01
+        shape, _, dens = workload.lower().partition("@")
+        ns, nl = shape.split("x")
+        cfg = dict(n_samples=int(ns), n_leaves=int(nl), density=float(dens) if dens else 0.10, weighted=True,
+                   seed=synth.SEED_BASE + 77)
+        name = workload.lower() if dens else "custom"   # (with a density: also the key of its counters in profiles/traffic.json)
     if n_samples is not None:
         cfg["n_samples"] = n_samples
     t0 = time.perf_counter()
@@ -499,7 +503,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                  "ms_per_step": elapsed / steps * 1e3,
                  "dtype": {0: "u32", 3: "u32", 1: "f64", 2: "i8", 4: "i8", 5: "f64", 6: "f64", 7: "f64"}[int(info.kernel)],
                  "config": {"workload": "%s: %d samples x %d-leaf Yule tree (B=%d branches), %s UniFrac, "
-                                        "leaf density %.2f, seed 0x%X%s" %
+                                        "leaf density %g, seed 0x%X%s" %
                                         (cfg["name"], n_samples, cfg["n_leaves"], B,
                                          "weighted" if weighted else "unweighted", cfg["density"], cfg["seed"],
                                          ", branch lengths log-normal (sigma 1.5)" if cfg.get("lengths") == "lognormal" else ""),
@@ -510,6 +514,8 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                                          # the exact unweighted kernel's, whose traffic does not depend on the lengths)
                                          None if cfg.get("lengths") == "lognormal" and int(info.kernel) != 5
                                          else traffic_of(cfg["name"], ctx.world, info, weighted))}
+        entry["_active_fraction"] = float(info.active_fraction)
+        entry["roofline"]["rows_staged"] = int(info.n_rows)   # branches some sample reaches (compaction) of B
         entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region
         entry["roofline"]["kernel_ms_between_events"] = kernel_ms_events
         if n_audit:
@@ -539,7 +545,7 @@ def main():
     # (defaults: about a second of GPU time in the timed region, so that an outside sampler of GPU activity sees it)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C3", help="C2|C3|C4|C5 or SAMPLESxLEAVES (e.g. 2048x5000)")
+    ap.add_argument("--workload", default="C3", help="C2|C3|C4|C5 or SAMPLESxLEAVES[@DENSITY] (e.g. 2048x5000, 8192x50000@0.01)")
     ap.add_argument("--precision", default="fixed32", choices=["auto", "fixed32", "exact64"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1: weak = samples grow as sqrt(N) (per-GPU pairs fixed), strong = the workload's own size; "
@@ -639,6 +645,7 @@ def main():
         weak_entry = measure(ctx, cfg_w, nodes, True, "fixed32", args.steps, args.warmup)
         if rank == 0:
             weak_entry["scaling"] = "weak"
+            weak_entry.pop("_active_fraction", None)
 
     e2e = None
     want_e2e = rank == 0 and world == 1 and not args.no_end_to_end and not ctx.rehearse
@@ -656,6 +663,7 @@ def main():
 
     out = None
     if rank == 0:
+        primary.pop("_active_fraction", None)
         out = {"metric": "sample-pairs/sec (lower triangle), weighted UniFrac 4096 samples x 10k-leaf tree"
                          if cfg["name"] == "C3" and weighted else "sample-pairs/sec (lower triangle)",
                "value": primary["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -717,7 +725,31 @@ def main():
             sec.append(measure(ctx, c2, n2, True, "fixed32", k, w))
             del n2
         if rank == 0:
+            for e in sec:
+                e.pop("_active_fraction", None)
             out["secondary"] = sec
+    if (rank == 0 and world == 1 and not args.no_secondary and args.workload == "C3" and not args.unweighted and
+            args.precision == "fixed32" and args.lengths == "generator"):
+        # Where real tables live: BASELINE configs[4]'s tree and sample count at 1 % and 0.2 % leaf density
+        # instead of its 5-10 %.  The engine compacts the branches no sample reaches and walks only the (sample block,
+        # branch) cells with something in them (pair_sad_sparse_kernel); the roofline stays priced on the UNCOMPACTED
+        # 2*B lane-ops per pair, so skipping shows as a fraction above the dense kernel's -- and the
+        # reference's merge walk costs O(flat nodes), not O(B), there: its rate on the SAME table stands beside it.
+        sparse = []
+        for wl in SPARSE_REGIME:
+            try:
+                c2, n2 = make_problem(ctx, wl)
+                e = measure(ctx, c2, n2, True, "fixed32", max(1, min(args.secondary_steps, args.steps)), 1)
+                e["active_fraction"] = e.pop("_active_fraction", None)
+                e["flat_nodes_per_sample"] = len(n2.branch_id) / float(n2.n_samples)
+                if not args.no_cpu_baseline:
+                    e["cpu_baseline"] = cpu_baseline(n2, True, min(args.cpu_budget, 6.0))
+                    e["gpu_over_cpu_all_cores"] = e["value"] / e["cpu_baseline"]["value"]
+                sparse.append(e)
+                del n2
+            except Exception as ex:  # (the line must come out)
+                sparse.append({"workload": wl, "error": "%s: %s" % (type(ex).__name__, ex)})
+        out["sparse_regime"] = sparse
     if (want_e2e and args.workload == "C3" and not args.unweighted and args.precision == "fixed32" and
             args.lengths == "generator" and not under_a_profiler()):
         # the command a user runs, on files: C3 and BASELINE configs[3]'s size on this one GPU

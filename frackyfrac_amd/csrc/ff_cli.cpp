@@ -270,11 +270,11 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
         return die("no HIP device available; this engine has no CPU path");
     }
     const int64_t P = ff_num_pairs(n);
-    int64_t budget = (int64_t)1 << 25;  // pairs per shard: 256 MB of results + up to 0.8 GB of their text, twice
+    int64_t budget = (int64_t)1 << 25;  // pairs per shard: 256 MB of results + up to 0.8 GB of their text, up to four times
     {
         const size_t free_b = ff::device_free_bytes(0);
-        // 4 B accumulator + 8 B result + 2 x 25 B of text per pair, the staged matrix and the rest in the other 40 %
-        if (free_b > 0) budget = std::min<int64_t>(budget, (int64_t)((double)free_b * 0.6 / 62.0));
+        // 4 B accumulator + 8 B result + 4 x 25 B of text per pair, the staged matrix and the rest in the other 40 %
+        if (free_b > 0) budget = std::min<int64_t>(budget, (int64_t)((double)free_b * 0.6 / 112.0));
         if (const char *e = getenv("FF_CLI_MAX_PAIRS"))  // (tests)
             if (atoll(e) > 0) budget = atoll(e);
         budget = std::max<int64_t>(budget, 1);

@@ -614,6 +614,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             for (int64_t w = 0; w < words; ++w) active += __builtin_popcountll(a64[(size_t)(ib * words + w)]);
         const double total = (double)std::max<int64_t>(1, (ib1 - ib0) * rows);
         const double inactive = 1.0 - (double)active / total;
+        inf.active_fraction = (double)active / total;
         const auto thr = ff::tuning("FF_SPARSE_MIN");
         // the list walk runs at about 0.77 of the dense loop's rate per row (shallower
         // prefetch, per-row address arithmetic), so it pays from about a quarter upwards

@@ -67,13 +67,15 @@ namespace {
 constexpr int RING_SLOTS = 3;
 constexpr int64_t SLOT_BYTES_MAX = (int64_t)64 << 20, SLOT_BYTES_MIN = (int64_t)1 << 16;
 
-// What a device holds for the pipeline: two text buffers (the copier empties one while the next pass fills the
-// other), the per-block work space, a stream for the copies that the legacy stream's kernels do not wait for.
+// What a device holds for the pipeline: up to TEXT_BUFS text buffers (the copier empties one while later passes fill
+// the others: the device is not held up by the file system until it is four passes ahead of it), the per-block work
+// space, a stream for the copies that the legacy stream's kernels do not wait for.
+constexpr int TEXT_BUFS = 4;
 struct DeviceSide {
     int device = 0;
-    char *d_text[2] = {nullptr, nullptr};
-    int64_t cap[2] = {0, 0};
-    bool busy[2] = {false, false};
+    char *d_text[TEXT_BUFS] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t cap[TEXT_BUFS] = {0, 0, 0, 0};
+    bool busy[TEXT_BUFS] = {false, false, false, false};
     uint32_t *d_block_bytes = nullptr;
     unsigned long long *d_block_off = nullptr;
     int64_t blocks_cap = 0;
@@ -270,8 +272,7 @@ TextPipeline::~TextPipeline()
     const bool have = hipGetDevice(&cur) == hipSuccess;
     for (DeviceSide &sd : m.sides) {
         if (hipSetDevice(sd.device) != hipSuccess) continue;
-        (void)hipFree(sd.d_text[0]);
-        (void)hipFree(sd.d_text[1]);
+        for (int k = 0; k < TEXT_BUFS; ++k) (void)hipFree(sd.d_text[k]);
         (void)hipFree(sd.d_block_bytes);
         (void)hipFree(sd.d_block_off);
         if (sd.copy_stream) (void)hipStreamDestroy(sd.copy_stream);
@@ -319,11 +320,19 @@ int TextPipeline::submit(int device, const double *d_vals, int64_t n, char *err,
         }
     }
     if (!sd->copy_stream) FF_HIP(hipStreamCreateWithFlags(&sd->copy_stream, hipStreamNonBlocking));
-    const int buf = (int)(sd->submits & 1);
+    int buf = -1;
     {
-        // the pass before last on this device used the same buffer: its text has to be out
+        // a buffer whose text is out (an allocated one first); all four on their way: wait for one
         std::unique_lock<std::mutex> lk(m.mu);
-        m.cv.wait(lk, [&] { return !sd->busy[buf]; });
+        auto pick = [&] {
+            buf = -1;
+            for (int k = 0; k < TEXT_BUFS && buf < 0; ++k)
+                if (!sd->busy[k] && sd->d_text[k]) buf = k;
+            for (int k = 0; k < TEXT_BUFS && buf < 0; ++k)
+                if (!sd->busy[k]) buf = k;
+            return buf >= 0;
+        };
+        m.cv.wait(lk, pick);
     }
     const int64_t nb = fmt_blocks(n), need = (int64_t)ff_text_bound(n);
     if (need > sd->cap[buf]) {

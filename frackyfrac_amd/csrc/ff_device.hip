@@ -142,6 +142,7 @@ int plan_begin(const ff_options *o, int64_t N, int64_t B, ff_plan *pl, hipDevice
     pl->weighted = o->weighted != 0;
     ff_plan_info &inf = pl->info;
     inf.audit_min_headroom = INFINITY;
+    inf.active_fraction = 1.0;
     inf.n_samples = N;
     inf.n_branches = B;
     inf.n_compute_units = prop->multiProcessorCount;

@@ -220,6 +220,9 @@ typedef struct ff_plan_info {
     double audit_worst_rel_err;
     double audit_min_headroom; /* smallest (U * 1e-6 - 2) / (5 sqrt(k)) over the run's pairs that were not
                                   re-computed exactly (the rule queues everything under 1); infinity: none */
+    double active_fraction;    /* FIXED32 weighted: share of the shard's (32-sample block, staged row) cells in
+                                  which some sample has the branch -- what pair_sad_sparse_kernel walks (it skips
+                                  the rest) and what decides between it and the dense kernel; 1 where not counted */
 } ff_plan_info;
 
 typedef enum ff_kernel {
