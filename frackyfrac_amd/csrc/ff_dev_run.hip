@@ -77,8 +77,8 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     inf.n_wave_slots = U;
     std::vector<Item> items;
     std::vector<int32_t> item_ptr;
-    // up to 255 planes of accumulators (FF_PLANES; 1 = atomics only), within 1 GiB
-    int max_planes = std::min(255, std::max(1, env_int("FF_PLANES", 255)));
+    // up to 255 planes of accumulators, within 1 GiB
+    int max_planes = 255;
     while (max_planes > 1 && (double)max_planes * 4.0 * (double)std::max<int64_t>(n_slots, 1) > 1073741824.0) --max_planes;
     build_schedule(tiles, rows, U, &items, &item_ptr, &inf.elements, xcd_slices(), pl->waves_per_wg,
                    max_planes > 1 ? max_planes : 0, inf.row_begin > 0);
@@ -165,7 +165,7 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
             inf.elements = (double)n_st * S_TILE * S_TILE * (double)pl->m_ldb * pl->m_digits;
             pl->m_all_private = false;
             pl->m_any_atomic = false;
-            pl->m_fused = env_int("FF_MFMA_FUSED_FINISH", -1) != 0;  // every slot has one writer: it can write the distance
+            pl->m_fused = true;  // every slot has one writer: it writes the distance
 #define FF_S_ATTR(ND)                                                                                                   \
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_small_kernel<ND>),                            \
                                hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
@@ -234,12 +234,8 @@ int schedule_mfma(ff_plan *pl, char *err, size_t errlen)
     }
     // The matrix-core path can finish in place when every slot has exactly one writer (its tile's
     // only item, or a reduce kernel): the integer sums then never go through num[], and there is
-    // neither a memset nor a finish launch.  FF_MFMA_FUSED_FINISH=1 / 0 forces either where possible;
-    // by default whenever every item owns a private partial tile.  Read here, once per schedule.
-    {
-        const int fuse_env = env_int("FF_MFMA_FUSED_FINISH", -1);
-        pl->m_fused = !pl->m_any_atomic && (fuse_env < 0 ? pl->m_all_private : fuse_env != 0);
-    }
+    // neither a memset nor a finish launch: whenever every item owns a private partial tile.
+    pl->m_fused = !pl->m_any_atomic && pl->m_all_private;
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     FF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_common_mfma_kernel<true>),
@@ -351,10 +347,7 @@ int upload_exact64_tiles(ff_plan *pl, int h, char *err, size_t errlen)
 // The tile height is picked once per plan.  Every height gives every pair the same operations in the
 // same order; what differs is the number of waves and how their count divides into rounds of resident
 // waves (C3: 33.9 ms with 16 rows, 29.8 with 12; 2,500 samples x 20,000 leaves: 34.1 with 16, 27.2 with 10).
-// The default is 12 rows (the best or second best at the three shapes above); FF_X_TILE_H forces another,
-// and with FF_X_CALIBRATE=1 -- for a host that runs a plan many times -- a shard big enough for it to
-// matter (a quarter as many tiles of 16 rows as waves fit the device, or more) is timed with each height when it is
-// scheduled, results into a scratch array, and keeps the fastest (eleven extra launches at plan time).
+// The height comes from a model of the tiles' rounds fitted to sweeps over sample counts (below); FF_X_TILE_H forces one.
 // The tiles of pair_exact_unw_kernel for the plan's shard.  Two column groups per tile (64 accumulator registers, six
 // waves per SIMD) is what the vector ALU wants; a shard with fewer such tiles than SIMDs is bound by one wave's chain
 // of steps and takes single groups (twice the waves, shorter steps).
@@ -436,48 +429,6 @@ int schedule_exact64(ff_plan *pl, char *err, size_t errlen)
         }
         for (int cand : X_TILE_HEIGHTS)
             if (cand == forced) h = forced;
-        const int64_t n_slots = inf.slot_end - inf.slot_begin;
-        std::vector<Tile> probe;
-        build_tiles(inf.n_samples, inf.row_begin, inf.row_end, 16, X_TILE_J, false, &probe);
-        const bool big = (int64_t)probe.size() * 4 > (int64_t)inf.n_compute_units * 4 * 6 && inf.n_rows > 0;
-        if (!forced && big && env_int("FF_X_CALIBRATE", 0)) {
-            // Anything that goes wrong here (no room for the scratch array, a failed launch or event) only
-            // costs the calibration: the plan keeps the default height.  Scratch and events are released on
-            // every path out.
-            Scratch<double> scratch;
-            struct Events {
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                ~Events()
-                {
-                    if (e0) (void)hipEventDestroy(e0);
-                    if (e1) (void)hipEventDestroy(e1);
-                }
-            } ev;
-            bool ok = scratch.alloc((size_t)std::max<int64_t>(n_slots, 1)) == hipSuccess &&
-                      hipEventCreate(&ev.e0) == hipSuccess && hipEventCreate(&ev.e1) == hipSuccess;
-            float best = 0;
-            int best_h = h;
-            bool warm = false;
-            for (int cand : X_TILE_HEIGHTS) {
-                if (!ok) break;
-                ok = upload_exact64_tiles(pl, cand, err, errlen) == FF_OK;
-                if (ok && !warm) ok = launch_exact64(pl, nullptr, scratch.p, err, errlen) == FF_OK;  // (clocks up)
-                warm = true;
-                for (int rep = 0; rep < 2 && ok; ++rep) {
-                    float ms = 0;
-                    ok = hipEventRecord(ev.e0, nullptr) == hipSuccess &&
-                         launch_exact64(pl, nullptr, scratch.p, err, errlen) == FF_OK &&
-                         hipEventRecord(ev.e1, nullptr) == hipSuccess && hipEventSynchronize(ev.e1) == hipSuccess &&
-                         hipEventElapsedTime(&ms, ev.e0, ev.e1) == hipSuccess;
-                    if (ok && (best == 0 || ms < best)) {
-                        best = ms;
-                        best_h = cand;
-                    }
-                }
-            }
-            if (ok) h = best_h;
-            else (void)hipGetLastError();
-        }
         pl->x_tile_h = h;
     }
     return upload_exact64_tiles(pl, pl->x_tile_h, err, errlen);

@@ -638,8 +638,18 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             FF_HIP(hipMalloc(&pl->d_aptr16, sizeof(uint32_t) * aptr.size()));
             FF_HIP(hipMemcpy(pl->d_aptr16, aptr.data(), sizeof(uint32_t) * aptr.size(), hipMemcpyHostToDevice));
             FF_HIP(hipMalloc(&pl->d_cs16, sizeof(uint32_t) * (size_t)(marks * ld)));
-            prefix16_kernel<<<dim3((unsigned)((ld + 63) / 64)), dim3(64)>>>(pl->d_QT, ld, rows, pl->d_cs16);
-            FF_HIP(hipGetLastError());
+            {
+                static_assert(PFX_CHUNK_ROWS % (2 * KSTEP) == 0, "prefix16: a chunk holds whole marks");
+                const int64_t n_chunks = (rows + PFX_CHUNK_ROWS - 1) / PFX_CHUNK_ROWS;
+                Scratch<uint32_t> chunk_sums;
+                FF_HIP(chunk_sums.alloc((size_t)(n_chunks * ld)));
+                const dim3 grid((unsigned)((ld + 63) / 64), (unsigned)n_chunks);
+                prefix16_sums_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, chunk_sums.p);
+                prefix16_scan_kernel<<<dim3((unsigned)((ld + 63) / 64)), dim3(64)>>>(chunk_sums.p, ld, n_chunks);
+                prefix16_fill_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, chunk_sums.p, pl->d_cs16);
+                FF_HIP(hipGetLastError());
+                FF_HIP(hipDeviceSynchronize());  // (chunk_sums goes out of scope)
+            }
             pl->sparse = true;
             inf.kernel = FF_KERNEL_SAD_U32_SPARSE;
         }

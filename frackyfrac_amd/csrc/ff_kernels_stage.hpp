@@ -86,15 +86,43 @@ __global__ void colsum_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64
     if (acc) atomicAdd(&W[s], acc);
 }
 
-// cs16[t][s] = sum of column s over the rows [0, 16 t): one column per lane, sequential over rows.
-__global__ void prefix16_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
-                                uint32_t *__restrict__ cs16)
+// cs16[t][s] = sum of column s over the rows [0, 16 t).  Three launches over chunks of PFX_CHUNK_ROWS rows -- the
+// chunks' sums, their exclusive scan per column, the marks of every chunk from its base -- so that a column is walked
+// by rows / PFX_CHUNK_ROWS threads instead of one (one thread per column took 38 ms for C5's 100,000 rows: more than
+// a pass of the kernel the sums are for; two reads of the staged matrix at the memory's rate take 2).
+constexpr int PFX_CHUNK_ROWS = 1024;  // a multiple of 16
+__global__ void prefix16_sums_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
+                                     uint32_t *__restrict__ chunk_sums)  // [chunk][ld]
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ld) return;
+    const int64_t r0 = (int64_t)blockIdx.y * PFX_CHUNK_ROWS, r1 = min(rows, r0 + PFX_CHUNK_ROWS);
+    uint32_t run = 0;
+    for (int64_t r = r0; r < r1; ++r) run += QT[r * ld + s];
+    chunk_sums[(int64_t)blockIdx.y * ld + s] = run;
+}
+
+__global__ void prefix16_scan_kernel(uint32_t *__restrict__ chunk_sums, int64_t ld, int64_t n_chunks)  // -> exclusive, in place
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ld) return;
     uint32_t run = 0;
-    cs16[s] = 0;
-    for (int64_t r = 0; r < rows; ++r) {
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const uint32_t v = chunk_sums[c * ld + s];
+        chunk_sums[c * ld + s] = run;
+        run += v;
+    }
+}
+
+__global__ void prefix16_fill_kernel(const uint32_t *__restrict__ QT, int64_t ld, int64_t rows,
+                                     const uint32_t *__restrict__ chunk_base, uint32_t *__restrict__ cs16)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ld) return;
+    const int64_t r0 = (int64_t)blockIdx.y * PFX_CHUNK_ROWS, r1 = min(rows, r0 + PFX_CHUNK_ROWS);
+    uint32_t run = chunk_base[(int64_t)blockIdx.y * ld + s];
+    if (blockIdx.y == 0) cs16[s] = 0;
+    for (int64_t r = r0; r < r1; ++r) {
         run += QT[r * ld + s];
         if ((r & 15) == 15) cs16[((r >> 4) + 1) * ld + s] = run;
     }

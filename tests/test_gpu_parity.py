@@ -510,8 +510,7 @@ def test_unweighted_mfma_ways_out_agree_at_a_size_with_whole_rounds(monkeypatch,
 
     want, info = run({"FF_UNWEIGHTED_MFMA": "0"})
     assert info.kernel in (0, 3)
-    for env in ({}, {"FF_MFMA_PRIVATE_MB": "0"}, {"FF_MFMA_FUSED_FINISH": "0"},
-                {"FF_MFMA_PRIVATE_MB": "0", "FF_MFMA_FUSED_FINISH": "0"}, {"FF_MFMA_GRADED": "0"},
+    for env in ({}, {"FF_MFMA_PRIVATE_MB": "0"}, {"FF_MFMA_GRADED": "0"},
                 {"FF_MFMA_GRADED": "0", "FF_MFMA_PRIVATE_MB": "0"}):
         got, info = run(env)
         assert info.kernel == 2 and info.n_digits == (3 if digits3 else 2) and info.n_tiles == 342
@@ -569,7 +568,7 @@ def test_unweighted_mfma_graded_planes_at_the_ends_of_their_ranges(monkeypatch, 
 
 @pytest.mark.parametrize("weighted", [True, False])
 def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
-    """EXACT64's tile height (FF_X_TILE_H: 4..16 rows per wave; FF_X_CALIBRATE=1 times them at plan creation)
+    """EXACT64's tile height (FF_X_TILE_H: 4..16 rows per wave)
     only changes which wave computes a pair: every pair still walks all branches in ascending id with the
     reference's operations (unifrac.go:174-205), so all heights -- and the oracle -- agree bit for bit.  The
     sample count is no multiple of any height, and large enough for the calibration to run."""
@@ -585,7 +584,7 @@ def test_exact64_tile_heights_give_the_same_bits(monkeypatch, weighted):
     if not weighted:
         monkeypatch.setenv("FF_EXACT_UNW", "0")
     for env in ({"FF_X_TILE_H": "4"}, {"FF_X_TILE_H": "8"}, {"FF_X_TILE_H": "10"}, {},
-                {"FF_X_TILE_H": "12"}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"}, {"FF_X_CALIBRATE": "1"},
+                {"FF_X_TILE_H": "12"}, {"FF_X_TILE_H": "14"}, {"FF_X_TILE_H": "16"},
                 {"FF_X_TILE_H": "8", "FF_X_SKIP": "0"}, {"FF_X_TILE_H": "12", "FF_X_SKIP": "0"},
                 {"FF_X_TILE_H": "16", "FF_X_SKIP": "0"}, {"FF_X_SKIP": "0"}):
         for k, v in env.items():
@@ -742,9 +741,10 @@ def test_unweighted_mfma_table_segments_odd_slab_counts_and_ragged_sample_counts
 @pytest.mark.parametrize("ns", [300, 1200])
 @pytest.mark.parametrize("small", ["0", "1"])
 def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch, exact_lengths, ns, small):
-    """FF_MFMA_FUSED_FINISH: distances written by the pair kernel's epilogue / the partial reduction
-    (no num[], no finish launch) or by finish_fixed32_kernel -- the same doubles either way, with the
-    refinement queue in play when the lengths are off the binary grid (replicated samples), and the
+    """Distances written by the matrix-core kernels' own ways out -- the small kernel's epilogue, the partial
+    reduction (every item a private tile: no num[], no finish launch), or with FF_MFMA_PRIVATE_MB=0 the pair kernel's
+    in-place finish of unsplit tiles and finish_fixed32_kernel behind the split ones' atomics -- the same doubles every
+    way, with the refinement queue in play when the lengths are off the binary grid (replicated samples), and the
     oracle's to 1e-6 (bit-exact for dyadic lengths)."""
     monkeypatch.setenv("FF_MFMA_SMALL", small)
     tree, ptr, idx, val = synth.make(ns, 1500, 0.1, 31 + ns)
@@ -762,7 +762,7 @@ def test_unweighted_finish_fused_into_the_matrix_core_kernels_or_not(monkeypatch
     want = O.unifrac_dists(ip, on, ft.dist, False, nthreads=HOST_THREADS)
     got = {}
     for fused in ("0", "1"):
-        monkeypatch.setenv("FF_MFMA_FUSED_FINISH", fused)
+        monkeypatch.setenv("FF_MFMA_PRIVATE_MB", "2048" if fused == "1" else "0")
         plan = ff.Plan(nodes, False, precision="fixed32")
         assert plan.info.kernel == MFMA_KERNEL[small] and plan.info.lengths_exact == (1 if exact_lengths else 0)
         got[fused] = plan.run_host()
@@ -1239,15 +1239,16 @@ def test_one_staging_serves_every_shard(monkeypatch, case):
 
 def test_two_accumulator_planes_equal_atomics(monkeypatch):
     """4,096 samples = 1,088 pair tiles, enough for a main round: the halves of every split tile
-    store into two planes (item flag 8) instead of adding atomically.  Same distances as with
-    FF_PLANES=1 (atomics only), also after re-targeting the plan at shards, and the oracle's on a sample."""
+    store into two planes (item flag 8) instead of adding atomically.  Same distances as the 8-wave kernel's
+    schedule gives (other splits, other planes), also after re-targeting the plan at shards (whose remainders add
+    atomically), and the oracle's on a sample."""
     import torch
 
     nodes, ip, on, ft = synth_problem(4096, 300, 0.2, 31)
     n = 4096
-    monkeypatch.setenv("FF_PLANES", "1")
+    monkeypatch.setenv("FF_WAVES_PER_WG", "8")
     want = ff.unifrac_dists(nodes, True, precision="fixed32")
-    monkeypatch.setenv("FF_PLANES", "255")
+    monkeypatch.delenv("FF_WAVES_PER_WG")
     plan = ff.Plan(nodes, True, precision="fixed32")
     assert plan.info.n_tiles >= 1024 and plan.info.kernel == 0
     assert np.array_equal(plan.run_host(), want)
