@@ -250,8 +250,9 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     lap(3);
 
     fputs("Converting abundances\n", stderr);  // unifrac.go:101
-    std::vector<int64_t> leaf_ptr, leaf_idx;
-    std::vector<double> leaf_val;
+    std::vector<int64_t> leaf_ptr;
+    ff::I64Vec leaf_idx;
+    ff::F64Vec leaf_val;
     ff::table_leaf_csr(*table, *tree, &leaf_ptr, &leaf_idx, &leaf_val, nt);
     const int64_t n = ff_table_num_samples(table);
     ff_table_free(table);

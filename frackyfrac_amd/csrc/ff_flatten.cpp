@@ -137,8 +137,8 @@ namespace ff {
 // abnd[tree.Name] for leaves only (unifrac.go:38-43): species -> leaf ids resolved once;
 // a name carried by several leaves feeds each of them; a key naming an internal node is
 // never looked up.
-void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
-                    std::vector<int64_t> *idx, std::vector<double> *val, int threads)
+void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr, I64Vec *idx, F64Vec *val,
+                    int threads)
 {
     std::vector<const std::vector<int64_t> *> where(tb.species.size(), nullptr);
     for (size_t k = 0; k < tb.species.size(); ++k) {
@@ -213,8 +213,9 @@ int ff_flatten(const ff_table *tb, const ff_tree *tr, int leave_unnormalized, ff
                char *err, size_t errlen)
 {
     if (!tb || !tr || !flat) return ff::fail(FF_ERR_ARG, err, errlen, "ff_flatten: null argument");
-    std::vector<int64_t> ptr, idx;
-    std::vector<double> val;
+    std::vector<int64_t> ptr;
+    ff::I64Vec idx;
+    ff::F64Vec val;
     ff::table_leaf_csr(*tb, *tr, &ptr, &idx, &val);
     return ff_flatten_leaf_csr(tr, (int64_t)ptr.size() - 1, ptr.data(), idx.data(), val.data(), leave_unnormalized,
                                flat, err, errlen);
@@ -237,8 +238,9 @@ int ff_unifrac(const ff_table *table, const ff_tree *tree, const ff_options *o,
                int leave_unnormalized, double *out, char *err, size_t errlen)
 {
     if (!table || !tree) return ff::fail(FF_ERR_ARG, err, errlen, "ff_unifrac: null argument");
-    std::vector<int64_t> ptr, idx;
-    std::vector<double> val;
+    std::vector<int64_t> ptr;
+    ff::I64Vec idx;
+    ff::F64Vec val;
     ff::table_leaf_csr(*table, *tree, &ptr, &idx, &val);
     return ff::unifrac_leaves_info(tree, (int64_t)ptr.size() - 1, ptr.data(), idx.data(), val.data(),
                                    leave_unnormalized, o, out, nullptr, err, errlen);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <optional>
 #include <string>
 #include <unordered_map>
@@ -32,6 +33,26 @@ bool go_parse_float(const char *b, const char *e, double *out, const char **why)
 
 // Reads a whole file (path; gunzipped when it ends in ".gz") or stdin (path == nullptr).
 int read_all(const char *path, std::string *out, char *err, size_t errlen);
+// The same for a text that may be large (an abundance table): a plain regular file is read by `threads` threads
+// straight into a buffer that nobody zero-fills first (a 155-MB table took 0.27 s through read_all's growing string,
+// a third of its parse on 16 threads); everything else goes through read_all.
+struct Text {
+    const char *data = nullptr;
+    size_t size = 0;
+    std::unique_ptr<char[]> buf;
+    std::string str;
+};
+int read_text(const char *path, unsigned threads, Text *out, char *err, size_t errlen);
+
+// std::allocator whose resize() leaves trivially constructible elements uninitialised: no zero fill, no page touched
+// by the thread that resizes (the threads that fill the array touch it, each its own part).
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
 
 unsigned clamp_threads(int requested);
 // CPUs this process may use: the smallest of the hardware's count, the scheduler affinity mask and the cgroup's
@@ -121,6 +142,10 @@ private:
     std::vector<std::string> bufs_, zbufs_;
 };
 
+// Large arrays that parallel loops fill: resize() does not zero them (NoInitAlloc, above).
+using I64Vec = std::vector<int64_t, NoInitAlloc<int64_t>>;
+using F64Vec = std::vector<double, NoInitAlloc<double>>;
+
 // The output path of frcfrc with the formatter on the device (ff_kernels_fmt.hpp): the distances of a pass are
 // turned into text in HBM, the text is copied out through a ring of pinned host slots on a stream of its own and
 // appended to the file, all of it behind the main thread's back -- pass k + 1 is reduced while pass k is on its
@@ -148,8 +173,8 @@ private:
 };
 
 // abnd[tree.Name] for every leaf (unifrac.go:38-43) as CSR over node ids.
-void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr,
-                    std::vector<int64_t> *idx, std::vector<double> *val, int threads = 1);
+void table_leaf_csr(const ff_table &tb, const ff_tree &tr, std::vector<int64_t> *ptr, I64Vec *idx, F64Vec *val,
+                    int threads = 1);
 
 
 // Index of a vector of distinct names: open addressing over (hash tag, id + 1).  A lookup
@@ -224,8 +249,8 @@ struct ff_table {
     std::vector<std::string> species;
     ff::NameIndex index;
     std::vector<int64_t> ptr;  // [n_samples + 1]
-    std::vector<int32_t> key;  // species index
-    std::vector<double> val;
+    std::vector<int32_t, ff::NoInitAlloc<int32_t>> key;  // species index
+    std::vector<double, ff::NoInitAlloc<double>> val;
     int32_t intern(const char *b, const char *e);
 };
 

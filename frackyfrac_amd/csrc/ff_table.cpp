@@ -297,10 +297,10 @@ int ff_table_parse_mt(const char *text, size_t len, int sparse, int threads, ff_
 
 int ff_table_read_file_mt(const char *path, int sparse, int threads, ff_table **table, char *err, size_t errlen)
 {
-    std::string text;
-    int rc = ff::read_all(path, &text, err, errlen);
+    ff::Text text;
+    int rc = ff::read_text(path, ff::clamp_threads(threads), &text, err, errlen);
     if (rc) return rc;
-    return parse_table(text.data(), text.size(), sparse != 0, threads, table, err, errlen);
+    return parse_table(text.data, text.size, sparse != 0, threads, table, err, errlen);
 }
 
 int ff_table_read_file(const char *path, int sparse, ff_table **table, char *err, size_t errlen)

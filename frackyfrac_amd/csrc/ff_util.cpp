@@ -367,6 +367,61 @@ int read_all(const char *path, std::string *out, char *err, size_t errlen)
     return FF_OK;
 }
 
+int read_text(const char *path, unsigned threads, Text *out, char *err, size_t errlen)
+{
+    out->buf.reset();
+    out->str.clear();
+    out->data = nullptr;
+    out->size = 0;
+    const bool packed = path && (has_suffix(path, ".gz") || has_suffix(path, ".zst") || has_suffix(path, ".bz2"));
+    if (path && !packed) {
+        const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return fail(FF_ERR_IO, err, errlen, "open %s: %s", path, strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            const size_t n = (size_t)st.st_size;
+            out->buf.reset(new (std::nothrow) char[n]);  // (default-initialised: not zero-filled)
+            if (!out->buf) {
+                ::close(fd);
+                return fail(FF_ERR_IO, err, errlen, "read %s: out of memory for %zu bytes", path, n);
+            }
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(threads, 8u), n >> 24));  // 16 MB or more each
+            std::vector<int> errs(nt, 0);
+            std::vector<size_t> got(nt, 0);
+            parallel_for((int64_t)n, nt, [&](unsigned t, int64_t b, int64_t e) {
+                int64_t at = b;
+                while (at < e) {
+                    const ssize_t r = pread(fd, out->buf.get() + at, (size_t)(e - at), (off_t)at);
+                    if (r < 0) {
+                        if (errno == EINTR) continue;
+                        errs[t] = errno;
+                        break;
+                    }
+                    if (r == 0) break;  // (the file shrank under us: what was read is the text)
+                    at += r;
+                }
+                got[t] = (size_t)(at - b);
+            });
+            ::close(fd);
+            size_t total = 0;
+            bool whole = true;
+            for (unsigned t = 0; t < nt; ++t) {
+                if (errs[t]) return fail(FF_ERR_IO, err, errlen, "read %s: %s", path, strerror(errs[t]));
+                if (whole) total += got[t];
+                if (got[t] < (size_t)(n * (t + 1) / nt - n * t / nt)) whole = false;  // (a short part ends the text)
+            }
+            out->data = out->buf.get();
+            out->size = total;
+            return FF_OK;
+        }
+        ::close(fd);  // (a pipe, a device, an empty file: the general way)
+    }
+    const int rc = read_all(path, &out->str, err, errlen);
+    out->data = out->str.data();
+    out->size = out->str.size();
+    return rc;
+}
+
 unsigned clamp_threads(int requested)
 {
     if (requested < 1) requested = 1;
