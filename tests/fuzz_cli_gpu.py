@@ -29,16 +29,28 @@ for case in range(ncase):
     open(d + "/t.tab", "w").write(text)
     otree = O.parse_newick(nwk)
     abnd = O.parse_sparse_abundance(text) if sparse else O.parse_abundance(text)
-    want = O.format_output(O.unifrac(abnd, otree, weighted, nnorm=unnorm, reference_l_quirk=True))
-    args = [L.FRCFRC_PATH, "-t", d + "/t.tree", "-i", d + "/t.tab", "-p", str(int(rng.choice([1, 3])))]
+    lsorted = unnorm and bool(rng.random() < 0.5)     # -l alone is the reference's unsorted-list walk; -l-sorted sorts
+    want = O.format_output(O.unifrac(abnd, otree, weighted, nnorm=unnorm, reference_l_quirk=not lsorted))
+    args = [L.FRCFRC_PATH, "-t", d + "/t.tree", "-i", d + "/t.tab"]
+    if rng.random() < 0.7: args += ["-p", str(int(rng.choice([1, 3])))]   # (else: the CPU quota)
     if sparse: args.append("-s")
     if weighted: args.append("-w")
     if unnorm: args.append("-l")
+    if lsorted: args.append("-l-sorted")
     if rng.random() < 0.3: args += ["-gpus", "2"]
     env = dict(os.environ)
     if rng.random() < 0.3: env["FF_CLI_MAX_PAIRS"] = "50"
+    # where the text goes: stdout (a pipe), a file, a gzip file -- the device formatter's pipeline behind each
+    sink = str(rng.choice(["stdout", "file", "gz"]))
+    out_path = d + ("/out.txt.gz" if sink == "gz" else "/out.txt")
+    if sink != "stdout": args += ["-o", out_path]
     r = subprocess.run(args, capture_output=True, text=True, env=env)
-    if r.returncode != 0 or r.stdout != want:
+    got = r.stdout
+    if r.returncode == 0 and sink == "file": got = open(out_path).read()
+    if r.returncode == 0 and sink == "gz":
+        import gzip
+        got = gzip.open(out_path, "rt").read()
+    if r.returncode != 0 or got != want:
         bad += 1
         print("CASE", seed0 + case, "n", n, "leaves", leaves, "sparse", sparse, "weighted", weighted, "unnorm", unnorm, "rc", r.returncode, r.stderr[-200:], flush=True)
     if case % 50 == 0: print("case", case, "bad", bad, flush=True)
