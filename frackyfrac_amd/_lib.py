@@ -54,6 +54,8 @@ class ff_plan_info(ctypes.Structure):
 
 # ff_dists_fn: int (*)(void *user, int64_t slot_begin, const double *dists, int64_t n)
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)
+# ff_text_fn: int (*)(void *user, const char *text, size_t n_bytes)
+TEXT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t)
 
 KERNEL_NAMES = {0: "pair_sad_kernel", 1: "pair_exact64_kernel", 2: "pair_common_mfma_kernel",
                 3: "pair_sad_sparse_kernel", 4: "pair_common_small_kernel", 5: "pair_exact_unw_kernel", 6: "pair_walk_kernel", 7: "pair_exact64_skip_kernel"}
@@ -125,6 +127,9 @@ SIGNATURES = {
     "ff_format_float": (c_int, [c_double, c_char_p]),
     "ff_write_distances": (c_int, [c_char_p, c_void_p, c_int64, c_int, c_char_p, c_size_t]),
     "ff_cpu_quota": (c_int, []),
+    "ff_unifrac_text_stream": (c_int, [POINTER(ff_problem), POINTER(ff_options), c_int64, TEXT_FN, c_void_p, c_char_p, c_size_t]),
+    "ff_unifrac_text_stream_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(ff_options), c_int64,
+                                           TEXT_FN, c_void_p, c_char_p, c_size_t]),
     "ff_text_bound": (c_size_t, [c_int64]),
     "ff_format_distances_device": (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_size_t), c_void_p, c_char_p, c_size_t]),
     "ff_frcfrc_main": (c_int, [c_int, POINTER(c_char_p)]),

@@ -276,6 +276,37 @@ def unifrac_dists(nodes: FlatNodes, weighted: bool, precision="auto", device: in
     return out
 
 
+def unifrac_text_stream(nodes: FlatNodes, weighted: bool, write, precision="auto", device: int = -1, rank: int = 0,
+                        world: int = 1, max_pairs_per_chunk: int = 0, flat_args: bool = False,
+                        unsorted_walk: bool = False) -> int:
+    """unifracDists and the loop that prints it (unifrac.go:209-228 + frcfrc.go:58-62) as one lazy sequence of TEXT
+    (ff_unifrac_text_stream): `write(bytes)` receives pieces of whole lines, in order, formatted on the device; a
+    `write` that returns False stops the computation.  Returns the number of bytes handed over."""
+    state = {"error": None, "bytes": 0}
+
+    def on_text(_user, text, n):
+        try:  # (nothing may leave a ctypes callback: see unifrac_dists_stream)
+            keep_going = write(ctypes.string_at(text, n))
+            state["bytes"] += int(n)
+            return 0 if keep_going is False else 1
+        except BaseException as e:  # noqa: BLE001
+            state["error"] = e
+            return 0
+
+    cb = L.TEXT_FN(on_text)
+    p, o, err = nodes.problem(), _opts(weighted, precision, device, rank, world, unsorted_walk), L.errbuf()
+    if flat_args:
+        rc = L.lib().ff_unifrac_text_stream_csr(nodes.n_samples, nodes.n_branches, nodes.branch_len.ctypes.data,
+                                                nodes.indptr.ctypes.data, nodes.branch_id.ctypes.data, nodes.abnd.ctypes.data,
+                                                ctypes.byref(o), int(max_pairs_per_chunk), cb, None, err, L.ERRLEN)
+    else:
+        rc = L.lib().ff_unifrac_text_stream(ctypes.byref(p), ctypes.byref(o), int(max_pairs_per_chunk), cb, None, err, L.ERRLEN)
+    if state["error"] is not None:
+        raise state["error"]
+    L.check(rc, err)
+    return state["bytes"]
+
+
 def unifrac_dists_stream(nodes: FlatNodes, weighted: bool, precision="auto", device: int = -1, rank: int = 0,
                          world: int = 1, max_pairs_per_chunk: int = 0, flat_args: bool = False
                          ) -> Iterator[Tuple[int, np.ndarray]]:

@@ -56,6 +56,263 @@ int ff_format_distances_device(const double *d_values, int64_t n, char *d_text, 
     return FF_OK;
 }
 
+// ---- unifracDists + the printing loop as ONE lazy sequence of text (frcfrc/unifrac.go:209-228 + frcfrc.go:58-62) ----
+
+namespace {
+
+// Two device text buffers (sub-shard k + 1 is reduced and formatted while sub-shard k's text is handed over) and two
+// pinned host slots the text passes through on its way to the callback.
+struct TextStreamBuffers {
+    double *d_out = nullptr;
+    int64_t out_cap = 0;
+    char *d_text[2] = {nullptr, nullptr};
+    int64_t text_cap[2] = {0, 0};
+    uint32_t *d_block_bytes = nullptr;
+    unsigned long long *d_block_off = nullptr;
+    int64_t blocks_cap = 0;
+    char *slot[2] = {nullptr, nullptr};
+    bool pinned = false;
+    int64_t slot_bytes = 0;
+    hipStream_t copy = nullptr;
+    ~TextStreamBuffers()
+    {
+        (void)hipFree(d_out);
+        (void)hipFree(d_text[0]);
+        (void)hipFree(d_text[1]);
+        (void)hipFree(d_block_bytes);
+        (void)hipFree(d_block_off);
+        if (slot[0]) {
+            if (pinned) (void)hipHostFree(slot[0]);
+            else free(slot[0]);
+        }
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+    int reserve(int buf, int64_t n, char *err, size_t errlen)
+    {
+        const int64_t nb = fmt_blocks(n), need = (int64_t)ff_text_bound(n);
+        if (n > out_cap) {
+            (void)hipFree(d_out);
+            d_out = nullptr;
+            out_cap = 0;
+            if (hipMalloc(&d_out, sizeof(double) * (size_t)n) != hipSuccess) {
+                (void)hipGetLastError();
+                return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot allocate %.2f GB for a sub-shard's results (a smaller "
+                                "max_pairs_per_chunk makes it smaller)", 8e-9 * (double)n);
+            }
+            out_cap = n;
+        }
+        if (need > text_cap[buf]) {
+            (void)hipFree(d_text[buf]);
+            d_text[buf] = nullptr;
+            text_cap[buf] = 0;
+            if (hipMalloc(&d_text[buf], (size_t)need) != hipSuccess) {
+                (void)hipGetLastError();
+                return ff::fail(FF_ERR_DEVICE, err, errlen, "HIP: cannot allocate %.2f GB for a sub-shard's text (a smaller "
+                                "max_pairs_per_chunk makes it smaller)", 1e-9 * (double)need);
+            }
+            text_cap[buf] = need;
+        }
+        if (nb > blocks_cap) {
+            (void)hipFree(d_block_bytes);
+            (void)hipFree(d_block_off);
+            d_block_bytes = nullptr;
+            d_block_off = nullptr;
+            blocks_cap = 0;
+            FF_HIP(hipMalloc(&d_block_bytes, sizeof(uint32_t) * (size_t)nb));
+            FF_HIP(hipMalloc(&d_block_off, sizeof(unsigned long long) * (size_t)(nb + 1)));
+            blocks_cap = nb;
+        }
+        return FF_OK;
+    }
+};
+
+}  // namespace
+
+int ff_unifrac_text_stream(const ff_problem *p, const ff_options *o, int64_t max_pairs, ff_text_fn fn, void *user, char *err,
+                           size_t errlen)
+{
+    using namespace ff::dev;
+    if (!fn) return ff::fail(FF_ERR_ARG, err, errlen, "null callback");
+    ff_options base;
+    ff_options_default(&base);
+    if (o) base = *o;
+    if (base.world < 1 || base.rank < 0 || base.rank >= base.world)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", base.rank, base.world);
+    if (max_pairs <= 0) max_pairs = (int64_t)1 << 25;
+    int rc = validate_problem(p, err, errlen, (base.flags & FF_FLAG_UNSORTED_WALK) != 0);
+    if (rc) return rc;
+    int64_t rb = 0, re = 0;
+    if (ff_shard_rows(p->n_samples, base.rank, base.world, &rb, &re) != FF_OK)
+        return ff::fail(FF_ERR_ARG, err, errlen, "bad shard %d of %d", base.rank, base.world);
+    const int64_t shard_pairs = (re > 0 ? re * (re - 1) / 2 : 0) - (rb > 0 ? rb * (rb - 1) / 2 : 0);
+    if (shard_pairs <= 0) return FF_OK;  // lazily: nothing to deliver, nothing staged
+    // sub-shards as in ff_unifrac_dists_stream: shard rank * c + k of world * c tile this shard's slots in order
+    int64_t c = (shard_pairs + max_pairs - 1) / max_pairs;
+    c = std::min<int64_t>(c, std::max<int64_t>(1, (re - rb + 31) / 32));
+    c = std::min<int64_t>(c, (int64_t)INT32_MAX / base.world);
+    ff_options o2 = base;
+    o2.rank = (int32_t)(base.rank * c);
+    o2.world = (int32_t)(base.world * c);
+    ff_plan *pl = nullptr;
+    rc = ff_plan_create(p, &o2, &pl, err, errlen);
+    if (rc) return rc;
+    struct PlanGuard {
+        ff_plan *&pl;
+        ~PlanGuard() { ff_plan_destroy(pl); }
+    } guard{pl};
+    DeviceScope scope;
+    FF_HIP(scope.enter(pl->device));
+    TextStreamBuffers buf;
+    FF_HIP(hipStreamCreateWithFlags(&buf.copy, hipStreamNonBlocking));
+    {
+        // two slots of up to 32 MB (a tenth of a small output: nothing is pinned that will not be used)
+        int64_t want = std::min<int64_t>((int64_t)32 << 20, std::max<int64_t>((int64_t)1 << 16, shard_pairs * 20 / 4));
+        want = std::max<int64_t>(want, FMT_BLOCK_BYTES_MAX);
+        want = (want + 4095) / 4096 * 4096;
+        void *base_ptr = nullptr;
+        buf.pinned = hipHostMalloc(&base_ptr, (size_t)want * 2, hipHostMallocDefault) == hipSuccess;
+        if (!buf.pinned) {
+            (void)hipGetLastError();
+            base_ptr = malloc((size_t)want * 2);
+            if (!base_ptr) return ff::fail(FF_ERR_INTERNAL, err, errlen, "out of host memory for the text slots");
+        }
+        buf.slot[0] = static_cast<char *>(base_ptr);
+        buf.slot[1] = buf.slot[0] + want;
+        buf.slot_bytes = want;
+    }
+    // one sub-shard: kernels + format into text buffer `tb`, its block offsets to the host (the only wait)
+    std::vector<unsigned long long> off[2];
+    auto produce = [&](int tb) -> int {
+        const int64_t n = pl->info.slot_end - pl->info.slot_begin;
+        off[tb].assign(1, 0ull);
+        if (n <= 0) return FF_OK;
+        int r = buf.reserve(tb, n, err, errlen);
+        if (r) return r;
+        r = plan_run_impl(pl, nullptr, buf.d_out, false, err, errlen);
+        if (r) return r;
+        bool ok = true;
+        if (plan_fixed32_verdict(pl, &ok, nullptr) == FF_OK && !ok) {
+            // replicates, or a failed audit: this sub-shard again, and all later ones, in binary64
+            const int32_t rk = pl->shard_rank, wd = pl->shard_world;
+            ff_plan_destroy(pl);
+            pl = nullptr;
+            o2.precision = FF_PRECISION_EXACT64;
+            o2.rank = rk;
+            o2.world = wd;
+            r = ff_plan_create(p, &o2, &pl, err, errlen);
+            if (r == FF_OK) r = plan_run_impl(pl, nullptr, buf.d_out, false, err, errlen);
+            if (r) return r;
+        }
+        r = launch_format(buf.d_out, n, buf.d_text[tb], buf.d_block_bytes, buf.d_block_off, nullptr, err, errlen);
+        if (r) return r;
+        const int64_t nb = fmt_blocks(n);
+        off[tb].resize((size_t)nb + 1);
+        FF_HIP(hipMemcpy(off[tb].data(), buf.d_block_off, sizeof(unsigned long long) * (size_t)(nb + 1), hipMemcpyDeviceToHost));
+        return FF_OK;
+    };
+    // hands the text of buffer `tb` to the callback in pieces of whole blocks (whole lines) through the two slots,
+    // the copy of piece q + 1 under the callback of piece q; false: the consumer stopped
+    auto deliver = [&](int tb, bool *go_on) -> int {
+        *go_on = true;
+        const std::vector<unsigned long long> &bo = off[tb];
+        const int64_t nb = (int64_t)bo.size() - 1;
+        auto piece_end = [&](int64_t b) {
+            const unsigned long long limit = bo[(size_t)b] + (unsigned long long)buf.slot_bytes;
+            const auto it = std::upper_bound(bo.begin() + b + 1, bo.end(), limit);
+            return std::max<int64_t>(b + 1, (int64_t)(it - bo.begin()) - 1);
+        };
+        int64_t b = 0;
+        int s = 0;
+        int64_t e = nb > 0 ? piece_end(0) : 0;
+        if (nb > 0) FF_HIP(hipMemcpyAsync(buf.slot[s], buf.d_text[tb] + bo[0], (size_t)(bo[(size_t)e] - bo[0]), hipMemcpyDeviceToHost, buf.copy));
+        while (b < nb) {
+            FF_HIP(hipStreamSynchronize(buf.copy));
+            const size_t len = (size_t)(bo[(size_t)e] - bo[(size_t)b]);
+            const int64_t b2 = e, e2 = b2 < nb ? piece_end(b2) : b2;
+            if (b2 < nb)
+                FF_HIP(hipMemcpyAsync(buf.slot[s ^ 1], buf.d_text[tb] + bo[(size_t)b2], (size_t)(bo[(size_t)e2] - bo[(size_t)b2]),
+                                      hipMemcpyDeviceToHost, buf.copy));
+            if (len > 0 && !fn(user, buf.slot[s], len)) {
+                *go_on = false;
+                FF_HIP(hipStreamSynchronize(buf.copy));  // (the copy in flight targets a slot that dies with this call)
+                return FF_OK;
+            }
+            b = b2;
+            e = e2;
+            s ^= 1;
+        }
+        return FF_OK;
+    };
+    rc = produce(0);
+    if (rc) return rc;
+    for (int64_t k = 0; k < c; ++k) {
+        const int cur = (int)(k & 1);
+        if (k + 1 < c) {
+            // sub-shard k + 1 is reduced and formatted while sub-shard k's text is handed over: launched here, waited
+            // for inside produce() only at its last step
+            rc = ff_plan_set_shard(pl, (int32_t)(base.rank * c + k + 1), (int32_t)(base.world * c), err, errlen);
+            if (rc) return rc;
+        }
+        // (set_shard synchronises the device: sub-shard k's text is complete.)  Sub-shard k + 1's pair kernels are
+        // enqueued BEFORE the hand-over -- plan_run_impl is asynchronous -- and waited for after it.
+        int rc_next = FF_OK;
+        bool go_on = true;
+        if (k + 1 < c) {
+            const int64_t n = pl->info.slot_end - pl->info.slot_begin;
+            if (n > 0) {
+                rc_next = buf.reserve(cur ^ 1, n, err, errlen);
+                if (rc_next == FF_OK) rc_next = plan_run_impl(pl, nullptr, buf.d_out, false, err, errlen);
+            }
+            if (rc_next) return rc_next;
+        }
+        rc = deliver(cur, &go_on);
+        if (rc) return rc;
+        if (!go_on) {
+            FF_HIP(hipDeviceSynchronize());  // the sub-shard in flight is dropped, the rest never computed
+            return FF_OK;
+        }
+        if (k + 1 < c) {
+            // finish sub-shard k + 1: verdict, format, offsets (its pair kernels have been running meanwhile)
+            const int64_t n = pl->info.slot_end - pl->info.slot_begin;
+            off[cur ^ 1].assign(1, 0ull);
+            if (n > 0) {
+                bool ok = true;
+                if (plan_fixed32_verdict(pl, &ok, nullptr) == FF_OK && !ok) {
+                    const int32_t rk = pl->shard_rank, wd = pl->shard_world;
+                    ff_plan_destroy(pl);
+                    pl = nullptr;
+                    o2.precision = FF_PRECISION_EXACT64;
+                    o2.rank = rk;
+                    o2.world = wd;
+                    rc = ff_plan_create(p, &o2, &pl, err, errlen);
+                    if (rc == FF_OK) rc = plan_run_impl(pl, nullptr, buf.d_out, false, err, errlen);
+                    if (rc) return rc;
+                }
+                rc = launch_format(buf.d_out, n, buf.d_text[cur ^ 1], buf.d_block_bytes, buf.d_block_off, nullptr, err, errlen);
+                if (rc) return rc;
+                const int64_t nb = fmt_blocks(n);
+                off[cur ^ 1].resize((size_t)nb + 1);
+                FF_HIP(hipMemcpy(off[cur ^ 1].data(), buf.d_block_off, sizeof(unsigned long long) * (size_t)(nb + 1), hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    return FF_OK;
+}
+
+int ff_unifrac_text_stream_csr(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                               const int32_t *branch_id, const double *abnd, const ff_options *o, int64_t max_pairs_per_chunk,
+                               ff_text_fn fn, void *user, char *err, size_t errlen)
+{
+    ff_problem p;
+    p.n_samples = n_samples;
+    p.n_branches = n_branches;
+    p.branch_len = branch_len;
+    p.indptr = indptr;
+    p.branch_id = branch_id;
+    p.abnd = abnd;
+    return ff_unifrac_text_stream(&p, o, max_pairs_per_chunk, fn, user, err, errlen);
+}
+
 }  // extern "C"
 
 // ---- the pipeline -----------------------------------------------------------------------------------

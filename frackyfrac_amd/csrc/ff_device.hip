@@ -26,9 +26,10 @@ int set_shard_geometry(ff_plan *pl, int32_t rank, int32_t world, char *err, size
 }  // namespace dev
 }  // namespace ff
 
-namespace {
+namespace ff {
+namespace dev {
 
-int validate_problem(const ff_problem *p, char *err, size_t errlen, bool unsorted_ok = false)
+int validate_problem(const ff_problem *p, char *err, size_t errlen, bool unsorted_ok)
 {
     if (!p) return ff::fail(FF_ERR_ARG, err, errlen, "null problem");
     if (p->n_samples < 0 || p->n_branches < 0 || p->n_branches > (int64_t)INT32_MAX - 64)
@@ -76,6 +77,11 @@ int validate_problem(const ff_problem *p, char *err, size_t errlen, bool unsorte
     }
     return FF_OK;
 }
+
+}  // namespace dev
+}  // namespace ff
+
+namespace {
 
 void plan_free_device(ff_plan *pl)
 {

@@ -223,6 +223,8 @@ struct Quant {
 };
 
 // ---- ff_device.hip
+// The caller's arrays are what an ff_problem promises (sizes, ascending ids unless unsorted_ok, positive abundances).
+int validate_problem(const ff_problem *p, char *err, size_t errlen, bool unsorted_ok = false);
 // Picks the device (it must be a gfx950) and fills the shard geometry.
 int set_shard_geometry(ff_plan *pl, int32_t rank, int32_t world, char *err, size_t errlen);
 

@@ -458,6 +458,21 @@ size_t ff_text_bound(int64_t n);
 int ff_format_distances_device(const double *d_values, int64_t n, char *d_text, size_t *n_bytes, void *stream,
                                char *err, size_t errlen);
 
+/* unifracDists AND the loop that prints it (frcfrc/unifrac.go:209-228 + frcfrc/frcfrc.go:58-62) as one lazy ordered
+ * sequence of TEXT: the lines `for f := range dists { fmt.Fprintln(w, f) }` would write, formatted on the device,
+ * handed to `fn` in pieces of whole lines (<= 32 MB each), in order, on the calling thread; fn returns 0 to stop --
+ * nothing further is computed.  What a host whose own formatter is the bottleneck calls instead of
+ * ff_unifrac_dists_stream (the reference's Fprintln loop is 5 s of a C4-sized run on one goroutine; this is 0.3):
+ * the callback's body is `w.Write(text[:n])`.  Same sub-shards, same FIXED32 -> EXACT64 repeat, same laziness as
+ * ff_unifrac_dists_stream; max_pairs_per_chunk bounds device memory (33 bytes per pair of a sub-shard), not the
+ * pieces.  The _csr form takes the problem's fields as separate arguments (cgo's pointer rule). */
+typedef int (*ff_text_fn)(void *user, const char *text, size_t n_bytes);
+int ff_unifrac_text_stream(const ff_problem *problem, const ff_options *options, int64_t max_pairs_per_chunk,
+                           ff_text_fn fn, void *user, char *err, size_t errlen);
+int ff_unifrac_text_stream_csr(int64_t n_samples, int64_t n_branches, const double *branch_len, const int64_t *indptr,
+                               const int32_t *branch_id, const double *abnd, const ff_options *options,
+                               int64_t max_pairs_per_chunk, ff_text_fn fn, void *user, char *err, size_t errlen);
+
 /* Whole `frcfrc` command (frcfrc/frcfrc.go:29-67): argv as the reference's flags
  * -i -o -t -w -s -p -l.  Returns the process exit code (0, or 2 after printing
  * "ERROR: ..." to stderr). */

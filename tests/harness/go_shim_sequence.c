@@ -4,6 +4,10 @@
  *     ff_options_default -> ff_unifrac_dists_stream_csr(n, B, treeDists, indptr, ids, abnd, &o, chunk,
  *                                                       deliver, &handle, err, errlen)
  *     with a callback that consumes the distances one by one and returns 0 when its consumer stops.
+ *   text (the shim's unifracTextGPU: the distances as the lines the reference prints, formatted on the device):
+ *     ff_options_default -> ff_unifrac_text_stream_csr(n, B, treeDists, indptr, ids, abnd, &o, chunk,
+ *                                                      write_text, &handle, err, errlen)
+ *     with a callback that writes every piece to stdout and returns 0 once its writer has taken `stop after` pieces.
  *   plan (a host that keeps the staged plan):
  *     ff_options_default -> ff_plan_create_csr -> { ff_plan_set_shard -> ff_plan_info_get ->
  *     ff_plan_run_host [-> on FF_ERR_PRECISION: destroy, create EXACT64, set_shard, run_host] }
@@ -14,7 +18,7 @@
  * from ff_flatten on a tree and a table file so that the test can run it on the reference's golden files.
  * Prints the distances like fmt.Fprintln(w, f); with a stop count, the consumer "breaks" after that many.
  *
- *   go_shim_sequence <stream|plan> <tree> <table> <dense|sparse> <weighted 0|1> [chunk pairs | shards] [stop after]
+ *   go_shim_sequence <stream|text|plan> <tree> <table> <dense|sparse> <weighted 0|1> [chunk pairs | shards] [stop after]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,9 +56,33 @@ static int deliver(void *user, int64_t slot_begin, const double *dists, int64_t 
     return 1;
 }
 
+typedef struct text_sink { /* the shim's gpuText: an io.Writer that fails after stop_after writes */
+    int64_t pieces, bytes, lines, stop_after, calls_after_stop;
+    int stopped;
+} text_sink;
+
+static int write_text(void *user, const char *text, size_t n) /* ffWriteText */
+{
+    text_sink *t = *(text_sink **)user;
+    if (t->stopped) {
+        ++t->calls_after_stop;
+        return 0;
+    }
+    if (t->stop_after >= 0 && t->pieces >= t->stop_after) { /* w.Write returned an error */
+        t->stopped = 1;
+        return 0;
+    }
+    if (n == 0 || text[n - 1] != '\n') DIE("a piece of %zu bytes does not end with a newline", n);
+    if (fwrite(text, 1, n, stdout) != n) DIE("write to stdout failed");
+    for (size_t k = 0; k < n; ++k) t->lines += text[k] == '\n';
+    ++t->pieces;
+    t->bytes += (int64_t)n;
+    return 1;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 6) DIE("usage: go_shim_sequence <stream|plan> <tree> <table> <dense|sparse> <weighted> [chunk|shards] [stop after]");
+    if (argc < 6) DIE("usage: go_shim_sequence <stream|text|plan> <tree> <table> <dense|sparse> <weighted> [chunk|shards] [stop after]");
     const int stream = strcmp(argv[1], "stream") == 0;
     char err[1024];
     ff_tree *tree = NULL;
@@ -73,7 +101,19 @@ int main(int argc, char **argv)
     if (getenv("FF_SHIM_PRECISION")) o.precision = atoi(getenv("FF_SHIM_PRECISION"));
     const int64_t total = ff_num_pairs(p.n_samples);
     int64_t printed = 0;
-    if (stream) {
+    if (strcmp(argv[1], "text") == 0) {
+        text_sink t = {0, 0, 0, argc > 7 ? atoll(argv[7]) : -1, 0, 0};
+        text_sink *handle = &t;
+        const int rc = ff_unifrac_text_stream_csr(p.n_samples, p.n_branches, p.branch_len, p.indptr, p.branch_id, p.abnd, &o,
+                                                  argc > 6 ? atoll(argv[6]) : 0, write_text, &handle, err, sizeof err);
+        if (rc) DIE("%s", err);
+        if (t.calls_after_stop) DIE("%lld calls after the writer stopped", (long long)t.calls_after_stop);
+        printed = t.lines;
+        if (t.stopped) {
+            fprintf(stderr, "stopped after %lld pieces, %lld lines of %lld\n", (long long)t.pieces, (long long)t.lines, (long long)total);
+            printed = total;
+        }
+    } else if (stream) {
         consumer c = {0, 0, argc > 7 ? atoll(argv[7]) : -1, 0, 0, 0};
         consumer *handle = &c;
         const int rc = ff_unifrac_dists_stream_csr(p.n_samples, p.n_branches, p.branch_len, p.indptr, p.branch_id, p.abnd, &o,

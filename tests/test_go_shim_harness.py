@@ -48,7 +48,7 @@ def c_calls(code):
     """[(name, [args])] of every C.ff_*(...) call (C.ff_dists_fn(...) is a conversion to a function pointer type)."""
     out = []
     for m in re.finditer(r"C\.(ff_[a-z0-9_]+)\(", code):
-        if m.group(1) == "ff_dists_fn":
+        if m.group(1) in ("ff_dists_fn", "ff_text_fn"):
             continue
         depth, k = 1, m.end()
         while depth:
@@ -134,12 +134,13 @@ def test_the_go_file_makes_the_calls_the_harness_makes():
     c = open(os.path.join(ROOT, "tests", "harness", "go_shim_sequence.c")).read()
     go_calls = {name for name, _ in c_calls(go_code())}
     harness_calls = set(re.findall(r"\b(ff_[a-z0-9_]+)\(", c))
-    assert go_calls == {"ff_options_default", "ff_unifrac_dists_stream_csr"}
+    assert go_calls == {"ff_options_default", "ff_unifrac_dists_stream_csr", "ff_unifrac_text_stream_csr"}
     assert go_calls <= harness_calls
     # same number of arguments, in the header's order
-    (args,) = [a for n, a in c_calls(go_code()) if n == "ff_unifrac_dists_stream_csr"]
-    assert len(args) == 12
-    assert len(open(GO_FILE).read().splitlines()) <= 120
+    for entry in ("ff_unifrac_dists_stream_csr", "ff_unifrac_text_stream_csr"):
+        (args,) = [a for n, a in c_calls(go_code()) if n == entry]
+        assert len(args) == 12
+    assert len(open(GO_FILE).read().splitlines()) <= 200
 
 
 def test_harness_builds_against_the_header_alone_and_fails_loudly_without_a_gpu(harness):
@@ -147,7 +148,7 @@ def test_harness_builds_against_the_header_alone_and_fails_loudly_without_a_gpu(
 
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the GPU tests below run the sequence for real")
-    for mode in ("stream", "plan"):
+    for mode in ("stream", "text", "plan"):
         r = subprocess.run([harness, mode, GOLDEN + "/wtd.tree", GOLDEN + "/wtd.dense", "dense", "1"], capture_output=True, text=True)
         assert r.returncode == 2 and r.stdout == ""
         assert r.stderr.startswith("ERROR: no HIP device available") and "no CPU path" in r.stderr
@@ -156,7 +157,8 @@ def test_harness_builds_against_the_header_alone_and_fails_loudly_without_a_gpu(
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,weighted", [("uwtd1", 0), ("uwtd2", 0), ("wtd", 1)])
 @pytest.mark.parametrize("kind", ["dense", "sparse"])
-@pytest.mark.parametrize("mode,cut", [("stream", None), ("stream", 1), ("stream", 2), ("plan", None), ("plan", 3)])
+@pytest.mark.parametrize("mode,cut", [("stream", None), ("stream", 1), ("stream", 2), ("text", None), ("text", 1), ("text", 2),
+                                      ("plan", None), ("plan", 3)])
 def test_shim_sequence_reproduces_the_reference_goldens(harness, name, weighted, kind, mode, cut):
     """cut: pairs per piece (stream) / number of shards (plan)."""
     args = [harness, mode, GOLDEN + "/" + name + ".tree", GOLDEN + "/" + name + "." + kind, kind, str(weighted)]
@@ -217,3 +219,33 @@ def test_shim_sequence_stops_when_the_consumer_stops(harness, tmp_path):
     assert np.array_equal(np.array([float(x) for x in full.stdout.split()]), want)
     m = re.search(r"stopped after 777 of 19900 distances, (\d+) pieces delivered", part.stderr)
     assert m and int(m.group(1)) == 1
+
+
+@pytest.mark.gpu
+def test_text_sequence_on_a_synthetic_table_in_pieces_after_a_precision_fallback_and_with_a_writer_that_fails(harness, tmp_path):
+    """The shim's unifracTextGPU: the bytes `for f := range dists { fmt.Fprintln(w, f) }` would write, for every
+    precision and sub-shard size; FIXED32 on a table of replicates repeats in EXACT64 inside the call; a writer that
+    fails after two pieces ends the computation (frcfrc.go:60 `break`)."""
+    from oracle import oracle as O
+
+    want = _replicate_table(tmp_path)
+    args = [harness, "text", str(tmp_path / "t.tree"), str(tmp_path / "t.sparse"), "sparse", "1"]
+    exact = subprocess.run(args + ["0"], capture_output=True, text=True, env=dict(os.environ, FF_SHIM_PRECISION="2"))
+    assert exact.returncode == 0, exact.stderr
+    assert exact.stdout == O.format_output(want)
+    for env_prec, cut in ((None, "4000"), ("1", "5000"), ("2", "777")):
+        env = dict(os.environ)
+        if env_prec:
+            env["FF_SHIM_PRECISION"] = env_prec
+        r = subprocess.run(args + [cut], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        if env_prec == "2":
+            assert r.stdout == exact.stdout
+        got = np.array([float(x) for x in r.stdout.split()])
+        zero = want == 0
+        assert got.shape == want.shape and np.all(got[zero] == 0)
+        assert np.max(np.abs(got[~zero] - want[~zero]) / want[~zero]) <= 1e-6
+    part = subprocess.run(args + ["1000", "2"], capture_output=True, text=True, env=dict(os.environ, FF_SHIM_PRECISION="2"))
+    assert part.returncode == 0, part.stderr
+    m = re.search(r"stopped after 2 pieces, (\d+) lines of 19900", part.stderr)
+    assert m and 0 < int(m.group(1)) < 19900 and exact.stdout.startswith(part.stdout) and part.stdout.endswith("\n")

@@ -131,3 +131,74 @@ def test_flat_argument_entry_points_equal_the_struct_ones(weighted):
     plan = ff.Plan(None, weighted, _handle=h)
     assert np.array_equal(plan.run_host(), want)
     plan.close()
+
+
+# ---- the same sequence as TEXT: unifracDists + the loop that prints it (frcfrc.go:58-62), ff_unifrac_text_stream ----
+
+def text_of(nodes, weighted, **kw):
+    pieces = []
+    n = api.unifrac_text_stream(nodes, weighted, pieces.append, **kw)
+    assert n == sum(len(p) for p in pieces) and all(p.endswith(b"\n") for p in pieces)
+    return b"".join(pieces).decode(), pieces
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("precision", ["exact64", "fixed32"])
+@pytest.mark.parametrize("flat_args", [False, True])
+def test_text_stream_is_what_the_printing_loop_writes(weighted, precision, flat_args):
+    nodes, ip, on, ft = problem(333, 900, 0.1, 41)
+    whole = ff.unifrac_dists(nodes, weighted, precision=precision)
+    for chunk in (0, 20000, 777):
+        text, _ = text_of(nodes, weighted, precision=precision, max_pairs_per_chunk=chunk, flat_args=flat_args)
+        assert text == O.format_output(whole)      # the one-pass entry's doubles, printed as fmt.Fprintln prints them
+    if precision == "exact64" or not weighted:
+        assert text == O.format_output(O.unifrac_dists(ip, on, ft.dist, weighted))
+
+
+def test_text_stream_of_one_shard_of_many_and_in_several_pieces_per_sub_shard():
+    """3,000 samples: 4.5 M lines, 87 MB of text -- sub-shards larger than a 32-MB slot, so a sub-shard reaches the
+    callback in several pieces; shards of a 3-way split tile the whole text."""
+    nodes, ip, on, ft = problem(3000, 400, 0.1, 8)
+    whole = O.format_output(ff.unifrac_dists(nodes, True, precision="exact64"))
+    text, pieces = text_of(nodes, True, precision="exact64")
+    assert text == whole and len(pieces) >= 3 and max(len(p) for p in pieces) <= 32 << 20
+    parts = [text_of(nodes, True, precision="exact64", rank=r, world=3, max_pairs_per_chunk=1 << 20)[0] for r in range(3)]
+    assert "".join(parts) == whole
+
+
+def test_text_stream_stops_when_the_writer_stops_and_is_lazy():
+    nodes, ip, on, ft = problem(700, 300, 0.2, 9)
+    whole = O.format_output(ff.unifrac_dists(nodes, False, precision="exact64"))
+    got = []
+
+    def writer(b):
+        got.append(b)
+        return len(got) < 3       # (w.Write fails on the third piece: frcfrc.go:60 `break`)
+
+    n = api.unifrac_text_stream(nodes, False, writer, precision="exact64", max_pairs_per_chunk=10000)
+    assert len(got) == 3 and n == sum(len(b) for b in got)
+    assert whole.startswith(b"".join(got).decode()) and len(b"".join(got)) < len(whole)
+    # a writer that raises: the exception reaches the caller, nothing further is computed
+    def bad(_b):
+        raise OSError("disk full")
+    with pytest.raises(OSError, match="disk full"):
+        api.unifrac_text_stream(nodes, False, bad, precision="exact64", max_pairs_per_chunk=10000)
+    # nothing to deliver: no callback, no error; a bad problem is an error before anything is staged
+    one = ff.FlatNodes(np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int32), np.array([1.0]), np.array([0.5]))
+    assert api.unifrac_text_stream(one, True, got.append) == 0
+    broken = ff.FlatNodes(nodes.indptr, nodes.branch_id[::-1].copy(), nodes.abnd, nodes.branch_len)
+    with pytest.raises(ff.FFError):
+        api.unifrac_text_stream(broken, True, got.append)
+
+
+def test_text_stream_repeats_a_failing_sub_shard_in_exact64():
+    """Replicated samples overflow FIXED32's refinement queue: the sub-shard in which that happens and all later ones
+    are computed in binary64, as ff_unifrac_dists_stream does."""
+    tree, ptr, idx, val = synth.make(1500, 300, 0.2, 77)
+    k = int(ptr[1])
+    ptr2 = np.concatenate([[0], np.cumsum([k] * 1500)]).astype(np.int64)       # 1,500 copies of one sample
+    idx2, val2 = np.tile(idx[:k], 1500), np.tile(val[:k], 1500)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr2, idx2, val2)
+    text, _ = text_of(nodes, True, precision="fixed32", max_pairs_per_chunk=300000)
+    assert text == "0\n" * (1500 * 1499 // 2)
