@@ -660,6 +660,27 @@ def main():
         e2e = time.perf_counter() - t0
         log("end-to-end through host buffers (H2D %d MB + stage + kernels + D2H %d MB): %.1f ms = %.3g pairs/s" %
             ((len(nodes.branch_id) * 12) >> 20, (P * 8) >> 20, e2e * 1e3, P / e2e))
+        # the same as TEXT (ff_unifrac_text_stream: what a host that prints the distances calls): + the formatter on the
+        # device, D2H of the text instead of the doubles; the callback only counts (a writer's time is not the engine's)
+        import ctypes
+        from frackyfrac_amd import _lib as L
+        from frackyfrac_amd.api import _opts
+        seen = [0]
+
+        def count(_user, _text, n):
+            seen[0] += int(n)
+            return 1
+
+        cb = L.TEXT_FN(count)
+        pr, op, eb = nodes.problem(), _opts(weighted, args.precision, ctx.local_rank), L.errbuf()
+        e2e_text = None
+        for _ in range(2):  # (second call: warm)
+            seen[0] = 0
+            t0 = time.perf_counter()
+            L.check(L.lib().ff_unifrac_text_stream(ctypes.byref(pr), ctypes.byref(op), 0, cb, None, eb, L.ERRLEN), eb)
+            e2e_text = time.perf_counter() - t0
+        e2e_text_bytes = seen[0]
+        log("the same as text (formatted on the device, %d MB down): %.1f ms" % (e2e_text_bytes >> 20, e2e_text * 1e3))
 
     out = None
     if rank == 0:
@@ -686,7 +707,10 @@ def main():
             out["end_to_end"] = {"host_buffers_ms": e2e * 1e3,
                                  "host_buffers_note": "ff_unifrac_dists on host arrays: H2D of the flat nodes (%d MB) + staging + "
                                                       "kernels + D2H of the distances (%d MB), second call in this process"
-                                                      % ((len(nodes.branch_id) * 12) >> 20, (ff.num_pairs(nodes.n_samples) * 8) >> 20)}
+                                                      % ((len(nodes.branch_id) * 12) >> 20, (ff.num_pairs(nodes.n_samples) * 8) >> 20),
+                                 "text_stream_ms": e2e_text * 1e3, "text_stream_bytes": e2e_text_bytes,
+                                 "text_stream_note": "ff_unifrac_text_stream on the same host arrays: + the formatter on the device, the "
+                                                     "distances come down as the lines the reference prints; the callback only counts"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, weighted, args.cpu_budget)
 

@@ -8,6 +8,10 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+#include <zlib.h>
+
+#include "ff_host.hpp"
 #include "frackyfrac_amd.h"
 
 static int fails = 0;
@@ -126,6 +130,60 @@ int main()
             v.push_back((double)(rnd() >> 11) * 0x1p-53);
         }
         CHECK(ff_write_distances("/dev/null", v.data(), (int64_t)v.size(), 3, err, sizeof err) == 0);
+    }
+    // the large-text reader (parallel preads into an unzeroed buffer) and the writer's text path (device-formatted
+    // text: plain parts by offset, gzip members, a non-seekable sink)
+    {
+        char path[] = "/tmp/ff_selftest_XXXXXX";
+        const int fd = mkstemp(path);
+        CHECK(fd >= 0);
+        std::string big;
+        while (big.size() < (size_t)40 << 20) {
+            char line[64];
+            big.append(line, (size_t)snprintf(line, sizeof line, "%.17g\n", (double)(rnd() >> 11) * 0x1p-53));
+        }
+        CHECK(write(fd, big.data(), big.size()) == (ssize_t)big.size());
+        close(fd);
+        for (unsigned nt : {1u, 2u, 3u}) {
+            ff::Text t;
+            CHECK(ff::read_text(path, nt, &t, err, sizeof err) == 0);
+            CHECK(t.size == big.size() && memcmp(t.data, big.data(), big.size()) == 0);
+        }
+        {
+            ff::Text t;
+            CHECK(ff::read_text("/nonexistent/file", 2, &t, err, sizeof err) == FF_ERR_IO && strlen(err) > 0);
+        }
+        for (int threads : {1, 4}) {
+            ff::DistWriter w;
+            CHECK(w.open(path, threads, err, sizeof err) == 0);
+            const size_t cut = big.size() / 3;
+            CHECK(w.write_text(big.data(), cut, err, sizeof err) == 0);
+            CHECK(w.write_text(big.data() + cut, big.size() - cut, err, sizeof err) == 0);
+            CHECK(w.write_text(big.data(), 0, err, sizeof err) == 0);
+            CHECK(w.close(err, sizeof err) == 0);
+            ff::Text t;
+            CHECK(ff::read_text(path, 2, &t, err, sizeof err) == 0);
+            CHECK(t.size == big.size() && memcmp(t.data, big.data(), big.size()) == 0);
+        }
+        {
+            std::string gz = std::string(path) + ".gz";
+            ff::DistWriter w;
+            CHECK(w.open(gz.c_str(), 3, err, sizeof err) == 0);
+            CHECK(w.write_text(big.data(), big.size() / 2, err, sizeof err) == 0);
+            CHECK(w.write_text(big.data() + big.size() / 2, big.size() - big.size() / 2, err, sizeof err) == 0);
+            CHECK(w.close(err, sizeof err) == 0);
+            std::string back;
+            CHECK(ff::read_all(gz.c_str(), &back, err, sizeof err) == 0);
+            CHECK(back == big);
+            unlink(gz.c_str());
+        }
+        {
+            ff::DistWriter w;
+            CHECK(w.open("/dev/null", 4, err, sizeof err) == 0);
+            CHECK(w.write_text(big.data(), big.size(), err, sizeof err) == 0);
+            CHECK(w.close(err, sizeof err) == 0);
+        }
+        unlink(path);
     }
     // shards and flag parsing paths that end before the device
     {

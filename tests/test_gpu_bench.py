@@ -99,7 +99,8 @@ def test_single_gpu_line_carries_the_secondary_entries():
     # end to end: host buffers, and the frcfrc executable on C3 and C4 as files -- default flags, -p 1,
     # -p <cores>: every run ends well, writes one line per pair, and the three outputs are the same bytes
     e2e = out["end_to_end"]
-    assert e2e["host_buffers_ms"] > 0
+    assert e2e["host_buffers_ms"] > 0 and e2e["text_stream_ms"] > 0
+    assert 15 * out["config"]["pairs"] < e2e["text_stream_bytes"] < 25 * out["config"]["pairs"]
     assert [e["workload"] for e in e2e["frcfrc"]] == ["C3", "C4"]
     for e in e2e["frcfrc"]:
         assert "error" not in e, e
