@@ -38,6 +38,7 @@ TextPipeline::TextPipeline(DistWriter *) : impl_(nullptr) {}
 TextPipeline::~TextPipeline() {}
 int TextPipeline::prepare(int64_t, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
 int TextPipeline::submit(int, const double *, int64_t, char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
+void TextPipeline::abandon() {}
 int TextPipeline::drain(char *err, size_t errlen) { return fail(FF_ERR_DEVICE, err, errlen, "device stub"); }
 }  // namespace ff
 

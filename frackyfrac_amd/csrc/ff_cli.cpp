@@ -390,6 +390,7 @@ extern "C" int ff_frcfrc_main(int argc, char **argv)
     ff_tree_free(tree);
     if (rc == 0) rc = writer.close(err, sizeof err);
     if (rc) return die(err);
+    if (getenv("FF_CLI_FAST_EXIT")) pipe.abandon();  // (set by the frcfrc executable, which ends right after this returns)
     lap(7);
     // Unweighted in fixed point is the reference bit for bit only when every branch length is a
     // multiple of 2^-scale; say so when it was not (the values are then within 1e-6, like weighted)

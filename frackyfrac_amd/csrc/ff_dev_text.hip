@@ -372,6 +372,7 @@ struct TextPipeline::Impl {
     std::thread copier, writer_thread;
     bool threads_started = false;
     double t_copy = 0, t_write = 0;  // seconds the copier spent copying, the writer writing (each on its own thread)
+    bool abandoned = false;
 
     void set_error(int code, const char *msg)
     {
@@ -525,6 +526,10 @@ TextPipeline::~TextPipeline()
     }
     m.cv.notify_all();
     if (m.writer_thread.joinable()) m.writer_thread.join();
+    if (m.abandoned) {
+        delete impl_;
+        return;
+    }
     int cur = -1;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     for (DeviceSide &sd : m.sides) {
@@ -541,6 +546,8 @@ TextPipeline::~TextPipeline()
     }
     delete impl_;
 }
+
+void TextPipeline::abandon() { impl_->abandoned = true; }
 
 int TextPipeline::prepare(int64_t expected_bytes, char *err, size_t errlen)
 {

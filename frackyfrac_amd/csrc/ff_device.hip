@@ -853,8 +853,19 @@ void ff::device_warmup(int want)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return;
     n = std::min(n, std::max(want, 1));
-    for (int d = 0; d < n; ++d)
-        if (hipSetDevice(d) == hipSuccess) (void)hipFree(nullptr);
+    for (int d = 0; d < n; ++d) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        // the context, and with one fill + one copy the device's queue and the runtime's own kernels: the first such
+        // call of a process pays for them (0.05-0.15 s), and this thread pays it while the inputs are read
+        void *p = nullptr;
+        unsigned word = 0;
+        if (hipMalloc(&p, 256) == hipSuccess) {
+            (void)hipMemset(p, 0, 256);
+            (void)hipMemcpy(&word, p, sizeof word, hipMemcpyDeviceToHost);
+            (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
     if (n > 0) (void)hipSetDevice(0);
 }
 

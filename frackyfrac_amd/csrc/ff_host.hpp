@@ -163,6 +163,9 @@ public:
     int submit(int device, const double *d_vals, int64_t n, char *err, size_t errlen);
     // Waits until everything submitted is in the file; the first error of the background threads.
     int drain(char *err, size_t errlen);
+    // The process is about to end: the destructor joins its threads but gives no memory back (unpinning the ring alone
+    // takes 30 ms that nobody is waiting for).
+    void abandon();
     double t_submit = 0;  // seconds the callers of submit() spent in it
     int64_t bytes = 0;    // text bytes produced so far
     double t_copy = 0, t_write = 0;  // after drain(): seconds the copier spent in device-to-host copies, the writer in the file
