@@ -296,6 +296,12 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
     if kernel == 0 and info.n_wave_slots == 12 * info.n_compute_units:
         kname = "pair_sad_kernel12"  # (the three-waves-per-SIMD variant the plan picks for whole triangles from ~3,300 samples)
     common = {"kernel": kname, "kernel_ms": kernel_ms, "launches": launches, "hbm": hbm}
+    if int(getattr(info, "rare_rows", 0)) > 0:
+        # the rows few samples reach are reduced by pair_low_kernel over the pairs that both have them; kernel_ms
+        # is both kernels' (one event pair around the two launches); the fraction stays priced on ALL 2*B lane-ops per pair,
+        # so the work that is skipped shows as a fraction that may pass 1
+        common["kernels"] = [kname, "pair_low_kernel"]
+        common["rare_rows"] = int(info.rare_rows)
     # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2, 7: VALU_PEAK_TLANEOPS / 2,
                 5: VALU_PEAK_TLANEOPS / 2}.get(kernel, VALU_PEAK_TLANEOPS) * 1e12
@@ -362,7 +368,7 @@ def under_a_profiler():
     return "rocprof" in pre or any(k.startswith("ROCPROF") for k in os.environ)
 
 
-def live_traffic(args, kernel, timeout_s=150.0):
+def live_traffic(args, kernel, timeout_s=150.0, kernels=None):
     """Fabric bytes per launch of `kernel` (the primary record's dominant kernel) measured ON THIS BOX, now:
     two child runs of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes, counters
     only besides the kernel trace that names the dispatches, the program directly behind `--` -- on the primary
@@ -402,14 +408,18 @@ def live_traffic(args, kernel, timeout_s=150.0):
             if r.returncode != 0:
                 return None, "the %s pass ended with code %d: %s" % (counter, r.returncode,
                                                                      r.stderr.decode(errors="replace").strip().splitlines()[-1:])
-            vals = []
+            per_kernel = {k: [] for k in (kernels or [kernel])}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for k in per_kernel:
+                        if k in row.get("Kernel_Name", ""):
+                            per_kernel[k].append(float(row["Counter_Value"]))
+            if not per_kernel[kernel]:
                 return None, "no %s rows for %s in the counter file" % (counter, kernel)
-            got[counter] = (sum(vals) / len(vals), len(vals))
+            # (per launch of the pass: the dominant kernel's average plus its companions')
+            got[counter] = (sum(sum(v) / len(v) for v in per_kernel.values() if v), len(per_kernel[kernel]))
     fetch, nf = got["FETCH_SIZE"]
     write, nw = got["WRITE_SIZE"]
     return {"traffic": (2.0 * fetch + write) * 1024.0,
@@ -797,7 +807,7 @@ def main():
             torch.cuda.empty_cache()
             t, why = None, None
             try:
-                t, why = live_traffic(args, out["roofline"]["kernel"])
+                t, why = live_traffic(args, out["roofline"]["kernel"], kernels=out["roofline"].get("kernels"))
             except Exception as e:  # (the line must come out whatever happens to the counter passes)
                 why = "%s: %s" % (type(e).__name__, e)
             if t:

@@ -30,6 +30,7 @@ using namespace ff::sched;
 #include "ff_kernels_finish.hpp"
 #include "ff_kernels_exact_unw.hpp"
 #include "ff_kernels_exact_w.hpp"
+#include "ff_kernels_low.hpp"
 
 }  // namespace
 
@@ -50,6 +51,19 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     free_and_null(pl->d_item_ptr);
     free_and_null(pl->d_num);
     free_and_null(pl->d_stamps);
+    free_and_null(pl->d_low_tiles);
+    free_and_null(pl->d_mlow);
+    pl->n_low_tiles = 0;
+    if (pl->split && n_slots > 0) {
+        // the blocks of pairs of pair_low_kernel that hold a row of the shard: sample blocks bi x bj <= bi
+        std::vector<LowTile> lt;
+        for (int64_t bi = inf.row_begin / pl->low_tile; bi * pl->low_tile < std::min(inf.row_end, N); ++bi)
+            for (int64_t bj = 0; bj <= bi; ++bj) lt.push_back({(int32_t)bi, (int32_t)bj});
+        pl->n_low_tiles = (int)lt.size();
+        FF_HIP(hipMalloc(&pl->d_low_tiles, sizeof(LowTile) * std::max<size_t>(lt.size(), 1)));
+        if (!lt.empty()) FF_HIP(hipMemcpy(pl->d_low_tiles, lt.data(), sizeof(LowTile) * lt.size(), hipMemcpyHostToDevice));
+        FF_ALLOC(pl->d_mlow, sizeof(uint32_t) * (size_t)n_slots, "the rare rows' sums");
+    }
     std::vector<Tile> tiles;
     build_tiles(N, inf.row_begin, inf.row_end, TILE_I, TILE_J, true, &tiles);
     inf.n_tiles = (int64_t)tiles.size();
@@ -532,6 +546,8 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
         fin.risk_list = pl->refine ? pl->d_risk_list : nullptr;
         fin.scale_log2 = inf.scale_log2;
         fin.weighted = pl->weighted;
+        fin.mlow = pl->split ? pl->d_mlow : nullptr;
+        fin.wl = pl->d_Wl;
         const bool fused = pl->mfma && pl->m_fused;  // (decided when the shard was scheduled: schedule_mfma)
         if (pl->refine) reset_counters_kernel<<<dim3(1), dim3(HEADROOM_SLOTS), 0, st>>>(pl->d_refine_count);
         if (!fused && (!pl->mfma || pl->m_any_atomic))
@@ -600,6 +616,12 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 <<<dim3((unsigned)pl->n_workgroups), dim3((unsigned)pl->waves_per_wg * 64), pl->lds_bytes, st>>>(
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, SYNC_TRIPS);
+        if (pl->split && pl->n_low_tiles > 0) {  // (inside the timed region: it is part of the pair reduction)
+            auto low = pl->low_tile == 128 ? pair_low_kernel<128> : pl->low_tile == 96 ? pair_low_kernel<96> : pair_low_kernel<64>;
+            low<<<dim3((unsigned)pl->n_low_tiles), dim3(LOW_THREADS), 0, st>>>(
+                pl->d_low_ptr, pl->d_low_sample, pl->d_low_q, pl->d_low_bits, pl->low_words, pl->low_rows + 1, pl->d_low_tiles,
+                inf.n_samples, inf.row_begin, inf.row_end, inf.slot_begin, pl->d_mlow);
+        }
         if (timed && !pl->mfma) FF_HIP(hipEventRecord(ev1, st));
         if (!fused) {
             const unsigned nb = (unsigned)std::min<int64_t>((n_slots + 256 * FINISH_RUN - 1) / (256 * FINISH_RUN), 1 << 22);

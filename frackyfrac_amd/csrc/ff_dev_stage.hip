@@ -556,11 +556,104 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
 {
     FF_STAGE_NAMES;
     const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
-    const int64_t rows = sad_staged_rows(R);
+    // Sparse tables -- and dense ones with many samples: the rows that few samples reach leave the matrix
+    // (ff_kernels_low.hpp).  A matrix row costs the dense kernel one lane-op per pair of the triangle:
+    // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  pair_low_kernel works in
+    // batches of 64 updates of an LDS accumulator, one batch at least per (bitmap word, tile) that has any: measured
+    // 1.26e-10 s per batch chip-wide (1.33e-10 at C4, 1.55e-10 at 8,192 samples, 2.3e-10 at C3 -- the same figure once the
+    // last, part-filled round of its 128 x 128 tiles on 2 workgroups per CU is counted: 17 / 5 / 2 rounds).  A rare row r
+    // with n_r flat nodes adds n_r^2 / 2 updates whatever the number of pairs, so a row is rare when that is cheaper than
+    // its matrix row -- n_r below about a tenth of the samples -- and the split is taken when the whole estimate saves 7 %
+    // or more (C3: estimated and measured a loss, left alone; C4 78.4 -> 69 ms; C5 96 -> 56; C5's tree at 1 % / 0.2 % leaf
+    // density 71.6 -> 16.0 / 27.5 -> 4.8: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
+    Scratch<int32_t> qt_row_of, low_of;   // branch id -> row of the matrix / rare row (-1: not there)
+    int64_t Rq = R, Rl = 0;
+    {
+        const int force = env_int("FF_SPARSE_SPLIT", -1);
+        if (weighted && force != 0 && N >= 2 * LOW_TILE_MAX && nnz > 0 && R > 32) {
+            Scratch<int32_t> cnt;
+            FF_HIP(cnt.alloc((size_t)R));
+            FF_HIP(hipMemset(cnt.p, 0, sizeof(int32_t) * (size_t)R));
+            row_counts_kernel<<<dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 16)), dim3(256)>>>(d_ids, nnz, row_of.p, cnt.p);
+            FF_HIP(hipGetLastError());
+            std::vector<int32_t> h_cnt((size_t)R);
+            FF_HIP(hipMemcpy(h_cnt.data(), cnt.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
+            const double P = (double)N * (double)(N - 1) / 2.0;
+            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10;
+            const double t_row = P / ROW_RATE;
+            // every side of the blocks of pairs is priced -- how full its last round of two workgroups per CU is against
+            // the (word, block) visits it makes -- and the cheapest estimate kept
+            const double slots = 2.0 * (double)std::max(1, prop.multiProcessorCount);  // blocks in flight
+            auto kernel_rows = [](double active_rows, double rows) { return active_rows <= 0.72 * rows ? active_rows / 0.77 : rows; };
+            // (the sparse-aware kernel is taken from 28 % inactive cells and walks a row at 0.77 of the dense rate)
+            double now_active = 0;
+            for (int64_t r = 0; r < R; ++r)
+                now_active += 1.0 - std::pow(1.0 - std::min(1.0, (double)h_cnt[(size_t)r] / (double)N), (double)TILE_I);  // P(a 32-sample block has it)
+            const double t_now = kernel_rows(now_active, (double)R) * t_row;
+            const int forced_tile = env_int("FF_LOW_TILE", 0);
+            double t_split = 0, rare_max = 0;
+            int tile = 0;
+            int64_t n_low = 0;
+            for (int cand : LOW_TILES) {
+                if (forced_tile && cand != forced_tile && (forced_tile == 128 || forced_tile == 96 || forced_tile == 64)) continue;
+                const double nbc = (double)((N + cand - 1) / cand), tc = nbc * (nbc + 1) / 2.0;
+                const double bc = BATCH_COST * std::ceil(tc / slots) * slots / tc;  // with the last round's idle slots
+                // (forced: every row up to the cap, whatever it is estimated to cost -- the tests' small problems)
+                const double rmax = force > 0 ? (double)N / LOW_SHARE_DIV : std::min((double)N / LOW_SHARE_DIV, std::sqrt(128.0 * t_row / bc));
+                double high_active = 0, updates = 0;
+                int64_t nl = 0;
+                for (int64_t r = 0; r < R; ++r) {
+                    const double n_r = (double)h_cnt[(size_t)r];
+                    if (n_r <= rmax) {
+                        ++nl;
+                        updates += n_r * n_r / 2.0;
+                    } else {
+                        high_active += 1.0 - std::pow(1.0 - std::min(1.0, n_r / (double)N), (double)TILE_I);
+                    }
+                }
+                const double t_low = (updates / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc;
+                const double t = kernel_rows(high_active, (double)(R - nl)) * t_row + t_low;
+                if (tile == 0 || t < t_split) {
+                    tile = cand;
+                    t_split = t;
+                    rare_max = rmax;
+                    n_low = nl;
+                }
+            }
+            const bool take = R - n_low >= 16 && n_low > 0 && (force > 0 || t_split <= 0.93 * t_now);
+            if (take) {
+                std::vector<int32_t> h_qt((size_t)B, -1), h_low((size_t)B, -1);
+                // The matrix rows keep the staged order.  The rare rows are numbered by DESCENDING sample count: a thread
+                // of pair_low_kernel walks the 64 rows of a bitmap word, the lanes of a wave neighbouring words, and a
+                // wave's loops run as long as its busiest lane's -- rows of like weight side by side keep the lanes in
+                // step (in branch order a wave ran 13 times the iterations its average lane needed).  Integer sums: any
+                // numbering gives the same M.
+                Rq = 0;
+                std::vector<int64_t> rare;
+                for (int64_t r = 0; r < R; ++r) {
+                    const int64_t b = branch_of_row.empty() ? r : branch_of_row[(size_t)r];
+                    if ((double)h_cnt[(size_t)r] <= rare_max) rare.push_back(r);  // (n_r = 0 cannot be: a staged row has a flat node)
+                    else h_qt[(size_t)b] = (int32_t)Rq++;
+                }
+                std::stable_sort(rare.begin(), rare.end(), [&](int64_t u, int64_t v) { return h_cnt[(size_t)u] > h_cnt[(size_t)v]; });
+                for (int64_t r : rare) h_low[(size_t)(branch_of_row.empty() ? r : branch_of_row[(size_t)r])] = (int32_t)Rl++;
+                FF_HIP(qt_row_of.alloc((size_t)B));
+                FF_HIP(low_of.alloc((size_t)B));
+                FF_HIP(hipMemcpy(qt_row_of.p, h_qt.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice));
+                FF_HIP(hipMemcpy(low_of.p, h_low.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice));
+                pl->split = true;
+                pl->low_tile = tile;
+                pl->low_rows = Rl;
+                inf.rare_rows = Rl;
+            }
+        }
+    }
+    const int32_t *stage_row_of = pl->split ? qt_row_of.p : row_of.p;
+    const int64_t rows = sad_staged_rows(Rq);
     inf.ld = ld;
     inf.rows_padded = rows;
     inf.lengths_exact = weighted ? 0 : q.lengths_exact;
-    const size_t qt_bytes = sizeof(uint32_t) * (size_t)sad_alloc_rows(R) * (size_t)ld;
+    const size_t qt_bytes = sizeof(uint32_t) * (size_t)sad_alloc_rows(Rq) * (size_t)ld;
     inf.staged_bytes = (double)qt_bytes;
     FF_ALLOC(pl->d_QT, qt_bytes, "the staged branch x sample matrix");
     FF_HIP(hipMalloc(&pl->d_W, sizeof(unsigned long long) * (size_t)ld));
@@ -570,18 +663,26 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
         if (B > 0) FF_HIP(hipMemcpy(klen.p, q.klen.data(), sizeof(uint32_t) * (size_t)B, hipMemcpyHostToDevice));
     }
     std::vector<unsigned long long> hW((size_t)ld);
+    const int nb = pl->split ? (int)((N + pl->low_tile - 1) / pl->low_tile) : 0;
+    if (pl->split) {
+        FF_HIP(hipMalloc(&pl->d_Wl, sizeof(uint32_t) * (size_t)ld));
+        FF_HIP(hipMemset(pl->d_Wl, 0, sizeof(uint32_t) * (size_t)ld));
+    }
     int e = q.e;
     for (int attempt = 0;; ++attempt) {
         FF_HIP(hipMemset(pl->d_QT, 0, qt_bytes));
         FF_HIP(hipMemset(pl->d_W, 0, sizeof(unsigned long long) * (size_t)ld));
         if (N > 0 && nnz > 0)
             stage_fixed32_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, klen.p,
-                                                                    weighted ? 1 : 0, e, row_of.p, pl->d_QT, ld);
+                                                                    weighted ? 1 : 0, e, stage_row_of, pl->d_QT, ld);
         if (rows > 0) {
             const int64_t rpb = std::max<int64_t>(64, round_up(rows, 256) / 256);
             dim3 grid((unsigned)(ld / 64), (unsigned)((rows + rpb - 1) / rpb));
             colsum_kernel<<<grid, dim3(64)>>>(pl->d_QT, ld, rows, rpb, pl->d_W);
         }
+        if (pl->split)  // the rare rows' share of every column sum: into Wl, and into W (every W_s must stay below 2^31)
+            low_sums_counts_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, e, low_of.p, Rl + 1, pl->low_tile, nullptr,
+                                                                      pl->d_Wl, pl->d_W);
         FF_HIP(hipGetLastError());
         FF_HIP(hipMemcpy(hW.data(), pl->d_W, sizeof(unsigned long long) * (size_t)ld, hipMemcpyDeviceToHost));
         unsigned long long wmax = 0;
@@ -593,6 +694,45 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     }
     klen.release();
     inf.scale_log2 = e;
+    if (pl->split) {
+        // the rare rows' entries grouped by sample block: counts -> positions -> (sample, value) pairs -> row bitmaps
+        pl->low_blocks = nb;
+        pl->low_words = (Rl + 63) / 64;
+        const int64_t rows1 = Rl + 1;
+        const size_t cells = (size_t)rows1 * (size_t)nb;
+        FF_ALLOC(pl->d_low_ptr, sizeof(uint32_t) * cells, "the rare rows' index");
+        FF_HIP(hipMemset(pl->d_low_ptr, 0, sizeof(uint32_t) * cells));
+        low_sums_counts_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, e, low_of.p, rows1, pl->low_tile, pl->d_low_ptr,
+                                                                  nullptr, nullptr);
+        Scratch<uint32_t> totals, cursor;
+        FF_HIP(totals.alloc((size_t)nb + 1));
+        FF_HIP(cursor.alloc(cells));
+        FF_HIP(hipMemset(cursor.p, 0, sizeof(uint32_t) * cells));
+        // per block: exclusive prefix over its rows1 positions (the last one becomes the block's total), then the
+        // blocks' bases
+        scan_segments_kernel<<<dim3((unsigned)nb), dim3(1024)>>>(pl->d_low_ptr, rows1, rows1, totals.p);
+        FF_HIP(hipGetLastError());
+        std::vector<uint32_t> h_tot((size_t)nb), h_base((size_t)nb + 1, 0u);
+        FF_HIP(hipMemcpy(h_tot.data(), totals.p, sizeof(uint32_t) * (size_t)nb, hipMemcpyDeviceToHost));
+        uint64_t run = 0;
+        for (int k = 0; k < nb; ++k) {
+            h_base[(size_t)k] = (uint32_t)run;
+            run += h_tot[(size_t)k];
+        }
+        if (run >= 0xFFFFFFF0ull) return ff::fail(FF_ERR_INTERNAL, err, errlen, "too many rare-row entries");
+        const uint32_t n_entries = (uint32_t)run;
+        FF_HIP(hipMemcpy(totals.p, h_base.data(), sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice));
+        low_add_base_kernel<<<dim3((unsigned)((cells + 255) / 256)), dim3(256)>>>(pl->d_low_ptr, rows1, nb, totals.p);
+        FF_ALLOC(pl->d_low_sample, sizeof(uint32_t) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
+        FF_ALLOC(pl->d_low_q, sizeof(uint32_t) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
+        low_fill_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, e, low_of.p, rows1, pl->low_tile, pl->d_low_ptr, cursor.p,
+                                                           pl->d_low_sample, pl->d_low_q);
+        FF_ALLOC(pl->d_low_bits, sizeof(unsigned long long) * (size_t)nb * (size_t)pl->low_words, "the rare rows' bitmaps");
+        low_bits_kernel<<<dim3((unsigned)pl->low_words, (unsigned)nb), dim3(64)>>>(pl->d_low_ptr, Rl, rows1, pl->low_words, pl->d_low_bits);
+        FF_HIP(hipGetLastError());
+        FF_HIP(hipDeviceSynchronize());  // (the scratch arrays go out of scope)
+        inf.staged_bytes += 4.0 * (double)cells + 8.0 * (double)n_entries + 8.0 * (double)nb * (double)pl->low_words;
+    }
     pl->n_workgroups = prop.multiProcessorCount;  // persistent: one workgroup per CU
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU
     // activity of every (i-block, branch row): decides between the dense and the

@@ -95,6 +95,13 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_arows);
     (void)hipFree(pl->d_aptr16);
     (void)hipFree(pl->d_cs16);
+    (void)hipFree(pl->d_low_ptr);
+    (void)hipFree(pl->d_low_sample);
+    (void)hipFree(pl->d_low_q);
+    (void)hipFree(pl->d_low_bits);
+    (void)hipFree(pl->d_Wl);
+    (void)hipFree(pl->d_mlow);
+    (void)hipFree(pl->d_low_tiles);
     (void)hipFree(pl->d_indptr);
     (void)hipFree(pl->d_ids);
     (void)hipFree(pl->d_abnd);

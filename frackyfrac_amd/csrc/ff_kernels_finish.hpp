@@ -25,6 +25,7 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         for (int e = 0; e < FINISH_RUN; ++e) {
             const int64_t te = t + 256 * e < n_slots ? t + 256 * e : n_slots - 1;
             u32[e] = num[te];
+            if (f.mlow) u32[e] -= 2u * f.mlow[te];  // (modulo 2^32: the sum below is the pair's U < 2^32)
         }
         for (int q = 1; q < n_planes; ++q) {
 #pragma unroll
@@ -35,7 +36,7 @@ void finish_fixed32_kernel(const uint32_t *__restrict__ num,
         }
 #pragma unroll
         for (int e = 0; e < FINISH_RUN; ++e, t += 256) {
-            if (t < n_slots) finish_pair(f, t, i, j, u32[e], h2min);
+            if (t < n_slots) finish_pair(f, t, i, j, f.mlow ? u32[e] + f.wl[i] + f.wl[j] : u32[e], h2min);
             j += 256;
             while (j >= i) {  // (rows are shorter than 256 only at the top of the triangle)
                 j -= i;

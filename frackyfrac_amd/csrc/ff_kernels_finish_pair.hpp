@@ -38,6 +38,8 @@ struct FinishArgs {
     unsigned long long refine_cap;
     unsigned long long *risk_list;  // local slots of the pairs just above the refinement rule's bound (null: none kept)
     int scale_log2, weighted;
+    // sparse tables (ff_kernels_low.hpp): the numerator is num + wl[i] + wl[j] - 2 mlow[t]; null: num alone
+    const uint32_t *mlow, *wl;
 };
 
 // Local slot t = pair (i, j), integer numerator u, w = W[i] + W[j] (the caller has loaded them).

@@ -1,0 +1,87 @@
+// ff_kernels_low.hpp -- the rare rows of a sparse table (FIXED32 weighted; ff_schedule.hpp LOW_*).
+// A fragment of ff_dev_run.hip: included there, once, inside its anonymous namespace.
+//
+// unifracDistWeighted adds l * |x - y| per branch (frcfrc/unifrac.go:191) -- in the staged integers |q_i - q_j| =
+// q_i + q_j - 2 min(q_i, q_j), and min(q_i, q_j) is zero unless BOTH samples have the branch.  For a row few samples
+// reach, that is the reference's own economy -- its merge walk only ever touches branches one of the two samples has --
+// made two-sided: U(i, j) = U_dense(i, j) + Wl_i + Wl_j - 2 M(i, j), with Wl_s the sample's sum over its rare rows and
+// M(i, j) = sum over the rare rows both have of min(q_i, q_j).  Same integers as one v_sad_u32 per term gives, so the
+// distances are the dense path's bit for bit (tests/test_gpu_parity.py::test_sparse_split_gives_the_same_integers).
+//
+// A workgroup owns a T x T block of pairs (T = LOW_TILE, one of ff_schedule.hpp's LOW_TILES, per plan) -- sample blocks bi (rows) and bj <= bi (columns) -- and keeps
+// its M in LDS.  The rare rows' entries are grouped by sample block, block-major (ptr[k][r] .. ptr[k][r + 1]: row r's
+// entries of block k, contiguous and ascending with r within the block); a bitmap per block says which rows have any.
+// A WAVE takes a word of bits[bi] & bits[bj] at a time: lane l looks up row 64 w + l -- its A entries of block bi, its
+// B entries of block bj, A x B updates -- the counts are scanned across the wave, and the wave then works through the
+// word's updates 64 at a time, every lane finding its (row, a, b) by a binary search over the scanned counts: whatever
+// the rows' weights, an instruction does 64 updates.  (A thread per word with nested loops over its rows' entries ran
+// as long as the busiest lane of every step: 16 ps per update, 63 ms at 1 % density for what this does in a tenth.)
+// Every slot of the tile is then written once (zeros included): no memset, no global atomics.
+template <int LOW_TILE>
+__global__ __launch_bounds__(LOW_THREADS)
+void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ ent_sample,
+                     const uint32_t *__restrict__ ent_q, const unsigned long long *__restrict__ bits, int64_t words,
+                     int64_t rows1, const LowTile *__restrict__ tiles, int64_t n_samples, int64_t row_begin, int64_t row_end,
+                     int64_t slot_begin, uint32_t *__restrict__ mlow)
+{
+    __shared__ uint32_t acc[LOW_TILE * LOW_TILE];  // 64 / 36 / 16 KiB
+    const LowTile tile = tiles[blockIdx.x];
+    const int bi = tile.bi, bj = tile.bj;
+    for (int q = threadIdx.x; q < LOW_TILE * LOW_TILE; q += LOW_THREADS) acc[q] = 0u;
+    __syncthreads();
+    const unsigned long long *wi = bits + (int64_t)bi * words, *wj = bits + (int64_t)bj * words;
+    const uint32_t *pi = ptr + (int64_t)bi * rows1, *pj = ptr + (int64_t)bj * rows1;
+    const uint32_t i_base = (uint32_t)bi * LOW_TILE, j_base = (uint32_t)bj * LOW_TILE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int64_t w = wave; w < words; w += LOW_THREADS / 64) {
+        const unsigned long long c = wi[w] & wj[w];  // (uniform: one word per wave)
+        if (c == 0) continue;
+        uint32_t a0 = 0, na = 0, b0 = 0, nbb = 0;
+        if ((c >> lane) & 1ull) {
+            const int64_t r = w * 64 + lane;
+            a0 = pi[r];
+            na = pi[r + 1] - a0;
+            b0 = pj[r];
+            nbb = pj[r + 1] - b0;
+        }
+        const uint32_t cnt = na * nbb;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t excl = incl - cnt;
+        for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            int L = 0;  // the lane whose row holds update k: the number of lanes with incl <= k
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const uint32_t v = __shfl(incl, L + step - 1, 64);
+                if (v <= k) L += step;
+            }
+            L = min(L, 63);  // (lanes past the word's last update)
+            const uint32_t local = k - __shfl(excl, L, 64);
+            const uint32_t ra0 = __shfl(a0, L, 64), rb0 = __shfl(b0, L, 64), rnb = __shfl(nbb, L, 64);
+            if (k < total) {
+                // local / rnb without the integer division's 25 instructions: the quotient is below 128 (a block holds at
+                // most LOW_TILE <= 128 entries of a row), (local + 0.5) / rnb lies at least 0.5 / 128 inside (q, q + 1), and the
+                // reciprocal and the product are off by less than 1e-4 of it
+                const uint32_t qa_i = (uint32_t)(((float)local + 0.5f) * __frcp_rn((float)rnb));
+                const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
+                const uint32_t sa = ent_sample[a], sb = ent_sample[b];
+                if (sb < sa)  // (a diagonal tile: each pair once; elsewhere always true)
+                    atomicAdd(&acc[(sa - i_base) * LOW_TILE + (sb - j_base)], min(ent_q[a], ent_q[b]));
+            }
+        }
+    }
+    __syncthreads();
+    // the tile's slots: row i = i_base + li holds columns j_base .. of slot i (i - 1) / 2 + j -- contiguous in j
+    for (int q = threadIdx.x; q < LOW_TILE * LOW_TILE; q += LOW_THREADS) {
+        const int64_t i = (int64_t)i_base + q / LOW_TILE, j = (int64_t)j_base + q % LOW_TILE;
+        if (i < row_begin || i >= row_end || i >= n_samples || j >= i) continue;
+        mlow[i * (i - 1) / 2 - slot_begin + j] = acc[q];
+    }
+}

@@ -4,6 +4,13 @@
 // (every kernel lives in exactly one translation unit, so the kernels stay internal and need no relocatable device code).
 
 
+// The staged value of one weighted flat node: floor(l_b x 2^e + u_b), u_b the branch's shared offset (ff_dither.hpp).
+__device__ __forceinline__ uint32_t stage_q_weighted(double len, double x_abnd, int e, int32_t b)
+{
+    const double x = len * x_abnd;  // treeDists[id] * abnd (unifrac.go:180)
+    return (uint32_t)(unsigned long long)floor(ldexp(x, e) + ff::branch_dither(b));
+}
+
 // Stage FIXED32: one workgroup per sample scatters its flat nodes into column s.
 // Weighted values are rounded with the branch's shared offset (ff_dither.hpp): q = floor(v + u_b).
 __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
@@ -18,14 +25,15 @@ __global__ void stage_fixed32_kernel(const int64_t *__restrict__ indptr,
     const int64_t b0 = indptr[s], b1 = indptr[s + 1];
     for (int64_t t = b0 + threadIdx.x; t < b1; t += blockDim.x) {
         const int32_t b = branch_id[t];
+        const int64_t row = row_of ? row_of[b] : b;
+        if (row < 0) continue;  // (a rare row of a sparse table: it lives in the lists of pair_low_kernel)
         uint32_t q;
         if (weighted) {
-            const double x = branch_len[b] * abnd[t];  // treeDists[id] * abnd (unifrac.go:180)
-            q = (uint32_t)(unsigned long long)floor(ldexp(x, e) + ff::branch_dither(b));
+            q = stage_q_weighted(branch_len[b], abnd[t], e, b);
         } else {
             q = klen[b];
         }
-        QT[(int64_t)(row_of ? row_of[b] : b) * ld + s] = q;
+        QT[row * ld + s] = q;
     }
 }
 
@@ -203,4 +211,117 @@ __global__ void stage_xbits_kernel(const int64_t *__restrict__ indptr, const int
         const int32_t b = branch_id[t], row = row_of ? row_of[b] : b;
         atomicOr(&Xb[(int64_t)(row / XU_SLAB) * ldx + s], 1u << (row % XU_SLAB));
     }
+}
+
+
+// ---- rare rows of a sparse table: lists by sample block for pair_low_kernel (ff_schedule.hpp LOW_*) ----------------
+// Layout: BLOCK-major.  ptr[block][r] .. ptr[block][r + 1] are the entries (sample, staged value) of rare row r among the
+// `tile` samples of the block (rows1 = rare rows + 1 positions per block); the entries of a block are contiguous and
+// ascend with the row, so a workgroup that joins two blocks streams two lists.  (Row-major -- ptr[r][block] -- was
+// built first: every row of every tile cost four cache lines for a few bytes, 75 GB of fabric traffic at 1 % density.)
+
+// Flat nodes per staged row.
+__global__ void row_counts_kernel(const int32_t *__restrict__ branch_id, int64_t nnz, const int32_t *__restrict__ row_of,
+                                  int32_t *__restrict__ counts)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&counts[row_of ? row_of[branch_id[t]] : branch_id[t]], 1);
+}
+
+// cnt == null: Wl[s] = sum of the staged values of sample s on its rare rows, and the same added into W[s] (which
+// holds the column sums of the dense part).  cnt != null: only cnt[block of s][r] += 1 for each of them.  One
+// workgroup per sample.
+__global__ __launch_bounds__(256)
+void low_sums_counts_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                            const double *__restrict__ abnd, const double *__restrict__ branch_len, int e,
+                            const int32_t *__restrict__ low_of, int64_t rows1, int tile, uint32_t *__restrict__ cnt,
+                            uint32_t *__restrict__ Wl, unsigned long long *__restrict__ W)
+{
+    __shared__ unsigned long long total;
+    const int64_t s = blockIdx.x;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
+        const int32_t b = branch_id[t], r = low_of[b];
+        if (r < 0) continue;
+        if (cnt) atomicAdd(&cnt[(s / tile) * rows1 + r], 1u);
+        else mine += stage_q_weighted(branch_len[b], abnd[t], e, b);
+    }
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && !cnt) {
+        Wl[s] = (uint32_t)total;  // (< 2^31 whenever the staging is accepted: the caller checks W)
+        W[s] += total;
+    }
+}
+
+// Segment blockIdx.x of `in` (n values at in + blockIdx.x * stride) -> its exclusive prefix sums in place, the
+// segment's total into totals[blockIdx.x].  One workgroup per segment.
+__global__ __launch_bounds__(1024)
+void scan_segments_kernel(uint32_t *__restrict__ data, int64_t n, int64_t stride, uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    uint32_t *seg = data + (int64_t)blockIdx.x * stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+        const int64_t k = b0 + threadIdx.x;
+        const uint32_t v = k < n ? seg[k] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (k < n) seg[k] = before + (inc - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// ptr[block][k] += base[block] (k <= rows: the last position of a block is its end = the next block's begin).
+__global__ void low_add_base_kernel(uint32_t *__restrict__ ptr, int64_t rows1, int n_blocks, const uint32_t *__restrict__ base)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows1 * n_blocks) return;
+    ptr[q] += base[q / rows1];
+}
+
+// The entries: (sample, staged value) of every rare flat node at ptr[block][r] + its turn (the order within a row's
+// block does not matter: integer sums).  cursor: zeroed, same shape as ptr.
+__global__ __launch_bounds__(256)
+void low_fill_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
+                     const double *__restrict__ abnd, const double *__restrict__ branch_len, int e,
+                     const int32_t *__restrict__ low_of, int64_t rows1, int tile, const uint32_t *__restrict__ ptr,
+                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ ent_sample, uint32_t *__restrict__ ent_q)
+{
+    const int64_t s = blockIdx.x;
+    for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
+        const int32_t b = branch_id[t], r = low_of[b];
+        if (r < 0) continue;
+        const int64_t cell = (s / tile) * rows1 + r;
+        const uint32_t at = ptr[cell] + atomicAdd(&cursor[cell], 1u);
+        ent_sample[at] = (uint32_t)s;
+        ent_q[at] = stage_q_weighted(branch_len[b], abnd[t], e, b);
+    }
+}
+
+// bits[block][w] bit t: rare row 64 w + t has an entry in the sample block.  One wave per (word, block).
+__global__ void low_bits_kernel(const uint32_t *__restrict__ ptr, int64_t n_rows, int64_t rows1, int64_t words,
+                                unsigned long long *__restrict__ bits)
+{
+    const int64_t w = blockIdx.x, blk = blockIdx.y, r = w * 64 + threadIdx.x;
+    bool any = false;
+    if (r < n_rows) any = ptr[blk * rows1 + r + 1] > ptr[blk * rows1 + r];
+    const unsigned long long mask = __ballot(any);
+    if (threadIdx.x == 0) bits[blk * words + w] = mask;
 }

@@ -51,6 +51,20 @@ struct ff_plan {
     uint32_t *d_arows = nullptr, *d_aptr16 = nullptr, *d_cs16 = nullptr;
     int64_t aptr_stride = 0;
     int32_t zero_row = 0;
+    // sparse tables: the rare rows live outside the staged matrix, as lists grouped by blocks of low_tile samples
+    bool split = false;
+    int low_tile = 0;                     // one of LOW_TILES
+    int64_t low_rows = 0;                 // rare rows
+    int low_blocks = 0;                   // sample blocks
+    int64_t low_words = 0;                // 64-bit words of a block's row bitmap
+    uint32_t *d_low_ptr = nullptr;        // [low_blocks][low_rows + 1]: where row r's entries of block k begin
+    uint32_t *d_low_sample = nullptr;     // entries: sample, staged value
+    uint32_t *d_low_q = nullptr;
+    unsigned long long *d_low_bits = nullptr;  // [low_blocks][low_words]: rows with an entry in the block
+    uint32_t *d_Wl = nullptr;             // [ld] column sums over the rare rows
+    uint32_t *d_mlow = nullptr;           // [slots of the shard] sum over the rare rows of min(q_i, q_j)
+    ff::sched::LowTile *d_low_tiles = nullptr;
+    int n_low_tiles = 0;
     // refinement of nearly-equal pairs: the flat nodes stay on the device
     bool refine = false;
     int64_t *d_indptr = nullptr;

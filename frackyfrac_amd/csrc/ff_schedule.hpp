@@ -47,6 +47,22 @@ inline int64_t sad_alloc_rows(int64_t R) { return sad_staged_rows(R) + SLACK_ROW
 constexpr int X_VALUES_PAD = 16;
 static_assert(X_VALUES_PAD >= X_TILE_HEIGHTS[sizeof(X_TILE_HEIGHTS) / sizeof(int) - 1] - 1, "EXACT64: padding behind the last row");
 
+// ---- rare rows of a sparse table (pair_low_kernel) ----
+// A staged row that few samples have a flat node on ("rare": at most N / LOW_SHARE_DIV of them, fewer where the cost
+// estimate of ff_dev_stage.hip says so) is kept out of the dense
+// matrix: its contribution sum |q_i - q_j| = q_i + q_j - 2 min(q_i, q_j) needs work only where BOTH samples have it.
+// The rows' entries are grouped by blocks of T samples; a workgroup owns a T x T block of pairs and sums min(q_i, q_j)
+// over the rows with entries in both of its sample blocks.  T is one of LOW_TILES, picked per plan: the blocks of pairs
+// are dealt to two workgroups per CU, and what decides is how full their last round is (C3, 4,096 samples: 528 blocks
+// of 128 x 128 on 512 slots are two rounds, the second all but empty; 946 of 96 x 96 fill 1.85).
+constexpr int LOW_TILES[] = {128, 96, 64};
+constexpr int LOW_TILE_MAX = 128;
+constexpr int LOW_THREADS = 1024;  // 16 waves on one tile's accumulators: the kernel lives on waves in flight (latency)
+constexpr int LOW_SHARE_DIV = 8;
+struct LowTile {
+    int32_t bi, bj;  // sample blocks: pairs (i, j) with i in block bi, j in block bj <= bi, j < i
+};
+
 struct Item {        // one unit of work for a persistent wave: a pair tile over a
     int32_t i0, j0;  // branch range [k0, k1)
     int32_t k0, k1;  // multiples of 2*KSTEP

@@ -223,6 +223,8 @@ typedef struct ff_plan_info {
     double active_fraction;    /* FIXED32 weighted: share of the shard's (32-sample block, staged row) cells in
                                   which some sample has the branch -- what pair_sad_sparse_kernel walks (it skips
                                   the rest) and what decides between it and the dense kernel; 1 where not counted */
+    int64_t rare_rows;         /* FIXED32 weighted on a sparse table: staged rows kept OUT of the matrix (few samples
+                                  reach them) and reduced by pair_low_kernel over the pairs that both have them; 0: none */
 } ff_plan_info;
 
 typedef enum ff_kernel {

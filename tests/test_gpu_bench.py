@@ -116,7 +116,13 @@ def test_single_gpu_line_carries_the_secondary_entries():
     assert sec[1]["roofline"]["kernel"] == "pair_common_mfma_kernel" and sec[2]["roofline"]["kernel"] == "pair_common_small_kernel"
     assert sec[3]["config"]["pairs"] == 16384 * 16383 // 2 and sec[4]["config"]["pairs"] == 8192 * 8191 // 2
     for e in sec:
-        assert e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < 1.0
+        # (where the rare rows are reduced by pair_low_kernel, work is skipped: the fraction of the full 2*B count may pass 1)
+        assert e["ms_per_step"] > 0 and 0 < e["roofline"]["frac"] < (40.0 if e["roofline"].get("rare_rows") else 1.0)
+    assert out["roofline"]["kernels"] == ["pair_sad_kernel12", "pair_low_kernel"] and out["roofline"]["rare_rows"] > 0
+    assert sec[3]["roofline"]["rare_rows"] > 0 and sec[4]["roofline"]["rare_rows"] > 0   # C4, C5
+    sp = out["sparse_regime"]
+    assert [e["roofline"]["kernels"][1] for e in sp] == ["pair_low_kernel"] * 2 and all(e["roofline"]["frac"] > 2 for e in sp)
+    assert all(e["cpu_baseline"]["value"] > 0 and e["gpu_over_cpu_all_cores"] > 100 for e in sp)
 
 
 def test_c2_pass_is_one_launch():

@@ -872,6 +872,7 @@ def test_sparse_aware_kernel(monkeypatch):
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=8)
     outs = {}
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "0")     # (the rare rows stay in the matrix: this test is about the list walk)
     for flag in ("1", "0"):
         monkeypatch.setenv("FF_SPARSE", flag)
         monkeypatch.setenv("FF_REFINE", "0")       # compare the raw kernels, not the refined pairs
@@ -894,6 +895,53 @@ def test_sparse_aware_kernel(monkeypatch):
     for r in range(3):
         ff.unifrac_dists(nodes2, True, precision="fixed32", rank=r, world=3, out=out)
     assert rel_err(out, want2) <= WEIGHTED_RTOL
+
+
+@pytest.mark.parametrize("ns,nl,dens", [(2100, 3000, 0.01), (700, 9000, 0.003), (333, 500, 0.05)])
+def test_sparse_split_gives_the_same_integers(monkeypatch, ns, nl, dens):
+    """The rows few samples reach out of the staged matrix (pair_low_kernel: sum of min(q_i, q_j) over the rows BOTH
+    samples have, U = U_dense + Wl_i + Wl_j - 2 M): the same integers as one v_sad_u32 per term, so the distances are
+    the unsplit path's bit for bit -- unrefined, refined, in shards, with sample counts LOW_TILE does not divide -- and
+    within tolerance of the oracle.  FF_SPARSE_SPLIT=1 forces the split, 0 forbids it."""
+    import torch
+    tree, ptr, idx, val = synth.make(ns, nl, dens, 17 + ns)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    outs, rare = {}, {}
+    monkeypatch.setenv("FF_REFINE", "0")       # compare the raw integers, not the refined pairs
+    for flag in ("1", "0", "128", "96", "64"):  # (the last three: the split with that side of the blocks of pairs forced)
+        monkeypatch.setenv("FF_SPARSE_SPLIT", "0" if flag == "0" else "1")
+        if len(flag) > 1:
+            monkeypatch.setenv("FF_LOW_TILE", flag)
+        plan = ff.Plan(nodes, True, precision="fixed32")
+        rare[flag] = int(plan.info.rare_rows)
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        outs[flag] = out.cpu().numpy()
+        if flag == "1":   # re-targeted at shards: the rare rows' tiles and sums follow the shard
+            parts = []
+            for r in range(3):
+                plan.set_shard(r, 3)
+                part = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+                plan.run(part.data_ptr())
+                torch.cuda.synchronize()
+                parts.append(part.cpu().numpy())
+            assert np.array_equal(np.concatenate(parts), outs["1"])
+        plan.close()
+    monkeypatch.delenv("FF_LOW_TILE")
+    assert rare["0"] == 0 and 0 < rare["1"] < nodes.n_branches
+    for flag in ("1", "128", "96", "64"):
+        assert np.array_equal(outs[flag], outs["0"]), flag
+    monkeypatch.delenv("FF_REFINE")
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "1")
+    got = ff.unifrac_dists(nodes, True, precision="fixed32")
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS)
+    assert rel_err(got, want) <= WEIGHTED_RTOL
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "0")
+    assert np.array_equal(ff.unifrac_dists(nodes, True, precision="fixed32"), got)
 
 
 # ---------------------------------------------------------------- stage A on the device
@@ -1074,11 +1122,14 @@ def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
         assert abs(got[slot] - o) <= WEIGHTED_RTOL * o
 
 
-def test_kernel_choice_per_rank_of_the_baseline_configs():
+def test_kernel_choice_per_rank_of_the_baseline_configs(monkeypatch):
     """Which weighted pair kernel every rank of a sharded run takes, as measured (tools/shard_balance.py,
     profiles/r04_shard_balance.txt): the 12-wave kernel for shards of several rounds -- C4 over 2 and 4 GPUs, C5 over
     2, 4 and 8, first rank or not --, the 8-wave kernel for C4 over 8 and for the weak problem's C3-sized shards
-    (except the first rank's triangle there).  DESIGN 4.1, ff_dev_run.hip schedule_sad and this test say the same."""
+    (except the first rank's triangle there).  DESIGN 4.1, ff_dev_run.hip schedule_sad and this test say the same.
+    (Measured with every row in the matrix, and asserted that way: with the rare rows out of it -- round 5 -- a shard
+    holds about half the (tile, row) units, and the same rule, which counts units, gives such shards the 8-wave kernel.)"""
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "0")
     def waves(nodes, rank, world, plan=None):
         p = ff.Plan(nodes, True, precision="fixed32", rank=rank, world=world) if plan is None else plan
         if plan is not None:

@@ -19,12 +19,14 @@ for set in "${sets[@]}"; do
 done
 KERN="$kern" OUT="$out" python3 - <<'PY' | tee "$out/summary.txt"
 import csv, glob, os
-kern, out = os.environ["KERN"], os.environ["OUT"]
+kerns, out = os.environ["KERN"].split("|"), os.environ["OUT"]   # "a|b": the per-launch averages of a and of b, added
 for f in sorted(glob.glob(out + "/pass_*/*/*counter_collection.csv")):
     acc = {}
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"]:
-            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        print("%-32s %16.1f   (avg of %d launches of *%s*)" % (k, sum(v) / len(v), len(v), kern))
+        for kern in kerns:
+            if kern in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], {}).setdefault(kern, []).append(float(r["Counter_Value"]))
+    for k, per in acc.items():
+        total = sum(sum(v) / len(v) for v in per.values())
+        print("%-32s %16.1f   (%s)" % (k, total, " + ".join("avg of %d launches of *%s*" % (len(v), kern) for kern, v in per.items())))
 PY

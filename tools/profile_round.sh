@@ -12,17 +12,17 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p "$out"
 declare -A ARGS KERN
 E2E="--no-end-to-end"   # (the bench's own child processes -- the frcfrc runs, the live counter passes -- stay out of a profile)
-ARGS[c3]="--no-cpu-baseline --no-secondary $E2E";                         KERN[c3]=pair_sad_kernel
+ARGS[c3]="--no-cpu-baseline --no-secondary $E2E";                         KERN[c3]="pair_sad_kernel|pair_low_kernel"
 ARGS[c3_unweighted]="--unweighted --no-cpu-baseline --no-secondary $E2E --steps 50"; KERN[c3_unweighted]=pair_common_mfma
 ARGS[c3_unweighted_lognormal]="--unweighted --lengths lognormal --no-cpu-baseline --no-secondary $E2E --steps 50"; KERN[c3_unweighted_lognormal]=pair_common_mfma
 ARGS[c3_unweighted_exact]="--unweighted --lengths lognormal --precision auto --no-cpu-baseline --no-secondary $E2E --steps 10"; KERN[c3_unweighted_exact]=pair_exact_unw
 ARGS[c3_exact64]="--precision exact64 --steps 5 --no-cpu-baseline --no-secondary $E2E"; KERN[c3_exact64]=pair_exact64
 ARGS[c2]="--workload C2 --unweighted --no-cpu-baseline --no-secondary $E2E --steps 50"; KERN[c2]=pair_common_small
-ARGS[c4]="--workload C4 --steps 5 --no-cpu-baseline --no-secondary $E2E";  KERN[c4]=pair_sad_kernel
-ARGS[c5]="--workload C5 --steps 5 --no-cpu-baseline --no-secondary $E2E";  KERN[c5]=pair_sad_kernel
+ARGS[c4]="--workload C4 --steps 5 --no-cpu-baseline --no-secondary $E2E";  KERN[c4]="pair_sad_kernel|pair_low_kernel"
+ARGS[c5]="--workload C5 --steps 5 --no-cpu-baseline --no-secondary $E2E";  KERN[c5]="pair_sad_kernel|pair_low_kernel"
 # the sparse regime (bench.py SPARSE_REGIME): C5's tree and sample count at 1 % and 0.2 % leaf density
-ARGS[c5s01]="--workload 8192x50000@0.01 --steps 5 --no-cpu-baseline --no-secondary $E2E";   KERN[c5s01]=pair_sad_sparse
-ARGS[c5s002]="--workload 8192x50000@0.002 --steps 5 --no-cpu-baseline --no-secondary $E2E"; KERN[c5s002]=pair_sad_sparse
+ARGS[c5s01]="--workload 8192x50000@0.01 --steps 5 --no-cpu-baseline --no-secondary $E2E";   KERN[c5s01]="pair_sad_kernel|pair_low_kernel"
+ARGS[c5s002]="--workload 8192x50000@0.002 --steps 5 --no-cpu-baseline --no-secondary $E2E"; KERN[c5s002]="pair_sad_kernel|pair_low_kernel"
 list=("$@"); [ ${#list[@]} -eq 0 ] && list=(c3 c3_unweighted c3_unweighted_lognormal c3_unweighted_exact c3_exact64 c2 c4 c5 c5s01 c5s002)
 cd /tmp && export TMPDIR=/tmp
 for w in "${list[@]}"; do
