@@ -564,8 +564,9 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     // last, part-filled round of its 128 x 128 tiles on 2 workgroups per CU is counted: 17 / 5 / 2 rounds).  A rare row r
     // with n_r flat nodes adds n_r^2 / 2 updates whatever the number of pairs, so a row is rare when that is cheaper than
     // its matrix row -- n_r below about a tenth of the samples -- and the split is taken when the whole estimate saves 7 %
-    // or more (C3: estimated and measured a loss, left alone; C4 78.4 -> 69 ms; C5 96 -> 56; C5's tree at 1 % / 0.2 % leaf
-    // density 71.6 -> 16.0 / 27.5 -> 4.8: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
+    // or more (measured, ms per pass without -> with: C3 5.07 -> 4.30, C4 78.4 -> 62.8, C5 96.0 -> 54.9, C5's tree at 1 % /
+    // 0.2 % leaf density 72.2 -> 15.3 / 27.5 -> 4.8; 3,000 samples of C3's tree: no gain, left alone:
+    // profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
     Scratch<int32_t> qt_row_of, low_of;   // branch id -> row of the matrix / rare row (-1: not there)
     int64_t Rq = R, Rl = 0;
     {
