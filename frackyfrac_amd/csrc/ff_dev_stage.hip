@@ -579,9 +579,12 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             FF_HIP(hipGetLastError());
             std::vector<int32_t> h_cnt((size_t)R);
             FF_HIP(hipMemcpy(h_cnt.data(), cnt.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
-            const double P = (double)N * (double)(N - 1) / 2.0;
+            // (priced for THIS plan's shard: its pairs, and its blocks of pairs -- a row shard of a multi-GPU run holds a
+            // G-th of the blocks, and how they fill their rounds decides the block side: C5 over 8 ranks, 260 blocks of
+            // 128 x 128 on 512 slots against 467 of 96 x 96)
+            const double P = (double)N * (double)(N - 1) / 2.0, Ps = std::max(1.0, (double)n_slots), share = Ps / P;
             constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10;
-            const double t_row = P / ROW_RATE;
+            const double t_row = Ps / ROW_RATE;
             // every side of the blocks of pairs is priced -- how full its last round of two workgroups per CU is against
             // the (word, block) visits it makes -- and the cheapest estimate kept
             const double slots = 2.0 * (double)std::max(1, prop.multiProcessorCount);  // blocks in flight
@@ -597,10 +600,12 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             int64_t n_low = 0;
             for (int cand : LOW_TILES) {
                 if (forced_tile && cand != forced_tile && (forced_tile == 128 || forced_tile == 96 || forced_tile == 64)) continue;
-                const double nbc = (double)((N + cand - 1) / cand), tc = nbc * (nbc + 1) / 2.0;
+                double tc = 0;  // the shard's blocks: sample blocks bi that hold one of its rows, times bj <= bi
+                for (int64_t bi = inf.row_begin / cand; bi * cand < std::min<int64_t>(inf.row_end, N); ++bi) tc += (double)(bi + 1);
+                tc = std::max(tc, 1.0);
                 const double bc = BATCH_COST * std::ceil(tc / slots) * slots / tc;  // with the last round's idle slots
                 // (forced: every row up to the cap, whatever it is estimated to cost -- the tests' small problems)
-                const double rmax = force > 0 ? (double)N / LOW_SHARE_DIV : std::min((double)N / LOW_SHARE_DIV, std::sqrt(128.0 * t_row / bc));
+                const double rmax = force > 0 ? (double)N / LOW_SHARE_DIV : std::min((double)N / LOW_SHARE_DIV, std::sqrt(128.0 * t_row / share / bc));
                 double high_active = 0, updates = 0;
                 int64_t nl = 0;
                 for (int64_t r = 0; r < R; ++r) {
@@ -612,7 +617,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                         high_active += 1.0 - std::pow(1.0 - std::min(1.0, n_r / (double)N), (double)TILE_I);
                     }
                 }
-                const double t_low = (updates / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc;
+                const double t_low = (updates * share / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc;
                 const double t = kernel_rows(high_active, (double)(R - nl)) * t_row + t_low;
                 if (tile == 0 || t < t_split) {
                     tile = cand;

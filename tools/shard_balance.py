@@ -29,10 +29,10 @@ for G in [int(a) for a in sys.argv[1:] if a not in skip] or [1, 2, 4, 8]:
     for pol in policies:
         L.lib().ff_tune(b"FF_WAVES_PER_WG", None if pol == "auto" else pol.encode())
         times, waves = [], []
-        plan = ff.Plan(nodes, True, precision="fixed32", rank=0, world=G)   # one staging; every further shard re-targets it
         for r in range(G):
-            if r:
-                plan.set_shard(r, G)
+            # a plan per rank, as the ranks of a real run make them: what is staged depends on the shard (the side of
+            # pair_low_kernel's blocks of pairs is chosen for the shard's own block count)
+            plan = ff.Plan(nodes, True, precision="fixed32", rank=r, world=G)
             out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
             for _ in range(2):
                 plan.run(out.data_ptr())
@@ -45,7 +45,7 @@ for G in [int(a) for a in sys.argv[1:] if a not in skip] or [1, 2, 4, 8]:
             times.append(ms / k)
             waves.append(int(plan.info.n_wave_slots // plan.info.n_compute_units))
             del out
-        plan.close()
+            plan.close()
         print("%s G=%d N=%d pairs=%d waves=%-4s | kernel ms per rank: %s | max %.3f mean %.3f max/mean %.3f | pairs/s if ranks ran "
               "in parallel: %.3e (%.3e per GPU)"
               % (strong or "weak", G, n, P, pol, " ".join("%.2f[%d]" % (t, w) for t, w in zip(times, waves)), max(times),
