@@ -302,6 +302,10 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         # so the work that is skipped shows as a fraction that may pass 1
         common["kernels"] = [kname, "pair_low_kernel"]
         common["rare_rows"] = int(info.rare_rows)
+        common["frac_note"] = ("priced on ALL 2*B lane-ops per pair (SURVEY 8d); %d of the %d staged rows are kept out of the matrix and "
+                               "reduced by pair_low_kernel over the pairs that both have them, so fewer lane-ops are issued than "
+                               "counted: the fraction may pass 1 (the matrix part alone runs at 0.87-0.89 of the peak on its own rows: "
+                               "profiles/r05_*_kernel_stats.csv)" % (int(info.rare_rows), int(info.n_rows)))
     # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2, 7: VALU_PEAK_TLANEOPS / 2,
                 5: VALU_PEAK_TLANEOPS / 2}.get(kernel, VALU_PEAK_TLANEOPS) * 1e12

@@ -59,7 +59,8 @@ def test_self_launch_runs_two_ranks_and_prints_one_line():
 def test_single_gpu_line_carries_the_secondary_entries():
     out, _ = run_bench("--steps", "3", "--warmup", "1", "--secondary-steps", "2", "--cpu-budget", "3")
     assert out["n_gpus"] == 1 and out["dtype"] == "u32" and out["config"]["workload"].startswith("C3:")
-    assert out["roofline"]["kernel"] == "pair_sad_kernel12" and 0.5 < out["roofline"]["frac"] < 1.0
+    # (half of C3's staged rows are reduced by pair_low_kernel: the fraction of the full 2*B count may pass 1)
+    assert out["roofline"]["kernel"] == "pair_sad_kernel12" and 0.5 < out["roofline"]["frac"] < 1.5 and "frac_note" in out["roofline"]
     a = out["audit"]
     assert a["uniform_sample"] == 4096 and a["pairs"] == 4096 + a["risk_pairs_checked"] and a["failed"] == 0
     assert a["min_headroom"] is None or a["min_headroom"] >= 1.0   # (everything under 1 is re-computed exactly)

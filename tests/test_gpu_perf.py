@@ -40,7 +40,7 @@ def test_round_4_figures_have_not_gone_backwards():
     pair_exact64_skip_kernel), the exact unweighted kernel (9.9-10.0 ms; 30 before it existed), C4 and C5 on one GPU."""
     out, _ = run_bench("--steps", "20", "--warmup", "3", "--secondary-steps", "3", "--no-cpu-baseline", "--no-live-traffic")
     sec = out["secondary"]
-    assert out["roofline"]["frac"] >= 0.80, out["roofline"]["frac"]
+    assert out["roofline"]["frac"] >= 0.90, out["roofline"]["frac"]   # (1.02 with the rare rows out of the matrix; 0.87 unsplit)
     assert out["reference_width"]["ms_per_step"] <= 25.0, out["reference_width"]["ms_per_step"]
     assert sec[6]["ms_per_step"] <= 12.0, sec[6]["ms_per_step"]
     assert sec[3]["roofline"]["frac"] >= 0.80 and sec[4]["roofline"]["frac"] >= 0.80
