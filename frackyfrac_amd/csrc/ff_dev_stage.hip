@@ -626,7 +626,9 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                     n_low = nl;
                 }
             }
-            const bool take = R - n_low >= 16 && n_low > 0 && (force > 0 || t_split <= 0.93 * t_now);
+            // (the index is (rare rows + 1) x sample blocks words, twice while it is built: not beyond 4 GB)
+            const bool fits = 8.0 * (double)(n_low + 1) * (double)((N + std::max(tile, 1) - 1) / std::max(tile, 1)) <= 4e9;
+            const bool take = R - n_low >= 16 && n_low > 0 && fits && (force > 0 || t_split <= 0.93 * t_now);
             if (take) {
                 std::vector<int32_t> h_qt((size_t)B, -1), h_low((size_t)B, -1);
                 // The matrix rows keep the staged order.  The rare rows are numbered by DESCENDING sample count: a thread
@@ -729,10 +731,9 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
         const uint32_t n_entries = (uint32_t)run;
         FF_HIP(hipMemcpy(totals.p, h_base.data(), sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice));
         low_add_base_kernel<<<dim3((unsigned)((cells + 255) / 256)), dim3(256)>>>(pl->d_low_ptr, rows1, nb, totals.p);
-        FF_ALLOC(pl->d_low_sample, sizeof(uint32_t) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
-        FF_ALLOC(pl->d_low_q, sizeof(uint32_t) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
+        FF_ALLOC(pl->d_low_ent, sizeof(uint2) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
         low_fill_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, e, low_of.p, rows1, pl->low_tile, pl->d_low_ptr, cursor.p,
-                                                           pl->d_low_sample, pl->d_low_q);
+                                                           pl->d_low_ent);
         FF_ALLOC(pl->d_low_bits, sizeof(unsigned long long) * (size_t)nb * (size_t)pl->low_words, "the rare rows' bitmaps");
         low_bits_kernel<<<dim3((unsigned)pl->low_words, (unsigned)nb), dim3(64)>>>(pl->d_low_ptr, Rl, rows1, pl->low_words, pl->d_low_bits);
         FF_HIP(hipGetLastError());

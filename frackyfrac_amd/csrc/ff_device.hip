@@ -96,8 +96,7 @@ void plan_free_device(ff_plan *pl)
     (void)hipFree(pl->d_aptr16);
     (void)hipFree(pl->d_cs16);
     (void)hipFree(pl->d_low_ptr);
-    (void)hipFree(pl->d_low_sample);
-    (void)hipFree(pl->d_low_q);
+    (void)hipFree(pl->d_low_ent);
     (void)hipFree(pl->d_low_bits);
     (void)hipFree(pl->d_Wl);
     (void)hipFree(pl->d_mlow);

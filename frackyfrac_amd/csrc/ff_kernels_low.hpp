@@ -22,8 +22,8 @@
 constexpr uint32_t LOW_ROWWISE_MIN = 64;
 template <int LOW_TILE>
 __global__ __launch_bounds__(LOW_THREADS)
-void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ ent_sample,
-                     const uint32_t *__restrict__ ent_q, const unsigned long long *__restrict__ bits, int64_t words,
+void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ entries,
+                     const unsigned long long *__restrict__ bits, int64_t words,
                      int64_t rows1, const LowTile *__restrict__ tiles, int64_t n_samples, int64_t row_begin, int64_t row_end,
                      int64_t slot_begin, uint32_t *__restrict__ mlow)
 {
@@ -35,6 +35,7 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restric
     const unsigned long long *wi = bits + (int64_t)bi * words, *wj = bits + (int64_t)bj * words;
     const uint32_t *pi = ptr + (int64_t)bi * rows1, *pj = ptr + (int64_t)bj * rows1;
     const uint32_t i_base = (uint32_t)bi * LOW_TILE, j_base = (uint32_t)bj * LOW_TILE;
+    const bool diagonal = bi == bj;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int64_t w = wave; w < words; w += LOW_THREADS / 64) {
@@ -71,8 +72,8 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restric
                 for (uint32_t local = (uint32_t)lane; local < rcnt; local += 64) {
                     const uint32_t qa_i = (uint32_t)(((float)local + 0.5f) * inv);  // local / rnb (see below)
                     const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
-                    const uint32_t sa = ent_sample[a], sb = ent_sample[b];
-                    if (sb < sa) atomicAdd(&acc[(sa - i_base) * LOW_TILE + (sb - j_base)], min(ent_q[a], ent_q[b]));
+                    const uint2 ea = entries[a], eb = entries[b];  // (x: the sample's index within its block, y: its value)
+                    if (!diagonal || eb.x < ea.x) atomicAdd(&acc[ea.x * LOW_TILE + eb.x], min(ea.y, eb.y));
                 }
             }
             continue;
@@ -94,9 +95,9 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restric
                 // reciprocal and the product are off by less than 1e-4 of it
                 const uint32_t qa_i = (uint32_t)(((float)local + 0.5f) * __frcp_rn((float)rnb));
                 const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
-                const uint32_t sa = ent_sample[a], sb = ent_sample[b];
-                if (sb < sa)  // (a diagonal tile: each pair once; elsewhere always true)
-                    atomicAdd(&acc[(sa - i_base) * LOW_TILE + (sb - j_base)], min(ent_q[a], ent_q[b]));
+                const uint2 ea = entries[a], eb = entries[b];
+                if (!diagonal || eb.x < ea.x)  // (a diagonal tile: each pair once)
+                    atomicAdd(&acc[ea.x * LOW_TILE + eb.x], min(ea.y, eb.y));
             }
         }
     }

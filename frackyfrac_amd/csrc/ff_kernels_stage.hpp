@@ -296,13 +296,14 @@ __global__ void low_add_base_kernel(uint32_t *__restrict__ ptr, int64_t rows1, i
     ptr[q] += base[q / rows1];
 }
 
-// The entries: (sample, staged value) of every rare flat node at ptr[block][r] + its turn (the order within a row's
-// block does not matter: integer sums).  cursor: zeroed, same shape as ptr.
+// The entries: (sample's index within its block, staged value) of every rare flat node -- 8 bytes, one load -- at
+// ptr[block][r] + its turn (the order within a row's block does not matter: integer sums).  cursor: zeroed, same shape
+// as ptr.
 __global__ __launch_bounds__(256)
 void low_fill_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ branch_id,
                      const double *__restrict__ abnd, const double *__restrict__ branch_len, int e,
                      const int32_t *__restrict__ low_of, int64_t rows1, int tile, const uint32_t *__restrict__ ptr,
-                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ ent_sample, uint32_t *__restrict__ ent_q)
+                     uint32_t *__restrict__ cursor, uint2 *__restrict__ entries)
 {
     const int64_t s = blockIdx.x;
     for (int64_t t = indptr[s] + threadIdx.x; t < indptr[s + 1]; t += blockDim.x) {
@@ -310,8 +311,7 @@ void low_fill_kernel(const int64_t *__restrict__ indptr, const int32_t *__restri
         if (r < 0) continue;
         const int64_t cell = (s / tile) * rows1 + r;
         const uint32_t at = ptr[cell] + atomicAdd(&cursor[cell], 1u);
-        ent_sample[at] = (uint32_t)s;
-        ent_q[at] = stage_q_weighted(branch_len[b], abnd[t], e, b);
+        entries[at] = uint2{(uint32_t)(s % tile), stage_q_weighted(branch_len[b], abnd[t], e, b)};
     }
 }
 

@@ -58,8 +58,7 @@ struct ff_plan {
     int low_blocks = 0;                   // sample blocks
     int64_t low_words = 0;                // 64-bit words of a block's row bitmap
     uint32_t *d_low_ptr = nullptr;        // [low_blocks][low_rows + 1]: where row r's entries of block k begin
-    uint32_t *d_low_sample = nullptr;     // entries: sample, staged value
-    uint32_t *d_low_q = nullptr;
+    uint2 *d_low_ent = nullptr;           // entries: (sample's index within its block, staged value)
     unsigned long long *d_low_bits = nullptr;  // [low_blocks][low_words]: rows with an entry in the block
     uint32_t *d_Wl = nullptr;             // [ld] column sums over the rare rows
     uint32_t *d_mlow = nullptr;           // [slots of the shard] sum over the rare rows of min(q_i, q_j)
