@@ -731,7 +731,8 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
         const uint32_t n_entries = (uint32_t)run;
         FF_HIP(hipMemcpy(totals.p, h_base.data(), sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice));
         low_add_base_kernel<<<dim3((unsigned)((cells + 255) / 256)), dim3(256)>>>(pl->d_low_ptr, rows1, nb, totals.p);
-        FF_ALLOC(pl->d_low_ent, sizeof(uint2) * std::max<size_t>(n_entries, 1), "the rare rows' entries");
+        FF_ALLOC(pl->d_low_ent, sizeof(uint2) * ((size_t)n_entries + 4), "the rare rows' entries");
+        FF_HIP(hipMemset(pl->d_low_ent + n_entries, 0, sizeof(uint2) * 4));  // (spare: pair_low_kernel loads four at a time, and adds the zeros)
         low_fill_kernel<<<dim3((unsigned)N), dim3(256)>>>(d_indptr, d_ids, d_abnd, d_len, e, low_of.p, rows1, pl->low_tile, pl->d_low_ptr, cursor.p,
                                                            pl->d_low_ent);
         FF_ALLOC(pl->d_low_bits, sizeof(unsigned long long) * (size_t)nb * (size_t)pl->low_words, "the rare rows' bitmaps");

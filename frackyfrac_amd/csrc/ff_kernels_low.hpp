@@ -19,18 +19,38 @@
 // Every slot of the tile is then written once (zeros included): no memset, no global atomics.
 // updates per row of a word from which its rows are taken one by one (swept 16 .. 96 at C3 / C4 / C5 / 1 % density:
 // 64 is the best or within 0.5 % of it everywhere; C3 4.77 -> 4.30 ms, C4 67.1 -> 62.8 against the batched way alone)
-constexpr uint32_t LOW_ROWWISE_MIN = 64;
+constexpr uint32_t LOW_ROWWISE_MIN = 32;
+struct __attribute__((aligned(8))) LowQuad { uint2 e[4]; };
+// One B entry (this lane's) against a row's A entries, four in flight at a time; past the row's end the loads bring other
+// rows' entries (or the array's spare ones, zeros) and the add is of zero: no branch in the step.  DIAGONAL: the block
+// of pairs lies on the diagonal, each pair once -- the other half adds zero (its cells are not written out anyway).
+template <bool DIAGONAL>
+__device__ __forceinline__ void low_walk_row(const uint2 *__restrict__ a, uint32_t rna, uint2 eb, char *col)
+{
+    for (uint32_t t = 0; t < rna; t += 4) {
+        const LowQuad e = *(const LowQuad *)(a + t);
+        const uint32_t left = rna - t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t v = min(e.e[u].y, eb.y);
+            if (u > 0) v = left > (uint32_t)u ? v : 0u;
+            if (DIAGONAL) v = eb.x < e.e[u].x ? v : 0u;
+            atomicAdd((uint32_t *)(col + e.e[u].x), v);
+        }
+    }
+}
+
 template <int LOW_TILE>
 __global__ __launch_bounds__(LOW_THREADS)
 void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ entries,
                      const unsigned long long *__restrict__ bits, int64_t words,
                      int64_t rows1, const LowTile *__restrict__ tiles, int64_t n_samples, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin, uint32_t *__restrict__ mlow)
+                     int64_t slot_begin, uint32_t *__restrict__ mlow, uint32_t rowwise_min)
 {
-    __shared__ uint32_t acc[LOW_TILE * LOW_TILE];  // 64 / 36 / 16 KiB
+    __shared__ uint32_t acc[LOW_TILE * LOW_STRIDE];  // 64 / 48 / 32 KiB: row li at li * LOW_STRIDE words
     const LowTile tile = tiles[blockIdx.x];
     const int bi = tile.bi, bj = tile.bj;
-    for (int q = threadIdx.x; q < LOW_TILE * LOW_TILE; q += LOW_THREADS) acc[q] = 0u;
+    for (int q = threadIdx.x; q < LOW_TILE * LOW_STRIDE; q += LOW_THREADS) acc[q] = 0u;
     __syncthreads();
     const unsigned long long *wi = bits + (int64_t)bi * words, *wj = bits + (int64_t)bj * words;
     const uint32_t *pi = ptr + (int64_t)bi * rows1, *pj = ptr + (int64_t)bj * rows1;
@@ -58,22 +78,31 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
         }
         const uint32_t total = __shfl(incl, 63, 64);
         const uint32_t excl = incl - cnt;
-        if (total >= LOW_ROWWISE_MIN * (uint32_t)__builtin_popcountll(c)) {
-            // A word of heavy rows (their updates average LOW_ROWWISE_MIN or more): row by row, the lanes taking the
-            // row's A x B updates 64 at a time (the rows are numbered by weight: a word's rows are alike).  The row's operands are scalars (v_readlane with a uniform lane), so
-            // there is no search and no shuffle: a third of the instructions of the batched way below.
-            for (unsigned long long rest = c; rest; rest &= rest - 1) {
-                const int L = __builtin_ctzll(rest);
-                const uint32_t rcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, L);
-                if (rcnt == 0) continue;
-                const uint32_t ra0 = (uint32_t)__builtin_amdgcn_readlane((int)a0, L), rb0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, L);
-                const uint32_t rnb = (uint32_t)__builtin_amdgcn_readlane((int)nbb, L);
-                const float inv = __frcp_rn((float)rnb);
-                for (uint32_t local = (uint32_t)lane; local < rcnt; local += 64) {
-                    const uint32_t qa_i = (uint32_t)(((float)local + 0.5f) * inv);  // local / rnb (see below)
-                    const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
-                    const uint2 ea = entries[a], eb = entries[b];  // (x: the sample's index within its block, y: its value)
-                    if (!diagonal || eb.x < ea.x) atomicAdd(&acc[ea.x * LOW_TILE + eb.x], min(ea.y, eb.y));
+        if (total >= rowwise_min * (uint32_t)__builtin_popcountll(c)) {
+            // A word of heavy rows (their updates average LOW_ROWWISE_MIN or more; the rows are numbered by weight, so a
+            // word's rows are alike): the wave splits into groups of G lanes, G the power of two that holds the word's
+            // longest B list (8 .. 64), a group takes a row -- its lanes the row's B entries, loaded once -- and walks the
+            // row's A entries, every lane of the group reading the same one (one address per group: a broadcast from L1):
+            // a step is a load, a min and an LDS add for 64 / G rows at once, no search, no shuffle, no division.
+            // Lanes along B: the accumulator's row is A's, so a group's adds fall in one LDS row, bank by bank.
+            uint32_t nb_sum = nbb;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nb_sum += (uint32_t)__shfl_xor((int)nb_sum, d, 64);
+            const uint32_t nb_avg = (nb_sum + (uint32_t)__builtin_popcountll(c) - 1) / (uint32_t)__builtin_popcountll(c);
+            const int lg = nb_avg <= 8 ? 3 : nb_avg <= 16 ? 4 : nb_avg <= 32 ? 5 : 6;
+            const int G = 1 << lg, per = 64 >> lg;       // lanes per group, rows per round
+            const int g = lane >> lg, idx = lane & (G - 1);
+            for (int round = 0; round < G; ++round) {     // rows round * per + g of the word
+                if (((c >> (round * per)) & (per == 64 ? ~0ull : (1ull << per) - 1)) == 0) continue;  // (uniform)
+                const int rl = round * per + g;
+                const uint32_t ra0 = __shfl(a0, rl, 64), rna = __shfl(na, rl, 64), rb0 = __shfl(b0, rl, 64), rnb = __shfl(nbb, rl, 64);
+                for (uint32_t bk = (uint32_t)idx; bk < rnb; bk += G) {  // (a second trip: the rows longer than G)
+                    const uint2 eb = entries[rb0 + bk];
+                    char *col = (char *)acc + (eb.x >> LOW_COL_SHIFT);
+                    // four A entries in flight at a time; past the row's end the loads bring other rows' entries (or the
+                    // array's spare ones, zeros) and the add is of zero -- no branch in the step
+                    if (diagonal) low_walk_row<true>(entries + ra0, rna, eb, col);  // (uniform)
+                    else low_walk_row<false>(entries + ra0, rna, eb, col);
                 }
             }
             continue;
@@ -97,15 +126,16 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
                 const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
                 const uint2 ea = entries[a], eb = entries[b];
                 if (!diagonal || eb.x < ea.x)  // (a diagonal tile: each pair once)
-                    atomicAdd(&acc[ea.x * LOW_TILE + eb.x], min(ea.y, eb.y));
+                    atomicAdd((uint32_t *)((char *)acc + (ea.x | (eb.x >> LOW_COL_SHIFT))), min(ea.y, eb.y));
             }
         }
     }
     __syncthreads();
     // the tile's slots: row i = i_base + li holds columns j_base .. of slot i (i - 1) / 2 + j -- contiguous in j
     for (int q = threadIdx.x; q < LOW_TILE * LOW_TILE; q += LOW_THREADS) {
-        const int64_t i = (int64_t)i_base + q / LOW_TILE, j = (int64_t)j_base + q % LOW_TILE;
+        const int li = q / LOW_TILE, lj = q % LOW_TILE;
+        const int64_t i = (int64_t)i_base + li, j = (int64_t)j_base + lj;
         if (i < row_begin || i >= row_end || i >= n_samples || j >= i) continue;
-        mlow[i * (i - 1) / 2 - slot_begin + j] = acc[q];
+        mlow[i * (i - 1) / 2 - slot_begin + j] = acc[li * LOW_STRIDE + lj];
     }
 }

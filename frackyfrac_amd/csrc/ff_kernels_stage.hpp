@@ -311,7 +311,7 @@ void low_fill_kernel(const int64_t *__restrict__ indptr, const int32_t *__restri
         if (r < 0) continue;
         const int64_t cell = (s / tile) * rows1 + r;
         const uint32_t at = ptr[cell] + atomicAdd(&cursor[cell], 1u);
-        entries[at] = uint2{(uint32_t)(s % tile), stage_q_weighted(branch_len[b], abnd[t], e, b)};
+        entries[at] = uint2{(uint32_t)(s % tile) << LOW_ROW_SHIFT, stage_q_weighted(branch_len[b], abnd[t], e, b)};
     }
 }
 

@@ -59,6 +59,11 @@ constexpr int LOW_TILES[] = {128, 96, 64};
 constexpr int LOW_TILE_MAX = 128;
 constexpr int LOW_THREADS = 1024;  // 16 waves on one tile's accumulators: the kernel lives on waves in flight (latency)
 constexpr int LOW_SHARE_DIV = 8;
+// An entry of a rare row carries its sample's place in the block as the BYTE offset of the accumulator's row in LDS --
+// li * LOW_STRIDE * 4 -- so that an update's address is one OR: (A entry's x) | (B entry's x >> LOW_COL_SHIFT = lj * 4).
+constexpr int LOW_STRIDE = 128;     // words between accumulator rows, whatever the block side
+constexpr int LOW_ROW_SHIFT = 9;    // li -> li * LOW_STRIDE * 4
+constexpr int LOW_COL_SHIFT = 7;    // li * LOW_STRIDE * 4 -> li * 4
 struct LowTile {
     int32_t bi, bj;  // sample blocks: pairs (i, j) with i in block bi, j in block bj <= bi, j < i
 };
