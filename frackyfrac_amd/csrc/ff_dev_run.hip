@@ -620,7 +620,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
             auto low = pl->low_tile == 128 ? pair_low_kernel<128> : pl->low_tile == 96 ? pair_low_kernel<96> : pair_low_kernel<64>;
             low<<<dim3((unsigned)pl->n_low_tiles), dim3(LOW_THREADS), 0, st>>>(
                 pl->d_low_ptr, pl->d_low_ent, pl->d_low_bits, pl->low_words, pl->low_rows + 1, pl->d_low_tiles,
-                inf.n_samples, inf.row_begin, inf.row_end, inf.slot_begin, pl->d_mlow, (uint32_t)env_int("FF_LOW_ROWWISE", (int)LOW_ROWWISE_MIN));
+                inf.n_samples, inf.row_begin, inf.row_end, inf.slot_begin, pl->d_mlow);
         }
         if (timed && !pl->mfma) FF_HIP(hipEventRecord(ev1, st));
         if (!fused) {

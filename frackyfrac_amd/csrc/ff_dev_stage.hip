@@ -558,15 +558,17 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
     // Sparse tables -- and dense ones with many samples: the rows that few samples reach leave the matrix
     // (ff_kernels_low.hpp).  A matrix row costs the dense kernel one lane-op per pair of the triangle:
-    // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  pair_low_kernel works in
-    // batches of 64 updates of an LDS accumulator, one batch at least per (bitmap word, tile) that has any: measured
-    // 1.26e-10 s per batch chip-wide (1.33e-10 at C4, 1.55e-10 at 8,192 samples, 2.3e-10 at C3 -- the same figure once the
-    // last, part-filled round of its 128 x 128 tiles on 2 workgroups per CU is counted: 17 / 5 / 2 rounds).  A rare row r
-    // with n_r flat nodes adds n_r^2 / 2 updates whatever the number of pairs, so a row is rare when that is cheaper than
-    // its matrix row -- n_r below about a tenth of the samples -- and the split is taken when the whole estimate saves 7 %
-    // or more (measured, ms per pass without -> with: C3 5.07 -> 4.30, C4 78.4 -> 62.8, C5 96.0 -> 54.9, C5's tree at 1 % /
-    // 0.2 % leaf density 72.2 -> 15.3 / 27.5 -> 4.8; 3,000 samples of C3's tree: no gain, left alone:
-    // profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
+    // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  pair_low_kernel's updates of
+    // an LDS accumulator are priced per 64, chip-wide: 1.26e-10 s for the light rows (taken 64 at a time by search, one
+    // batch at least per (bitmap word, tile) that has any: 1.33e-10 at C4, 1.55e-10 at 8,192 samples, 2.3e-10 at C3 -- the
+    // same figure once the last, part-filled round of its tiles on 2 workgroups per CU is counted), 0.35e-10 s for the rows
+    // whose words go by groups of lanes (LOW_ROWWISE_MIN; the price swept 15 .. 100 ps: flat from 15 to 50,
+    // profiles/r05_low_group_cost_sweep.txt).  A rare row r with n_r flat nodes adds n_r^2 / 2 updates whatever the number
+    // of pairs, so a row is rare when that is cheaper than its matrix row -- n_r up to a quarter of the samples
+    // (LOW_SHARE_DIV: the cap swept 1/8, 1/5, 1/3 -- C3 3.21 / 3.08 / 3.05 ms, C4 47.8 / 44.0 / 44.0, C5 42.0 / 37.3 /
+    // 37.0) -- and the split is taken when the whole estimate saves 7 % or more (ms per pass without -> with: C3 5.07 ->
+    // 3.05, C4 78.4 -> 44.0, C5 96.0 -> 37.2, C5's tree at 1 % / 0.2 % leaf density 72.2 -> 10.5 / 27.5 -> 3.5; 3,000
+    // samples of C3's tree 2.82 -> 2.12: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
     Scratch<int32_t> qt_row_of, low_of;   // branch id -> row of the matrix / rare row (-1: not there)
     int64_t Rq = R, Rl = 0;
     {
@@ -583,7 +585,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             // G-th of the blocks, and how they fill their rounds decides the block side: C5 over 8 ranks, 260 blocks of
             // 128 x 128 on 512 slots against 467 of 96 x 96)
             const double P = (double)N * (double)(N - 1) / 2.0, Ps = std::max(1.0, (double)n_slots), share = Ps / P;
-            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10;
+            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10, GROUP_COST = 0.35e-10;
             const double t_row = Ps / ROW_RATE;
             // every side of the blocks of pairs is priced -- how full its last round of two workgroups per CU is against
             // the (word, block) visits it makes -- and the cheapest estimate kept
@@ -603,21 +605,24 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                 double tc = 0;  // the shard's blocks: sample blocks bi that hold one of its rows, times bj <= bi
                 for (int64_t bi = inf.row_begin / cand; bi * cand < std::min<int64_t>(inf.row_end, N); ++bi) tc += (double)(bi + 1);
                 tc = std::max(tc, 1.0);
-                const double bc = BATCH_COST * std::ceil(tc / slots) * slots / tc;  // with the last round's idle slots
+                const double fill = std::ceil(tc / slots) * slots / tc;  // the last round's idle slots
+                const double bc = BATCH_COST * fill, gc = GROUP_COST * fill;
+                const double heavy_from = std::sqrt((double)LOW_ROWWISE_MIN) * (double)((N + cand - 1) / cand);  // n_r from which a word goes by groups
                 // (forced: every row up to the cap, whatever it is estimated to cost -- the tests' small problems)
-                const double rmax = force > 0 ? (double)N / LOW_SHARE_DIV : std::min((double)N / LOW_SHARE_DIV, std::sqrt(128.0 * t_row / share / bc));
-                double high_active = 0, updates = 0;
+                const double cap = (double)N / LOW_SHARE_DIV;
+                const double rmax = force > 0 ? cap : std::min(cap, std::sqrt(128.0 * t_row / share / gc));
+                double high_active = 0, updates = 0, updates_heavy = 0;
                 int64_t nl = 0;
                 for (int64_t r = 0; r < R; ++r) {
                     const double n_r = (double)h_cnt[(size_t)r];
                     if (n_r <= rmax) {
                         ++nl;
-                        updates += n_r * n_r / 2.0;
+                        (n_r >= heavy_from ? updates_heavy : updates) += n_r * n_r / 2.0;
                     } else {
                         high_active += 1.0 - std::pow(1.0 - std::min(1.0, n_r / (double)N), (double)TILE_I);
                     }
                 }
-                const double t_low = (updates * share / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc;
+                const double t_low = (updates * share / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc + updates_heavy * share / 64.0 * gc;
                 const double t = kernel_rows(high_active, (double)(R - nl)) * t_row + t_low;
                 if (tile == 0 || t < t_split) {
                     tile = cand;

@@ -8,18 +8,24 @@
 // M(i, j) = sum over the rare rows both have of min(q_i, q_j).  Same integers as one v_sad_u32 per term gives, so the
 // distances are the dense path's bit for bit (tests/test_gpu_parity.py::test_sparse_split_gives_the_same_integers).
 //
-// A workgroup owns a T x T block of pairs (T = LOW_TILE, one of ff_schedule.hpp's LOW_TILES, per plan) -- sample blocks bi (rows) and bj <= bi (columns) -- and keeps
-// its M in LDS.  The rare rows' entries are grouped by sample block, block-major (ptr[k][r] .. ptr[k][r + 1]: row r's
-// entries of block k, contiguous and ascending with r within the block); a bitmap per block says which rows have any.
+// A workgroup owns a T x T block of pairs (T = LOW_TILE, one of ff_schedule.hpp's LOW_TILES, per plan) -- sample blocks
+// bi (rows) and bj <= bi (columns) -- and keeps its M in LDS.  The rare rows' entries are grouped by sample block,
+// block-major (ptr[k][r] .. ptr[k][r + 1]: row r's entries of block k, contiguous and ascending with r within the
+// block); an entry is (x: the byte offset of its sample's accumulator row, li * LOW_STRIDE * 4; y: the staged value), so
+// that an update's LDS address is A.x | B.x >> LOW_COL_SHIFT.  A bitmap per block says which rows have any entry.
 // A WAVE takes a word of bits[bi] & bits[bj] at a time: lane l looks up row 64 w + l -- its A entries of block bi, its
-// B entries of block bj, A x B updates -- the counts are scanned across the wave, and the wave then works through the
-// word's updates 64 at a time, every lane finding its (row, a, b) by a binary search over the scanned counts: whatever
-// the rows' weights, an instruction does 64 updates.  (A thread per word with nested loops over its rows' entries ran
-// as long as the busiest lane of every step: 16 ps per update, 63 ms at 1 % density for what this does in a tenth.)
+// B entries of block bj, A x B updates -- and the counts are scanned across the wave.  Then one of two ways:
+//   light words (fewer than LOW_ROWWISE_MIN updates a row on average): the word's updates 64 at a time, every lane
+//     finding its (row, a, b) by a binary search over the scanned counts -- whatever the rows' weights, an instruction
+//     does 64 updates (61 instructions per 64);
+//   heavy words: the wave splits into groups of G lanes (G = 8 .. 64, the power of two that holds the word's average
+//     B list), a group takes a row, its lanes the row's B entries, and walks the row's A entries four loads ahead:
+//     29 instructions per four steps of 64 / G rows each (low_walk_row).
+// (History, measured at C3 / 1 % density: a thread per word with nested loops ran as long as the busiest lane of every
+// step, 63 ms at 1 %; the search alone 4.6 ms at C3; rows one by one on scalar operands 4.30; groups with one load
+// per step 4.46 -- the load's latency in every step; four loads ahead 3.72; the address as one OR, the tail by
+// adding zero instead of branching, the diagonal case compiled apart: 3.23.)
 // Every slot of the tile is then written once (zeros included): no memset, no global atomics.
-// updates per row of a word from which its rows are taken one by one (swept 16 .. 96 at C3 / C4 / C5 / 1 % density:
-// 64 is the best or within 0.5 % of it everywhere; C3 4.77 -> 4.30 ms, C4 67.1 -> 62.8 against the batched way alone)
-constexpr uint32_t LOW_ROWWISE_MIN = 32;
 struct __attribute__((aligned(8))) LowQuad { uint2 e[4]; };
 // One B entry (this lane's) against a row's A entries, four in flight at a time; past the row's end the loads bring other
 // rows' entries (or the array's spare ones, zeros) and the add is of zero: no branch in the step.  DIAGONAL: the block
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(LOW_THREADS)
 void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__ entries,
                      const unsigned long long *__restrict__ bits, int64_t words,
                      int64_t rows1, const LowTile *__restrict__ tiles, int64_t n_samples, int64_t row_begin, int64_t row_end,
-                     int64_t slot_begin, uint32_t *__restrict__ mlow, uint32_t rowwise_min)
+                     int64_t slot_begin, uint32_t *__restrict__ mlow)
 {
     __shared__ uint32_t acc[LOW_TILE * LOW_STRIDE];  // 64 / 48 / 32 KiB: row li at li * LOW_STRIDE words
     const LowTile tile = tiles[blockIdx.x];
@@ -78,13 +84,11 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
         }
         const uint32_t total = __shfl(incl, 63, 64);
         const uint32_t excl = incl - cnt;
-        if (total >= rowwise_min * (uint32_t)__builtin_popcountll(c)) {
-            // A word of heavy rows (their updates average LOW_ROWWISE_MIN or more; the rows are numbered by weight, so a
-            // word's rows are alike): the wave splits into groups of G lanes, G the power of two that holds the word's
-            // longest B list (8 .. 64), a group takes a row -- its lanes the row's B entries, loaded once -- and walks the
-            // row's A entries, every lane of the group reading the same one (one address per group: a broadcast from L1):
-            // a step is a load, a min and an LDS add for 64 / G rows at once, no search, no shuffle, no division.
-            // Lanes along B: the accumulator's row is A's, so a group's adds fall in one LDS row, bank by bank.
+        if (total >= LOW_ROWWISE_MIN * (uint32_t)__builtin_popcountll(c)) {
+            // A word of heavy rows (the rows are numbered by weight, so a word's rows are alike).  Lanes along B: the
+            // accumulator's row is A's, so a group's adds fall in one LDS row, bank by bank.  A group's row with more than
+            // G entries in B takes a second trip (G follows the average, not the longest: one long row in 64 would halve
+            // the lanes in use for all of them).
             uint32_t nb_sum = nbb;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) nb_sum += (uint32_t)__shfl_xor((int)nb_sum, d, 64);

@@ -1611,6 +1611,7 @@ def test_remaining_schedule_and_audit_switches_are_bit_neutral(monkeypatch):
     """FF_XCD_SLICES (how the main rounds pin branch slices to XCD groups: 0 = not at all, 2 default, 4, 8) changes
     which wave sweeps which rows, never a sum; FF_AUDIT=0 drops the run-time audit (ff_plan_audit then reports
     nothing checked) and changes no distance.  5,000 samples: two whole XCD-sliced rounds and a remainder."""
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "0")  # (the dense kernel's schedule over all the rows is what is switched)
     nodes, ip, on, ft = synth_problem(5000, 300, 0.15, 91)
     plan = ff.Plan(nodes, True, precision="fixed32")
     want = plan.run_host()
