@@ -617,7 +617,9 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, SYNC_TRIPS);
         if (pl->split && pl->n_low_tiles > 0) {  // (inside the timed region: it is part of the pair reduction)
-            auto low = pl->low_tile == 128 ? pair_low_kernel<128> : pl->low_tile == 96 ? pair_low_kernel<96> : pair_low_kernel<64>;
+            static_assert(sizeof(LOW_TILES) / sizeof(int) == 5, "one instance of pair_low_kernel per block side");
+            auto low = pl->low_tile == 128 ? pair_low_kernel<128> : pl->low_tile == 112 ? pair_low_kernel<112> :
+                       pl->low_tile == 96 ? pair_low_kernel<96> : pl->low_tile == 80 ? pair_low_kernel<80> : pair_low_kernel<64>;
             low<<<dim3((unsigned)pl->n_low_tiles), dim3(LOW_THREADS), 0, st>>>(
                 pl->d_low_ptr, pl->d_low_ent, pl->d_low_bits, pl->low_words, pl->low_rows + 1, pl->d_low_tiles,
                 inf.n_samples, inf.row_begin, inf.row_end, inf.slot_begin, pl->d_mlow);

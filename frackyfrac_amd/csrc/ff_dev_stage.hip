@@ -558,17 +558,15 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     const int64_t ld = round_up(std::max<int64_t>(N, 1), TILE_J);
     // Sparse tables -- and dense ones with many samples: the rows that few samples reach leave the matrix
     // (ff_kernels_low.hpp).  A matrix row costs the dense kernel one lane-op per pair of the triangle:
-    // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  pair_low_kernel's updates of
-    // an LDS accumulator are priced per 64, chip-wide: 1.26e-10 s for the light rows (taken 64 at a time by search, one
-    // batch at least per (bitmap word, tile) that has any: 1.33e-10 at C4, 1.55e-10 at 8,192 samples, 2.3e-10 at C3 -- the
-    // same figure once the last, part-filled round of its tiles on 2 workgroups per CU is counted), 0.35e-10 s for the rows
-    // whose words go by groups of lanes (LOW_ROWWISE_MIN; the price swept 15 .. 100 ps: flat from 15 to 50,
-    // profiles/r05_low_group_cost_sweep.txt).  A rare row r with n_r flat nodes adds n_r^2 / 2 updates whatever the number
-    // of pairs, so a row is rare when that is cheaper than its matrix row -- n_r up to a quarter of the samples
-    // (LOW_SHARE_DIV: the cap swept 1/8, 1/5, 1/3 -- C3 3.21 / 3.08 / 3.05 ms, C4 47.8 / 44.0 / 44.0, C5 42.0 / 37.3 /
-    // 37.0) -- and the split is taken when the whole estimate saves 7 % or more (ms per pass without -> with: C3 5.07 ->
-    // 3.05, C4 78.4 -> 44.0, C5 96.0 -> 37.2, C5's tree at 1 % / 0.2 % leaf density 72.2 -> 10.5 / 27.5 -> 3.5; 3,000
-    // samples of C3's tree 2.82 -> 2.12: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
+    // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  A rare row r with n_r flat
+    // nodes costs pair_low_kernel n_r^2 / 2 updates of an LDS accumulator whatever the number of pairs: priced below per
+    // candidate side of its blocks of pairs -- 1.26e-10 s per 64 updates of the light rows (taken 64 at a time by search,
+    // one batch at least per (bitmap word, block) that has any), 1.25e-11 s per step of a group of lanes for the heavy ones,
+    // and the last, part-filled round of the blocks on 2 workgroups per CU counted.  A row is rare when that is cheaper
+    // than its matrix row, up to a quarter of the samples (LOW_SHARE_DIV: beyond, the two prices meet), and the split is
+    // taken when the whole estimate saves 7 % or more (ms per pass without -> with: C3 5.02 -> 3.0, C4 78.2 -> 40.6, C5
+    // 96.2 -> 34.3, C5's tree at 1 % / 0.2 % leaf density 72.0 -> 10.0 / 27.4 -> 3.2; 3,000 samples of C3's tree 2.82 ->
+    // 2.1: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
     Scratch<int32_t> qt_row_of, low_of;   // branch id -> row of the matrix / rare row (-1: not there)
     int64_t Rq = R, Rl = 0;
     {
@@ -584,11 +582,9 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             // (priced for THIS plan's shard: its pairs, and its blocks of pairs -- a row shard of a multi-GPU run holds a
             // G-th of the blocks, and how they fill their rounds decides the block side: C5 over 8 ranks, 260 blocks of
             // 128 x 128 on 512 slots against 467 of 96 x 96)
-            const double P = (double)N * (double)(N - 1) / 2.0, Ps = std::max(1.0, (double)n_slots), share = Ps / P;
-            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10, GROUP_COST = 0.35e-10;
+            const double Ps = std::max(1.0, (double)n_slots);
+            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10, STEP_COST = 0.125e-10, ROUND_STEPS = 6.5;
             const double t_row = Ps / ROW_RATE;
-            // every side of the blocks of pairs is priced -- how full its last round of two workgroups per CU is against
-            // the (word, block) visits it makes -- and the cheapest estimate kept
             const double slots = 2.0 * (double)std::max(1, prop.multiProcessorCount);  // blocks in flight
             auto kernel_rows = [](double active_rows, double rows) { return active_rows <= 0.72 * rows ? active_rows / 0.77 : rows; };
             // (the sparse-aware kernel is taken from 28 % inactive cells and walks a row at 0.77 of the dense rate)
@@ -597,37 +593,74 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                 now_active += 1.0 - std::pow(1.0 - std::min(1.0, (double)h_cnt[(size_t)r] / (double)N), (double)TILE_I);  // P(a 32-sample block has it)
             const double t_now = kernel_rows(now_active, (double)R) * t_row;
             const int forced_tile = env_int("FF_LOW_TILE", 0);
+            const int64_t cap = N / LOW_SHARE_DIV;
             double t_split = 0, rare_max = 0;
             int tile = 0;
             int64_t n_low = 0;
+            std::vector<double> price((size_t)cap + 1);
+            std::vector<char> light((size_t)cap + 1);
             for (int cand : LOW_TILES) {
-                if (forced_tile && cand != forced_tile && (forced_tile == 128 || forced_tile == 96 || forced_tile == 64)) continue;
+                bool known = false;
+                for (int t : LOW_TILES) known = known || t == forced_tile;
+                if (known && cand != forced_tile) continue;
                 double tc = 0;  // the shard's blocks: sample blocks bi that hold one of its rows, times bj <= bi
                 for (int64_t bi = inf.row_begin / cand; bi * cand < std::min<int64_t>(inf.row_end, N); ++bi) tc += (double)(bi + 1);
                 tc = std::max(tc, 1.0);
                 const double fill = std::ceil(tc / slots) * slots / tc;  // the last round's idle slots
-                const double bc = BATCH_COST * fill, gc = GROUP_COST * fill;
-                const double heavy_from = std::sqrt((double)LOW_ROWWISE_MIN) * (double)((N + cand - 1) / cand);  // n_r from which a word goes by groups
-                // (forced: every row up to the cap, whatever it is estimated to cost -- the tests' small problems)
-                const double cap = (double)N / LOW_SHARE_DIV;
-                const double rmax = force > 0 ? cap : std::min(cap, std::sqrt(128.0 * t_row / share / gc));
-                double high_active = 0, updates = 0, updates_heavy = 0;
-                int64_t nl = 0;
-                for (int64_t r = 0; r < R; ++r) {
-                    const double n_r = (double)h_cnt[(size_t)r];
-                    if (n_r <= rmax) {
-                        ++nl;
-                        (n_r >= heavy_from ? updates_heavy : updates) += n_r * n_r / 2.0;
+                const double nblk = (double)((N + cand - 1) / cand);
+                // price[n]: a rare row with n flat nodes, in seconds of the chip.  n / nblk entries per sample block, a block
+                // has any with p = 1 - exp(-that), so the row is met in tc p^2 of the shard's blocks of pairs with a = n /
+                // (nblk p) entries on each side.  A light row (a^2 < LOW_ROWWISE_MIN) costs its a^2 updates at the batch
+                // price.  A heavy one is walked by a group of G lanes, 64 / G rows to a round of the wave:
+                //   G is the power of two (8 .. 64) that holds the WORD's average B list -- the mean of 64 lists of a, normal
+                //     with deviation sqrt(a / 64): the levels are mixed by their probabilities;
+                //   the round lasts as long as its longest row -- a + k sqrt(a), k the expected maximum of 64 / G normals --
+                //     and twice that when any of its rows has more than G entries in B (a second trip);
+                //   + ROUND_STEPS for the round's set-up, the quads' zero adds, the loads' latency; each step G / 64 of a wave.
+                // This reproduces pair_low_kernel within 4 % at every block side at C3, C4 and C5 with one STEP_COST
+                // (tools/experiments/low_tile_sweep.sh, profiles/r05_low_tile_sweep.txt: the estimate beside the measurement).
+                // Rare: every row up to the first n that a matrix row would do cheaper (or, forced, up to the cap -- the
+                // tests' small problems).
+                auto Phi = [](double x) { return 0.5 * std::erfc(-x * 0.7071067811865476); };
+                int64_t rmax = 0;
+                for (int64_t n = 1; n <= cap; ++n) {
+                    const double na = (double)n / nblk, p = 1.0 - std::exp(-na), a = na / p, visits = tc * p * p;
+                    light[(size_t)n] = a * a < (double)LOW_ROWWISE_MIN;
+                    if (light[(size_t)n]) {
+                        price[(size_t)n] = visits * a * a / 64.0 * BATCH_COST * fill;
                     } else {
-                        high_active += 1.0 - std::pow(1.0 - std::min(1.0, n_r / (double)N), (double)TILE_I);
+                        static const double LEVEL[4] = {8, 16, 32, 64}, KMAX[4] = {1.42, 1.03, 0.56, 0.0};  // (E max of 8 / 4 / 2 / 1 normals)
+                        const double sd = std::sqrt(a), sd_word = sd / 8.0;
+                        double steps = 0, below = 0;
+                        for (int l = 0; l < 4; ++l) {
+                            const double upto = l == 3 ? 1.0 : Phi((LEVEL[l] - a) / sd_word), per = 64.0 / LEVEL[l];
+                            const double second = 1.0 - std::pow(Phi((LEVEL[l] + 0.5 - a) / sd), per);  // P(a row of the round overflows G)
+                            steps += (upto - below) * ((a + KMAX[l] * sd) * (1.0 + second) + ROUND_STEPS) * LEVEL[l] / 64.0;
+                            below = upto;
+                        }
+                        price[(size_t)n] = visits * steps * STEP_COST * fill;
+                    }
+                    if (force <= 0 && price[(size_t)n] >= t_row) break;
+                    rmax = n;
+                }
+                double high_active = 0, t_low = 0;
+                int64_t nl = 0, nl_light = 0;
+                for (int64_t r = 0; r < R; ++r) {
+                    const int64_t n = h_cnt[(size_t)r];
+                    if (n <= rmax) {
+                        ++nl;
+                        nl_light += light[(size_t)n];
+                        t_low += price[(size_t)n];
+                    } else {
+                        high_active += 1.0 - std::pow(1.0 - std::min(1.0, (double)n / (double)N), (double)TILE_I);
                     }
                 }
-                const double t_low = (updates * share / 64.0 + std::ceil((double)nl / 64.0) * tc) * bc + updates_heavy * share / 64.0 * gc;
+                t_low += std::ceil((double)nl_light / 64.0) * tc * BATCH_COST * fill;  // (a batch at least per word and block of pairs)
                 const double t = kernel_rows(high_active, (double)(R - nl)) * t_row + t_low;
                 if (tile == 0 || t < t_split) {
                     tile = cand;
                     t_split = t;
-                    rare_max = rmax;
+                    rare_max = (double)rmax;
                     n_low = nl;
                 }
             }

@@ -31,20 +31,23 @@ struct __attribute__((aligned(8))) LowQuad { uint2 e[4]; };
 // rows' entries (or the array's spare ones, zeros) and the add is of zero: no branch in the step.  DIAGONAL: the block
 // of pairs lies on the diagonal, each pair once -- the other half adds zero (its cells are not written out anyway).
 template <bool DIAGONAL>
-__device__ __forceinline__ void low_walk_row(const uint2 *__restrict__ a, uint32_t rna, uint2 eb, char *col)
+__device__ __forceinline__ void low_quad(const LowQuad &e, uint32_t left, uint2 eb, char *col)
 {
-    for (uint32_t t = 0; t < rna; t += 4) {
-        const LowQuad e = *(const LowQuad *)(a + t);
-        const uint32_t left = rna - t;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t v = min(e.e[u].y, eb.y);
-            if (u > 0) v = left > (uint32_t)u ? v : 0u;
-            if (DIAGONAL) v = eb.x < e.e[u].x ? v : 0u;
-            atomicAdd((uint32_t *)(col + e.e[u].x), v);
-        }
+    for (int u = 0; u < 4; ++u) {
+        uint32_t v = min(e.e[u].y, eb.y);
+        if (u > 0) v = left > (uint32_t)u ? v : 0u;
+        if (DIAGONAL) v = eb.x < e.e[u].x ? v : 0u;
+        atomicAdd((uint32_t *)(col + e.e[u].x), v);
     }
 }
+// (first: the row's first four A entries, loaded a round ahead)
+template <bool DIAGONAL>
+__device__ __forceinline__ void low_walk_row(const uint2 *__restrict__ a, uint32_t rna, uint2 eb, char *col)
+{
+    for (uint32_t t = 0; t < rna; t += 4) low_quad<DIAGONAL>(*(const LowQuad *)(a + t), rna - t, eb, col);
+}
+struct LowRound { uint32_t ra0, rna, rb0, rnb; uint2 eb; };  // a group's row: its lists, this lane's B entry, the first A entries
 
 template <int LOW_TILE>
 __global__ __launch_bounds__(LOW_THREADS)
@@ -96,18 +99,31 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
             const int lg = nb_avg <= 8 ? 3 : nb_avg <= 16 ? 4 : nb_avg <= 32 ? 5 : 6;
             const int G = 1 << lg, per = 64 >> lg;       // lanes per group, rows per round
             const int g = lane >> lg, idx = lane & (G - 1);
-            for (int round = 0; round < G; ++round) {     // rows round * per + g of the word
-                if (((c >> (round * per)) & (per == 64 ? ~0ull : (1ull << per) - 1)) == 0) continue;  // (uniform)
+            // rows round * per + g of the word; a round's operands (four shuffles, the lane's B entry, the first four A
+            // entries: unconditional loads from valid addresses, used or not) are fetched while the round before is worked
+            auto fetch = [&](int round) {
+                LowRound r;
                 const int rl = round * per + g;
-                const uint32_t ra0 = __shfl(a0, rl, 64), rna = __shfl(na, rl, 64), rb0 = __shfl(b0, rl, 64), rnb = __shfl(nbb, rl, 64);
-                for (uint32_t bk = (uint32_t)idx; bk < rnb; bk += G) {  // (a second trip: the rows longer than G)
-                    const uint2 eb = entries[rb0 + bk];
-                    char *col = (char *)acc + (eb.x >> LOW_COL_SHIFT);
-                    // four A entries in flight at a time; past the row's end the loads bring other rows' entries (or the
-                    // array's spare ones, zeros) and the add is of zero -- no branch in the step
-                    if (diagonal) low_walk_row<true>(entries + ra0, rna, eb, col);  // (uniform)
-                    else low_walk_row<false>(entries + ra0, rna, eb, col);
+                r.ra0 = __shfl(a0, rl, 64), r.rna = __shfl(na, rl, 64), r.rb0 = __shfl(b0, rl, 64), r.rnb = __shfl(nbb, rl, 64);
+                r.eb = entries[r.rb0 + min((uint32_t)idx, max(r.rnb, 1u) - 1u)];
+                return r;
+            };
+            LowRound cur = fetch(0);
+            for (int round = 0; round < G; ++round) {
+                LowRound nxt = cur;
+                if (round + 1 < G) nxt = fetch(round + 1);
+                if ((uint32_t)idx < cur.rnb) {
+                    char *col = (char *)acc + (cur.eb.x >> LOW_COL_SHIFT);
+                    if (diagonal) low_walk_row<true>(entries + cur.ra0, cur.rna, cur.eb, col);  // (uniform)
+                    else low_walk_row<false>(entries + cur.ra0, cur.rna, cur.eb, col);
                 }
+                for (uint32_t bk = (uint32_t)idx + G; bk < cur.rnb; bk += G) {  // (a second trip: the rows longer than G)
+                    const uint2 eb = entries[cur.rb0 + bk];
+                    char *col = (char *)acc + (eb.x >> LOW_COL_SHIFT);
+                    if (diagonal) low_walk_row<true>(entries + cur.ra0, cur.rna, eb, col);
+                    else low_walk_row<false>(entries + cur.ra0, cur.rna, eb, col);
+                }
+                cur = nxt;
             }
             continue;
         }

@@ -55,7 +55,7 @@ static_assert(X_VALUES_PAD >= X_TILE_HEIGHTS[sizeof(X_TILE_HEIGHTS) / sizeof(int
 // over the rows with entries in both of its sample blocks.  T is one of LOW_TILES, picked per plan: the blocks of pairs
 // are dealt to two workgroups per CU, and what decides is how full their last round is (C3, 4,096 samples: 528 blocks
 // of 128 x 128 on 512 slots are two rounds, the second all but empty; 946 of 96 x 96 fill 1.85).
-constexpr int LOW_TILES[] = {128, 96, 64};
+constexpr int LOW_TILES[] = {128, 112, 96, 80, 64};
 constexpr int LOW_TILE_MAX = 128;
 constexpr int LOW_THREADS = 1024;  // 16 waves on one tile's accumulators: the kernel lives on waves in flight (latency)
 constexpr int LOW_SHARE_DIV = 4;

@@ -18,7 +18,7 @@ SWITCHES = [
     ("FF_SPARSE", "1", "tuning", "the sparse-aware weighted kernel where enough (32-sample block, branch) cells are empty"),
     ("FF_SPARSE_MIN", "0.28", "tuning", "the share of empty cells from which the sparse-aware kernel is taken"),
     ("FF_SPARSE_SPLIT", "unset", "tuning", "weighted FIXED32: 1 / 0 forces / forbids keeping the rows few samples reach out of the staged matrix and reducing them by pair_low_kernel over the pairs that both have them (unset: when that is estimated to save 30 % or more; same integers)"),
-    ("FF_LOW_TILE", "unset", "tuning", "128 / 96 / 64 forces the side of pair_low_kernel's blocks of pairs (unset: the one whose blocks fill their rounds of two workgroups per CU best)"),
+    ("FF_LOW_TILE", "unset", "tuning", "128 / 112 / 96 / 80 / 64 forces the side of pair_low_kernel's blocks of pairs (unset: the one whose blocks fill their rounds of two workgroups per CU best)"),
     ("FF_REFINE", "1", "tuning", "FIXED32: exact re-computation of nearly equal pairs (0: tests of what it protects against)"),
     ("FF_AUDIT", "1", "tuning", "FIXED32: the run-time audit -- the uniform sample of a shard's pairs and the run's pairs just above the refinement bound, against binary64"),
     ("FF_EXACT_UNW", "1", "tuning", "EXACT64 unweighted on pair_exact_unw_kernel (0: the weighted kernel's arithmetic on presence as 1.0 / 0.0; same bits, three times the time)"),

@@ -911,7 +911,7 @@ def test_sparse_split_gives_the_same_integers(monkeypatch, ns, nl, dens):
     ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
     outs, rare = {}, {}
     monkeypatch.setenv("FF_REFINE", "0")       # compare the raw integers, not the refined pairs
-    for flag in ("1", "0", "128", "96", "64"):  # (the last three: the split with that side of the blocks of pairs forced)
+    for flag in ("1", "0", "128", "112", "96", "80", "64"):  # (the last five: the split with that side of the blocks of pairs forced)
         monkeypatch.setenv("FF_SPARSE_SPLIT", "0" if flag == "0" else "1")
         if len(flag) > 1:
             monkeypatch.setenv("FF_LOW_TILE", flag)
@@ -933,7 +933,7 @@ def test_sparse_split_gives_the_same_integers(monkeypatch, ns, nl, dens):
         plan.close()
     monkeypatch.delenv("FF_LOW_TILE")
     assert rare["0"] == 0 and 0 < rare["1"] < nodes.n_branches
-    for flag in ("1", "128", "96", "64"):
+    for flag in ("1", "128", "112", "96", "80", "64"):
         assert np.array_equal(outs[flag], outs["0"]), flag
     monkeypatch.delenv("FF_REFINE")
     monkeypatch.setenv("FF_SPARSE_SPLIT", "1")
