@@ -149,7 +149,10 @@ def test_default_multi_gpu_line_leads_with_c4_strong_and_carries_the_weak_one():
     assert out["config"]["workload"].startswith("C4:") and out["config"]["pairs"] == 16384 * 16383 // 2
     assert sum(r["pairs"] for r in out["ranks"]) == 16384 * 16383 // 2
     assert abs(out["value"] - 16384 * 16383 // 2 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
-    assert 0 < out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"]
+    # (floor_ms prices ALL 2*B lane-ops per pair; with the rare rows reduced by pair_low_kernel fewer are issued and the
+    # kernels may finish under it: roofline.frac_note)
+    assert 0 < out["roofline"]["floor_ms"] and 0 < out["roofline"]["kernel_ms"]
+    assert out["roofline"]["floor_ms"] < out["roofline"]["kernel_ms"] or out["roofline"].get("rare_rows", 0) > 0
     # the base of the strong curve: the same problem on one GPU, same build, same run
     sb = out["strong_base"]
     assert sb["n_gpus"] == 1 and sb["workload"].startswith("C4:") and sb["value"] > 0 and sb["kernel"].startswith("pair_sad_kernel")
