@@ -897,6 +897,60 @@ def test_sparse_aware_kernel(monkeypatch):
     assert rel_err(out, want2) <= WEIGHTED_RTOL
 
 
+@pytest.mark.parametrize("tile", ["128", "112", "96", "80", "64"])
+def test_sparse_split_on_clustered_samples(monkeypatch, tile):
+    """Samples are not independent draws in a real table: a clade may live in one run of consecutive samples and nowhere
+    else.  Its rows are rare by count (a quarter of the samples or fewer) while a sample block holds them in EVERY
+    sample: pair_low_kernel's widest groups (64 lanes), second and third trips over B lists longer than the group, the
+    diagonal blocks with A = B = the whole block, rows whose entries all sit in one or two blocks.  1,100 samples, 9
+    runs of 128 / 256 consecutive samples owning a slice of the leaves each (all of it, or every other leaf), a thin
+    random background; every block side; against the unsplit path bit for bit and the oracle within tolerance."""
+    import torch
+    ns, nl = 1100, 900
+    tree = synth.yule_tree(nl, 4242)
+    rng = np.random.default_rng(99)
+    leaves = np.asarray(tree.leaf_ids)
+    runs = [(0, 128), (128, 256), (300, 428), (428, 684), (700, 828), (828, 956), (956, 1084), (50, 306), (844, 1100)]
+    own = np.array_split(rng.permutation(nl), len(runs) + 1)   # (the last slice: background only)
+    rows = [dict() for _ in range(ns)]
+    for k, (lo, hi) in enumerate(runs):
+        for s in range(lo, hi):
+            pick = own[k] if k % 2 == 0 else own[k][(s % 2)::2]
+            for leaf in pick:
+                rows[s][int(leaf)] = float(rng.integers(1, 50))
+    for s in range(ns):
+        for leaf in rng.choice(nl, 6, replace=False):
+            rows[s].setdefault(int(leaf), float(rng.integers(1, 9)))
+    ptr = np.zeros(ns + 1, dtype=np.int64)
+    idx, val = [], []
+    for s in range(ns):
+        for leaf in sorted(rows[s]):
+            idx.append(int(leaves[leaf]))
+            val.append(rows[s][leaf])
+        ptr[s + 1] = len(idx)
+    idx, val = np.array(idx, dtype=np.int64), np.array(val)
+    T = ff.parse_newick(tree.newick())
+    nodes = ff.flatten_leaf_csr(T, ptr, idx, val)
+    monkeypatch.setenv("FF_REFINE", "0")
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FF_SPARSE_SPLIT", flag)
+        monkeypatch.setenv("FF_LOW_TILE", tile)
+        plan = ff.Plan(nodes, True, precision="fixed32")
+        assert (plan.info.rare_rows > 100) == (flag == "1")
+        out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
+        plan.run(out.data_ptr())
+        torch.cuda.synchronize()
+        outs[flag] = out.cpu().numpy()
+        plan.close()
+    assert np.array_equal(outs["1"], outs["0"])
+    monkeypatch.delenv("FF_REFINE")
+    ft = O.FlatTree(tree.names, tree.branch_len, tree.size, tree.parent)
+    ip, on = O.flatten_samples(ft, ptr, idx, val, 0)
+    want = O.unifrac_dists(ip, on, ft.dist, True, nthreads=HOST_THREADS)
+    assert rel_err(ff.unifrac_dists(nodes, True, precision="fixed32"), want) <= WEIGHTED_RTOL
+
+
 @pytest.mark.parametrize("ns,nl,dens", [(2100, 3000, 0.01), (700, 9000, 0.003), (333, 500, 0.05)])
 def test_sparse_split_gives_the_same_integers(monkeypatch, ns, nl, dens):
     """The rows few samples reach out of the staged matrix (pair_low_kernel: sum of min(q_i, q_j) over the rows BOTH
