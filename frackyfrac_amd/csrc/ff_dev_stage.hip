@@ -560,13 +560,10 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
     // (ff_kernels_low.hpp).  A matrix row costs the dense kernel one lane-op per pair of the triangle:
     // P / 33e12 s (measured: 0.97 us a row at 8,192 samples, 0.26 at 4,096, 3.9 at 16,384).  A rare row r with n_r flat
     // nodes costs pair_low_kernel n_r^2 / 2 updates of an LDS accumulator whatever the number of pairs: priced below per
-    // candidate side of its blocks of pairs -- 1.26e-10 s per 64 updates of the light rows (taken 64 at a time by search,
-    // one batch at least per (bitmap word, block) that has any), 1.25e-11 s per step of a group of lanes for the heavy ones,
-    // and the last, part-filled round of the blocks on 2 workgroups per CU counted.  A row is rare when that is cheaper
-    // than its matrix row, up to a quarter of the samples (LOW_SHARE_DIV: beyond, the two prices meet), and the split is
-    // taken when the whole estimate saves 7 % or more (ms per pass without -> with: C3 5.02 -> 3.0, C4 78.2 -> 40.6, C5
-    // 96.2 -> 34.3, C5's tree at 1 % / 0.2 % leaf density 72.0 -> 10.0 / 27.4 -> 3.2; 3,000 samples of C3's tree 2.82 ->
-    // 2.1: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
+    // candidate side of its blocks of pairs, in steps of a wave at 1.3e-11 s chip-wide, the last, part-filled round of
+    // the blocks on 2 workgroups per CU counted.  A row is rare when that is cheaper than its matrix row, up to
+    // N / LOW_SHARE_DIV samples, and the split is taken when the whole estimate saves 7 % or more (ms per pass without ->
+    // with: profiles/r05_sparse_split.txt).  FF_SPARSE_SPLIT = 1 / 0 forces / forbids it.
     Scratch<int32_t> qt_row_of, low_of;   // branch id -> row of the matrix / rare row (-1: not there)
     int64_t Rq = R, Rl = 0;
     {
@@ -583,7 +580,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             // G-th of the blocks, and how they fill their rounds decides the block side: C5 over 8 ranks, 260 blocks of
             // 128 x 128 on 512 slots against 467 of 96 x 96)
             const double Ps = std::max(1.0, (double)n_slots);
-            constexpr double ROW_RATE = 33e12, BATCH_COST = 1.26e-10, STEP_COST = 0.125e-10, ROUND_STEPS = 6.5;
+            constexpr double ROW_RATE = 33e12, STEP_COST = 0.13e-10, ROUND_STEPS = 4, WORD_STEPS = 8, ZERO_STEPS = 5;
             const double t_row = Ps / ROW_RATE;
             const double slots = 2.0 * (double)std::max(1, prop.multiProcessorCount);  // blocks in flight
             auto kernel_rows = [](double active_rows, double rows) { return active_rows <= 0.72 * rows ? active_rows / 0.77 : rows; };
@@ -598,7 +595,6 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             int tile = 0;
             int64_t n_low = 0;
             std::vector<double> price((size_t)cap + 1);
-            std::vector<char> light((size_t)cap + 1);
             for (int cand : LOW_TILES) {
                 bool known = false;
                 for (int t : LOW_TILES) known = known || t == forced_tile;
@@ -610,52 +606,40 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                 const double nblk = (double)((N + cand - 1) / cand);
                 // price[n]: a rare row with n flat nodes, in seconds of the chip.  n / nblk entries per sample block, a block
                 // has any with p = 1 - exp(-that), so the row is met in tc p^2 of the shard's blocks of pairs with a = n /
-                // (nblk p) entries on each side.  A light row (a^2 < LOW_ROWWISE_MIN) costs its a^2 updates at the batch
-                // price.  A heavy one is walked by a group of G lanes, 64 / G rows to a round of the wave:
-                //   G is the power of two (8 .. 64) that holds the WORD's average B list -- the mean of 64 lists of a, normal
-                //     with deviation sqrt(a / 64): the levels are mixed by their probabilities;
-                //   the round lasts as long as its longest row -- a + k sqrt(a), k the expected maximum of 64 / G normals --
-                //     and twice that when any of its rows has more than G entries in B (a second trip);
-                //   + ROUND_STEPS for the round's set-up, the quads' zero adds, the loads' latency; each step G / 64 of a wave.
-                // This reproduces pair_low_kernel within 4 % at every block side at C3, C4 and C5 with one STEP_COST
-                // (tools/experiments/low_tile_sweep.sh, profiles/r05_low_tile_sweep.txt: the estimate beside the measurement).
+                // (nblk p) entries on each side.  There its B entries take a / 64 of a round of the wave, and the round lasts
+                // as long as the longest A list among its 64 / a rows -- a + k sqrt(a), k the expected maximum of that many
+                // normals -- + 1.5 for the last quad's zero adds + ROUND_STEPS for the search and the loads' latency.  Per
+                // bitmap word and block of pairs: WORD_STEPS where the word has any row in both sample blocks (the index
+                // look-ups, the scan), ZERO_STEPS where it has none; a row carries a 64th of its word.
+                // One STEP_COST reproduces pair_low_kernel within 12 % (5 % rms) at every block side at C3, C4, C5 and
+                // C5's tree at 1 % and 0.2 % leaf density (tools/experiments/low_tile_sweep.sh,
+                // profiles/r05_low_tile_sweep.txt), and picks the side that measures best at each.
                 // Rare: every row up to the first n that a matrix row would do cheaper (or, forced, up to the cap -- the
                 // tests' small problems).
-                auto Phi = [](double x) { return 0.5 * std::erfc(-x * 0.7071067811865476); };
+                static const double KMAX[7] = {0, 0.56, 1.03, 1.42, 1.77, 2.07, 2.33};  // E max of 1, 2, 4 .. 64 normals
                 int64_t rmax = 0;
                 for (int64_t n = 1; n <= cap; ++n) {
-                    const double na = (double)n / nblk, p = 1.0 - std::exp(-na), a = na / p, visits = tc * p * p;
-                    light[(size_t)n] = a * a < (double)LOW_ROWWISE_MIN;
-                    if (light[(size_t)n]) {
-                        price[(size_t)n] = visits * a * a / 64.0 * BATCH_COST * fill;
-                    } else {
-                        static const double LEVEL[4] = {8, 16, 32, 64}, KMAX[4] = {1.42, 1.03, 0.56, 0.0};  // (E max of 8 / 4 / 2 / 1 normals)
-                        const double sd = std::sqrt(a), sd_word = sd / 8.0;
-                        double steps = 0, below = 0;
-                        for (int l = 0; l < 4; ++l) {
-                            const double upto = l == 3 ? 1.0 : Phi((LEVEL[l] - a) / sd_word), per = 64.0 / LEVEL[l];
-                            const double second = 1.0 - std::pow(Phi((LEVEL[l] + 0.5 - a) / sd), per);  // P(a row of the round overflows G)
-                            steps += (upto - below) * ((a + KMAX[l] * sd) * (1.0 + second) + ROUND_STEPS) * LEVEL[l] / 64.0;
-                            below = upto;
-                        }
-                        price[(size_t)n] = visits * steps * STEP_COST * fill;
-                    }
+                    const double na = (double)n / nblk, p = 1.0 - std::exp(-na), a = na / p, both = p * p;
+                    const double lg = std::min(6.0, std::max(0.0, std::log2(64.0 / a)));
+                    const int l0 = std::min(5, (int)lg);
+                    const double k = KMAX[l0] + (KMAX[l0 + 1] - KMAX[l0]) * (lg - l0);
+                    const double row_steps = both * a / 64.0 * (a + k * std::sqrt(a) + 1.5 + ROUND_STEPS);
+                    const double word_steps = ((1.0 - std::pow(1.0 - both, 64.0)) * WORD_STEPS + ZERO_STEPS) / 64.0;
+                    price[(size_t)n] = tc * (row_steps + word_steps) * STEP_COST * fill;
                     if (force <= 0 && price[(size_t)n] >= t_row) break;
                     rmax = n;
                 }
                 double high_active = 0, t_low = 0;
-                int64_t nl = 0, nl_light = 0;
+                int64_t nl = 0;
                 for (int64_t r = 0; r < R; ++r) {
                     const int64_t n = h_cnt[(size_t)r];
                     if (n <= rmax) {
                         ++nl;
-                        nl_light += light[(size_t)n];
                         t_low += price[(size_t)n];
                     } else {
                         high_active += 1.0 - std::pow(1.0 - std::min(1.0, (double)n / (double)N), (double)TILE_I);
                     }
                 }
-                t_low += std::ceil((double)nl_light / 64.0) * tc * BATCH_COST * fill;  // (a batch at least per word and block of pairs)
                 const double t = kernel_rows(high_active, (double)(R - nl)) * t_row + t_low;
                 if (tile == 0 || t < t_split) {
                     tile = cand;

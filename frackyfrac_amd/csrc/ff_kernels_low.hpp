@@ -14,17 +14,17 @@
 // block); an entry is (x: the byte offset of its sample's accumulator row, li * LOW_STRIDE * 4; y: the staged value), so
 // that an update's LDS address is A.x | B.x >> LOW_COL_SHIFT.  A bitmap per block says which rows have any entry.
 // A WAVE takes a word of bits[bi] & bits[bj] at a time: lane l looks up row 64 w + l -- its A entries of block bi, its
-// B entries of block bj, A x B updates -- and the counts are scanned across the wave.  Then one of two ways:
-//   light words (fewer than LOW_ROWWISE_MIN updates a row on average): the word's updates 64 at a time, every lane
-//     finding its (row, a, b) by a binary search over the scanned counts -- whatever the rows' weights, an instruction
-//     does 64 updates (61 instructions per 64);
-//   heavy words: the wave splits into groups of G lanes (G = 8 .. 64, the power of two that holds the word's average
-//     B list), a group takes a row, its lanes the row's B entries, and walks the row's A entries four loads ahead:
-//     29 instructions per four steps of 64 / G rows each (low_walk_row).
+// B entries of block bj, A x B updates -- the B list lengths are scanned across the wave, and the wave works through the
+// word's B ENTRIES 64 at a time: a lane finds its (row, B entry) by a binary search over the scanned lengths, loads the
+// entry, and walks the row's A entries four loads ahead -- 29 instructions per four steps, no branch (past the row's end
+// the add is of zero); the next 64's operands are fetched while these are worked.  Whatever the rows' weights every lane
+// has an entry, and a round lasts as long as the longest A list among its rows.
 // (History, measured at C3 / 1 % density: a thread per word with nested loops ran as long as the busiest lane of every
-// step, 63 ms at 1 %; the search alone 4.6 ms at C3; rows one by one on scalar operands 4.30; groups with one load
-// per step 4.46 -- the load's latency in every step; four loads ahead 3.72; the address as one OR, the tail by
-// adding zero instead of branching, the diagonal case compiled apart: 3.23.)
+// step, 63 ms at 1 %; lanes dealt to the word's UPDATES (row, a, b) by search, 61 instructions per 64: 4.6 ms at C3;
+// heavy rows one by one on scalar operands 4.30; by groups of G lanes, G a power of two, a row per group, one load per
+// step 4.46 -- the load's latency in every step; four loads ahead 3.72; the address as one OR, the tail by adding zero
+// instead of branching, the diagonal case compiled apart: 3.23; a round fetched ahead, block sides 112 and 80: 2.99;
+// lanes dealt to the B entries without gaps -- this -- 2.65, and the search over updates, slower at every density, went.)
 // Every slot of the tile is then written once (zeros included): no memset, no global atomics.
 struct __attribute__((aligned(8))) LowQuad { uint2 e[4]; };
 // One B entry (this lane's) against a row's A entries, four in flight at a time; past the row's end the loads bring other
@@ -47,7 +47,7 @@ __device__ __forceinline__ void low_walk_row(const uint2 *__restrict__ a, uint32
 {
     for (uint32_t t = 0; t < rna; t += 4) low_quad<DIAGONAL>(*(const LowQuad *)(a + t), rna - t, eb, col);
 }
-struct LowRound { uint32_t ra0, rna, rb0, rnb; uint2 eb; };  // a group's row: its lists, this lane's B entry, the first A entries
+struct LowRound { uint32_t ra0, rna; uint2 eb; bool on; };  // a lane's part of a round: its row's A list, its B entry, whether it has one
 
 template <int LOW_TILE>
 __global__ __launch_bounds__(LOW_THREADS)
@@ -78,76 +78,46 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
             b0 = pj[r];
             nbb = pj[r + 1] - b0;
         }
-        const uint32_t cnt = na * nbb;
-        uint32_t incl = cnt;
+        // The lanes are dealt to the word's B entries, row after row without gaps (lane -> (row, entry) by a binary
+        // search over the scanned list lengths), 64 at a time, and every lane walks its row's A entries: no lane idles
+        // for a short list, a round lasts as long as the longest A list among its rows (the rows are numbered by weight:
+        // alike).  Lanes along B: the accumulator's row is A's, so a row's adds fall in one LDS row, bank by bank.
+        uint32_t inclb = nbb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
+            const uint32_t up = __shfl_up(inclb, d, 64);
+            if (lane >= d) inclb += up;
         }
-        const uint32_t total = __shfl(incl, 63, 64);
-        const uint32_t excl = incl - cnt;
-        if (total >= LOW_ROWWISE_MIN * (uint32_t)__builtin_popcountll(c)) {
-            // A word of heavy rows (the rows are numbered by weight, so a word's rows are alike).  Lanes along B: the
-            // accumulator's row is A's, so a group's adds fall in one LDS row, bank by bank.  A group's row with more than
-            // G entries in B takes a second trip (G follows the average, not the longest: one long row in 64 would halve
-            // the lanes in use for all of them).
-            uint32_t nb_sum = nbb;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) nb_sum += (uint32_t)__shfl_xor((int)nb_sum, d, 64);
-            const uint32_t nb_avg = (nb_sum + (uint32_t)__builtin_popcountll(c) - 1) / (uint32_t)__builtin_popcountll(c);
-            const int lg = nb_avg <= 8 ? 3 : nb_avg <= 16 ? 4 : nb_avg <= 32 ? 5 : 6;
-            const int G = 1 << lg, per = 64 >> lg;       // lanes per group, rows per round
-            const int g = lane >> lg, idx = lane & (G - 1);
-            // rows round * per + g of the word; a round's operands (four shuffles, the lane's B entry, the first four A
-            // entries: unconditional loads from valid addresses, used or not) are fetched while the round before is worked
-            auto fetch = [&](int round) {
-                LowRound r;
-                const int rl = round * per + g;
-                r.ra0 = __shfl(a0, rl, 64), r.rna = __shfl(na, rl, 64), r.rb0 = __shfl(b0, rl, 64), r.rnb = __shfl(nbb, rl, 64);
-                r.eb = entries[r.rb0 + min((uint32_t)idx, max(r.rnb, 1u) - 1u)];
-                return r;
-            };
-            LowRound cur = fetch(0);
-            for (int round = 0; round < G; ++round) {
-                LowRound nxt = cur;
-                if (round + 1 < G) nxt = fetch(round + 1);
-                if ((uint32_t)idx < cur.rnb) {
-                    char *col = (char *)acc + (cur.eb.x >> LOW_COL_SHIFT);
-                    if (diagonal) low_walk_row<true>(entries + cur.ra0, cur.rna, cur.eb, col);  // (uniform)
-                    else low_walk_row<false>(entries + cur.ra0, cur.rna, cur.eb, col);
-                }
-                for (uint32_t bk = (uint32_t)idx + G; bk < cur.rnb; bk += G) {  // (a second trip: the rows longer than G)
-                    const uint2 eb = entries[cur.rb0 + bk];
-                    char *col = (char *)acc + (eb.x >> LOW_COL_SHIFT);
-                    if (diagonal) low_walk_row<true>(entries + cur.ra0, cur.rna, eb, col);
-                    else low_walk_row<false>(entries + cur.ra0, cur.rna, eb, col);
-                }
-                cur = nxt;
-            }
-            continue;
-        }
-        for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+        const uint32_t totalb = __shfl(inclb, 63, 64);
+        const uint32_t b_at = b0 - (inclb - nbb);  // + k: the place of the word's k-th B entry, for k in this lane's row (mod 2^32)
+        // (a round's operands -- the search, three shuffles, the lane's B entry -- are fetched while the round before is
+        // worked)
+        auto fetch = [&](uint32_t k0) {
+            LowRound r;
             const uint32_t k = k0 + (uint32_t)lane;
-            int L = 0;  // the lane whose row holds update k: the number of lanes with incl <= k
+            int L = 0;  // the lane whose row holds B entry k: the number of lanes with inclb <= k
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
-                const uint32_t v = __shfl(incl, L + step - 1, 64);
+                const uint32_t v = __shfl(inclb, L + step - 1, 64);
                 if (v <= k) L += step;
             }
-            L = min(L, 63);  // (lanes past the word's last update)
-            const uint32_t local = k - __shfl(excl, L, 64);
-            const uint32_t ra0 = __shfl(a0, L, 64), rb0 = __shfl(b0, L, 64), rnb = __shfl(nbb, L, 64);
-            if (k < total) {
-                // local / rnb without the integer division's 25 instructions: the quotient is below 128 (a block holds at
-                // most LOW_TILE <= 128 entries of a row), (local + 0.5) / rnb lies at least 0.5 / 128 inside (q, q + 1), and the
-                // reciprocal and the product are off by less than 1e-4 of it
-                const uint32_t qa_i = (uint32_t)(((float)local + 0.5f) * __frcp_rn((float)rnb));
-                const uint32_t a = ra0 + qa_i, b = rb0 + (local - qa_i * rnb);
-                const uint2 ea = entries[a], eb = entries[b];
-                if (!diagonal || eb.x < ea.x)  // (a diagonal tile: each pair once)
-                    atomicAdd((uint32_t *)((char *)acc + (ea.x | (eb.x >> LOW_COL_SHIFT))), min(ea.y, eb.y));
+            L = min(L, 63);  // (lanes past the word's last entry)
+            r.on = k < totalb;
+            const uint32_t at = __shfl(b_at, L, 64) + k;
+            r.ra0 = __shfl(a0, L, 64), r.rna = __shfl(na, L, 64);
+            r.eb = entries[r.on ? at : 0u];
+            return r;
+        };
+        LowRound cur = fetch(0);
+        for (uint32_t k0 = 0; k0 < totalb; k0 += 64) {
+            LowRound nxt = cur;
+            if (k0 + 64 < totalb) nxt = fetch(k0 + 64);  // (uniform)
+            if (cur.on) {
+                char *col = (char *)acc + (cur.eb.x >> LOW_COL_SHIFT);
+                if (diagonal) low_walk_row<true>(entries + cur.ra0, cur.rna, cur.eb, col);  // (uniform)
+                else low_walk_row<false>(entries + cur.ra0, cur.rna, cur.eb, col);
             }
+            cur = nxt;
         }
     }
     __syncthreads();

@@ -58,11 +58,7 @@ static_assert(X_VALUES_PAD >= X_TILE_HEIGHTS[sizeof(X_TILE_HEIGHTS) / sizeof(int
 constexpr int LOW_TILES[] = {128, 112, 96, 80, 64};
 constexpr int LOW_TILE_MAX = 128;
 constexpr int LOW_THREADS = 1024;  // 16 waves on one tile's accumulators: the kernel lives on waves in flight (latency)
-constexpr int LOW_SHARE_DIV = 4;
-// Updates per row, on average over a bitmap word's rows, from which pair_low_kernel takes the word by groups of lanes
-// rather than 64 updates at a time by search (swept 4 .. 64 at C3 / C4 / C5 / 1 % / 0.2 % leaf density: 8 is the best or
-// within 1 % of it everywhere -- profiles/r05_low_rowwise_sweep.txt).
-constexpr uint32_t LOW_ROWWISE_MIN = 8;
+constexpr int LOW_SHARE_DIV = 2;
 // An entry of a rare row carries its sample's place in the block as the BYTE offset of the accumulator's row in LDS --
 // li * LOW_STRIDE * 4 -- so that an update's address is one OR: (A entry's x) | (B entry's x >> LOW_COL_SHIFT = lj * 4).
 constexpr int LOW_STRIDE = 128;     // words between accumulator rows, whatever the block side
