@@ -41,7 +41,6 @@ __device__ __forceinline__ void low_quad(const LowQuad &e, uint32_t left, uint2 
         atomicAdd((uint32_t *)(col + e.e[u].x), v);
     }
 }
-// (first: the row's first four A entries, loaded a round ahead)
 template <bool DIAGONAL>
 __device__ __forceinline__ void low_walk_row(const uint2 *__restrict__ a, uint32_t rna, uint2 eb, char *col)
 {
