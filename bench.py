@@ -271,7 +271,7 @@ def barrier(ctx):
     ctx.torch.cuda.synchronize()
 
 
-def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, traffic):
+def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, traffic, rare_ms=None):
     """Roofline of the dominant kernel from the ALGORITHMIC work of one launch."""
     from frackyfrac_amd._lib import KERNEL_NAMES
 
@@ -306,6 +306,16 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
                                "reduced by pair_low_kernel over the pairs that both have them, so fewer lane-ops are issued than "
                                "counted: the fraction may pass 1 (the matrix part alone runs at 0.87-0.89 of the peak on its own rows: "
                                "profiles/r05_*_kernel_stats.csv)" % (int(info.rare_rows), int(info.n_rows)))
+        if rare_ms and 0 < rare_ms < kernel_ms:
+            # each kernel on its own rows, from the event the plan records between the two launches
+            # (ff_plan_timing_collect_parts): the matrix rows' kernel against the vector ALU's peak for ITS 2 lane-ops per
+            # row and pair; the rare rows' kernel has no such count (its work is the pairs that both have a row)
+            matrix_rows = int(info.n_rows) - int(info.rare_rows)
+            matrix_ms = kernel_ms - rare_ms
+            common["parts"] = [
+                {"kernel": kname, "rows": matrix_rows, "ms": matrix_ms,
+                 "frac": 2.0 * matrix_rows * shard_pairs / (matrix_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS},
+                {"kernel": "pair_low_kernel", "rows": int(info.rare_rows), "ms": rare_ms}]
     # the binding floor of THIS launch (one rank's shard): its algorithmic work (2*B per pair) at the unit's peak
     peak_ops = {2: MFMA_I8_PEAK_TOPS, 4: MFMA_I8_PEAK_TOPS, 1: VALU_PEAK_TLANEOPS / 2, 7: VALU_PEAK_TLANEOPS / 2,
                 5: VALU_PEAK_TLANEOPS / 2}.get(kernel, VALU_PEAK_TLANEOPS) * 1e12
@@ -481,7 +491,7 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
         res = run.step(timed=(k % event_every == 0))
     barrier(ctx)
     elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = run.timing_collect()
+    kernel_ms_total, rare_ms_total, launches = run.timing_collect_parts()
     per_rank = None
     if ctx.world > 1:
         # what a post-mortem of the first multi-GPU run needs, from every rank: its own clock around the
@@ -527,7 +537,8 @@ def measure(ctx, cfg, nodes, weighted, precision, steps, warmup, event_every=1):
                                          # (the counters in profiles/traffic.json are the generator-length runs', except
                                          # the exact unweighted kernel's, whose traffic does not depend on the lengths)
                                          None if cfg.get("lengths") == "lognormal" and int(info.kernel) != 5
-                                         else traffic_of(cfg["name"], ctx.world, info, weighted))}
+                                         else traffic_of(cfg["name"], ctx.world, info, weighted),
+                                         rare_ms=rare_ms_total / max(launches, 1))}
         entry["_active_fraction"] = float(info.active_fraction)
         entry["roofline"]["rows_staged"] = int(info.n_rows)   # branches some sample reaches (compaction) of B
         entry["roofline"]["timed_every"] = event_every  # the event pair brackets every n-th launch of the timed region

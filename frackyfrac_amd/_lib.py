@@ -83,6 +83,7 @@ SIGNATURES = {
     "ff_plan_run": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_plan_run_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_char_p, c_size_t]),
     "ff_plan_timing_collect": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int32)]),
+    "ff_plan_timing_collect_parts": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_int32)]),
     "ff_plan_refined_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "ff_plan_audit": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),
     "ff_plan_audit_detail": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_double)]),

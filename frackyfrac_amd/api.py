@@ -459,6 +459,15 @@ class Plan:
             raise FFError(rc, "ff_plan_timing_collect failed")
         return ms.value, n.value
 
+    def timing_collect_parts(self) -> Tuple[float, float, int]:
+        """(summed ms of the pair reduction, of which the rare rows' kernel, launches) over the timed runs since the
+        last call (ff_plan_timing_collect_parts); synchronises on their events."""
+        ms, rare, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+        rc = L.lib().ff_plan_timing_collect_parts(self._h, ctypes.byref(ms), ctypes.byref(rare), ctypes.byref(n))
+        if rc:
+            raise FFError(rc, "ff_plan_timing_collect_parts failed")
+        return ms.value, rare.value, n.value
+
 
     def refined_pairs(self) -> Tuple[int, int]:
         """(pairs the last completed run re-computed exactly, queue capacity)."""

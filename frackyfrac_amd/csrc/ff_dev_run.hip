@@ -514,16 +514,18 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
     if (!d_out) return ff::fail(FF_ERR_ARG, err, errlen, "null output pointer");
     DeviceScope scope;  // (the caller's current device is its own again when this returns: a host that drives several
     FF_HIP(scope.enter(pl->device));  // plans on several devices from one thread does not find it changed under it)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
     if (timed) {
         if (pl->events_used == pl->events.size()) {
-            hipEvent_t a, b;
+            hipEvent_t a, b, m;
             FF_HIP(hipEventCreate(&a));
             FF_HIP(hipEventCreate(&b));
-            pl->events.push_back({a, b});
+            FF_HIP(hipEventCreate(&m));
+            pl->events.push_back({a, b, m});
         }
         ev0 = pl->events[pl->events_used].first;
         ev1 = pl->events[pl->events_used].second;
+        ev_mid = pl->events[pl->events_used].mid;
         ++pl->events_used;
     }
     if (pl->walk) {
@@ -617,6 +619,7 @@ int plan_run_impl(ff_plan *pl, hipStream_t st, double *d_out, bool timed, char *
                 pl->d_QT, inf.ld, pl->d_items, pl->d_item_ptr, pl->d_num, pl->plane_stride, inf.row_begin, inf.row_end,
                 inf.slot_begin, pl->d_stamps, SYNC_TRIPS);
         if (pl->split && pl->n_low_tiles > 0) {  // (inside the timed region: it is part of the pair reduction)
+            if (timed) FF_HIP(hipEventRecord(ev_mid, st));
             static_assert(sizeof(LOW_TILES) / sizeof(int) == 5, "one instance of pair_low_kernel per block side");
             auto low = pl->low_tile == 128 ? pair_low_kernel<128> : pl->low_tile == 112 ? pair_low_kernel<112> :
                        pl->low_tile == 96 ? pair_low_kernel<96> : pl->low_tile == 80 ? pair_low_kernel<80> : pair_low_kernel<64>;

@@ -577,8 +577,7 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             std::vector<int32_t> h_cnt((size_t)R);
             FF_HIP(hipMemcpy(h_cnt.data(), cnt.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
             // (priced for THIS plan's shard: its pairs, and its blocks of pairs -- a row shard of a multi-GPU run holds a
-            // G-th of the blocks, and how they fill their rounds decides the block side: C5 over 8 ranks, 260 blocks of
-            // 128 x 128 on 512 slots against 467 of 96 x 96)
+            // G-th of the blocks, and how they fill their rounds weighs on the block side: profiles/r05_shard_balance.txt)
             const double Ps = std::max(1.0, (double)n_slots);
             constexpr double ROW_RATE = 33e12, STEP_COST = 0.13e-10, ROUND_STEPS = 4, WORD_STEPS = 8, ZERO_STEPS = 5;
             const double t_row = Ps / ROW_RATE;
@@ -653,11 +652,10 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
             const bool take = R - n_low >= 16 && n_low > 0 && fits && (force > 0 || t_split <= 0.93 * t_now);
             if (take) {
                 std::vector<int32_t> h_qt((size_t)B, -1), h_low((size_t)B, -1);
-                // The matrix rows keep the staged order.  The rare rows are numbered by DESCENDING sample count: a thread
-                // of pair_low_kernel walks the 64 rows of a bitmap word, the lanes of a wave neighbouring words, and a
-                // wave's loops run as long as its busiest lane's -- rows of like weight side by side keep the lanes in
-                // step (in branch order a wave ran 13 times the iterations its average lane needed).  Integer sums: any
-                // numbering gives the same M.
+                // The matrix rows keep the staged order.  The rare rows are numbered by DESCENDING sample count: the 64
+                // rows of a bitmap word are worked together by a wave of pair_low_kernel, a round of it lasts as long as the
+                // longest list among the rows it holds, and rows of like weight side by side keep those alike (in branch
+                // order the round's longest list was 13 times its average one).  Integer sums: any numbering gives the same M.
                 Rq = 0;
                 std::vector<int64_t> rare;
                 for (int64_t r = 0; r < R; ++r) {

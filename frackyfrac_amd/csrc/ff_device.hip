@@ -129,6 +129,7 @@ void plan_free_device(ff_plan *pl)
     for (auto &e : pl->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
+        (void)hipEventDestroy(e.mid);
     }
 }
 
@@ -377,23 +378,33 @@ int ff_debug_read_stamps(ff_plan *pl, unsigned long long *out)
     return FF_OK;
 }
 
-int ff_plan_timing_collect(ff_plan *pl, double *total_ms, int32_t *launches)
+int ff_plan_timing_collect_parts(ff_plan *pl, double *total_ms, double *rare_ms, int32_t *launches)
 {
-    if (!pl || !total_ms || !launches) return FF_ERR_ARG;
-    double sum = 0;
+    if (!pl || !total_ms || !rare_ms || !launches) return FF_ERR_ARG;
+    double sum = 0, rare = 0;
     int32_t n = 0;
+    const bool parts = pl->split && pl->n_low_tiles > 0;  // (the runs since the last collect are all of this shard's schedule)
     for (size_t k = 0; k < pl->events_used; ++k) {
-        float ms = 0.f;
+        float ms = 0.f, low = 0.f;
         if (hipEventSynchronize(pl->events[k].second) != hipSuccess ||
             hipEventElapsedTime(&ms, pl->events[k].first, pl->events[k].second) != hipSuccess)
             return FF_ERR_DEVICE;
+        if (parts && hipEventElapsedTime(&low, pl->events[k].mid, pl->events[k].second) != hipSuccess) return FF_ERR_DEVICE;
         sum += (double)ms;
+        rare += (double)low;
         ++n;
     }
     pl->events_used = 0;
     *total_ms = sum;
+    *rare_ms = rare;
     *launches = n;
     return FF_OK;
+}
+
+int ff_plan_timing_collect(ff_plan *pl, double *total_ms, int32_t *launches)
+{
+    double rare = 0;
+    return ff_plan_timing_collect_parts(pl, total_ms, &rare, launches);
 }
 
 int ff_unifrac_dists(const ff_problem *p, const ff_options *o, double *out, char *err, size_t errlen)

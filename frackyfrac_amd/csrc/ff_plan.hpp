@@ -115,8 +115,10 @@ struct ff_plan {
     int xu_slabs = 0;
     ff::sched::XUTile *d_xutiles = nullptr;
     int n_xutiles = 0;
-    // timing: one event pair per timed run since the last collect
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // timing: the events of every timed run since the last collect -- around the pair reduction, and between the matrix
+    // rows' kernel and the rare rows' (recorded only where the plan is split: `split` says which)
+    struct TimedRun { hipEvent_t first, second, mid; };
+    std::vector<TimedRun> events;
     size_t events_used = 0;
 };
 

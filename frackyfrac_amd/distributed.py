@@ -522,12 +522,18 @@ class ShardedRun:
                                      self.root, self.full, self.group)
 
     def timing_collect(self):
-        ms = n = 0
+        ms, _, n = self.timing_collect_parts()
+        return ms, n
+
+    def timing_collect_parts(self):
+        """(ms of the pair reduction, of which the rare rows' kernel, launches) summed over the sub-shard plans."""
+        ms = rare = n = 0
         for p in self.plans:
-            a, b = p.timing_collect()
+            a, r, b = p.timing_collect_parts()
             ms += a
+            rare += r
             n += b
-        return ms, n // max(1, len(self.plans))
+        return ms, rare, n // max(1, len(self.plans))
 
     def _drop_mapping(self):
         if getattr(self, "remote", None) is not None:

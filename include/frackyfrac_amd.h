@@ -290,6 +290,9 @@ int ff_plan_run_host(ff_plan *plan, double *out, char *err, size_t errlen);
  */
 int ff_plan_run_timed(ff_plan *plan, void *stream, double *d_out, char *err, size_t errlen);
 int ff_plan_timing_collect(ff_plan *plan, double *total_ms, int32_t *launches);
+/* The same with the share of the rare rows' kernel (pair_low_kernel, ff_plan_info.rare_rows > 0: the rest of total_ms is
+ * the matrix rows' kernel; 0 where the plan is not split) -- so that a benchmark can price each kernel on its own rows. */
+int ff_plan_timing_collect_parts(ff_plan *plan, double *total_ms, double *rare_ms, int32_t *launches);
 
 /*
  * FIXED32 re-computes the few pairs whose integer sum is too small for the 1e-6
