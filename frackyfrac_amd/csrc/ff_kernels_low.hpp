@@ -13,18 +13,20 @@
 // block-major (ptr[k][r] .. ptr[k][r + 1]: row r's entries of block k, contiguous and ascending with r within the
 // block); an entry is (x: the byte offset of its sample's accumulator row, li * LOW_STRIDE * 4; y: the staged value), so
 // that an update's LDS address is A.x | B.x >> LOW_COL_SHIFT.  A bitmap per block says which rows have any entry.
-// A WAVE takes a word of bits[bi] & bits[bj] at a time: lane l looks up row 64 w + l -- its A entries of block bi, its
-// B entries of block bj, A x B updates -- the B list lengths are scanned across the wave, and the wave works through the
-// word's B ENTRIES 64 at a time: a lane finds its (row, B entry) by a binary search over the scanned lengths, loads the
-// entry, and walks the row's A entries four loads ahead -- 29 instructions per four steps, no branch (past the row's end
-// the add is of zero); the next 64's operands are fetched while these are worked.  Whatever the rows' weights every lane
-// has an entry, and a round lasts as long as the longest A list among its rows.
+// A WAVE takes the rows of a word of bits[bi] & bits[bj] at a time (or, where the words are sparse, 64 rows compacted
+// from up to 64 of its words: below): lane l looks up its row -- the row's A entries of block bi, its B entries of block
+// bj, A x B updates -- the B list lengths are scanned across the wave, and the wave works through the rows' B ENTRIES 64
+// at a time: a lane finds its (row, B entry) by a binary search over the scanned lengths, loads the entry, and walks the
+// row's A entries four loads ahead -- 29 instructions per four steps, no branch (past the row's end the add is of zero);
+// the next 64's operands are fetched while these are worked.  Whatever the rows' weights every lane has an entry, and a
+// round lasts as long as the longest A list among its rows.
 // (History, measured at C3 / 1 % density: a thread per word with nested loops ran as long as the busiest lane of every
 // step, 63 ms at 1 %; lanes dealt to the word's UPDATES (row, a, b) by search, 61 instructions per 64: 4.6 ms at C3;
 // heavy rows one by one on scalar operands 4.30; by groups of G lanes, G a power of two, a row per group, one load per
 // step 4.46 -- the load's latency in every step; four loads ahead 3.72; the address as one OR, the tail by adding zero
 // instead of branching, the diagonal case compiled apart: 3.23; a round fetched ahead, block sides 112 and 80: 2.99;
-// lanes dealt to the B entries without gaps -- this -- 2.65, and the search over updates, slower at every density, went.)
+// lanes dealt to the B entries without gaps -- this -- 2.65, and the search over updates, slower at every density, went.
+// Sparse words compacted 64 rows at a time: nothing at C3, the kernel at 0.2 % / 0.05 % leaf density 2.14 -> 1.66 / 1.13 -> 0.74 ms.)
 // Every slot of the tile is then written once (zeros included): no memset, no global atomics.
 struct __attribute__((aligned(8))) LowQuad { uint2 e[4]; };
 // One B entry (this lane's) against a row's A entries, four in flight at a time; past the row's end the loads bring other
@@ -66,16 +68,68 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
     const bool diagonal = bi == bj;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int64_t w = wave; w < words; w += LOW_THREADS / 64) {
-        const unsigned long long c = wi[w] & wj[w];  // (uniform: one word per wave)
-        if (c == 0) continue;
+    // The wave's words are wave, wave + 16, wave + 32 .. (the rows are numbered by weight: every wave gets its share of the
+    // heavy ones); it looks at 64 of them at a time, a word per lane, and counts the rows each has in both sample blocks.
+    //   Dense words (32 rows or more on average): word by word, lane l looks up row l of the word.
+    //   Sparse ones (a table at 0.2 % density: 3 rows of 64): the 64 words' rows are compacted -- the k-th of them found by a
+    //   search over the scanned counts, then the k-th set bit of that word -- and looked up 64 at a time, so that the look-
+    //   ups, the scan and the search below are paid per 64 ROWS, not per word.
+    constexpr int WAVES = LOW_THREADS / 64;
+    for (int64_t chunk = 0; wave + WAVES * 64 * chunk < words; ++chunk) {
+        const int64_t my_word = wave + WAVES * (64 * chunk + lane);
+        const unsigned long long cw = my_word < words ? wi[my_word] & wj[my_word] : 0ull;
+        const uint32_t pc = (uint32_t)__builtin_popcountll(cw);
+        uint32_t incl_pc = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl_pc, d, 64);
+            if (lane >= d) incl_pc += up;
+        }
+        const uint32_t rows_here = (uint32_t)__builtin_amdgcn_readlane((int)incl_pc, 63);  // (a scalar: what follows is uniform)
+        if (rows_here == 0) continue;
+        const int64_t words_left = (words - wave - WAVES * 64 * chunk + WAVES - 1) / WAVES;  // of this wave, from this chunk on
+        const uint32_t n_words = (uint32_t)(words_left < 64 ? words_left : 64);
+        const bool dense = rows_here >= 32u * n_words;                                   // (uniform)
+        const uint32_t trips = dense ? n_words : (rows_here + 63u) / 64u;
+        for (uint32_t trip = 0; trip < trips; ++trip) {
         uint32_t a0 = 0, na = 0, b0 = 0, nbb = 0;
-        if ((c >> lane) & 1ull) {
-            const int64_t r = w * 64 + lane;
-            a0 = pi[r];
-            na = pi[r + 1] - a0;
-            b0 = pj[r];
-            nbb = pj[r + 1] - b0;
+        {
+            int64_t r = -1;
+            if (dense) {
+                const unsigned long long c = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cw, (int)trip) |
+                                             (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cw >> 32), (int)trip) << 32;
+                if (c == 0) continue;  // (uniform)
+                if ((c >> lane) & 1ull) r = (wave + WAVES * (64 * chunk + (int64_t)trip)) * 64 + lane;
+            } else {
+                const uint32_t k = trip * 64u + (uint32_t)lane;
+                int L = 0;  // the lane whose word holds the chunk's k-th row: the number of lanes with incl_pc <= k
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const uint32_t v = __shfl(incl_pc, L + step - 1, 64);
+                    if (v <= k) L += step;
+                }
+                L = min(L, 63);
+                uint32_t j = k - __shfl(incl_pc - pc, L, 64);  // which of that word's rows
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)cw, L, 64), hi = (uint32_t)__shfl((int)(uint32_t)(cw >> 32), L, 64);
+                if (k < rows_here) {
+                    // the j-th set bit of the word: halve the span six times
+                    uint32_t x = lo, pos = 0;
+                    const uint32_t in_lo = (uint32_t)__builtin_popcount(lo);
+                    if (j >= in_lo) { j -= in_lo; x = hi; pos = 32; }
+#pragma unroll
+                    for (int width = 16; width >= 1; width >>= 1) {
+                        const uint32_t below = (uint32_t)__builtin_popcount(x & ((1u << width) - 1u));
+                        if (j >= below) { j -= below; x >>= width; pos += width; }
+                    }
+                    r = (wave + WAVES * (64 * chunk + (int64_t)L)) * 64 + pos;
+                }
+            }
+            if (r >= 0) {
+                a0 = pi[r];
+                na = pi[r + 1] - a0;
+                b0 = pj[r];
+                nbb = pj[r + 1] - b0;
+            }
         }
         // The lanes are dealt to the word's B entries, row after row without gaps (lane -> (row, entry) by a binary
         // search over the scanned list lengths), 64 at a time, and every lane walks its row's A entries: no lane idles
@@ -87,7 +141,7 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
             const uint32_t up = __shfl_up(inclb, d, 64);
             if (lane >= d) inclb += up;
         }
-        const uint32_t totalb = __shfl(inclb, 63, 64);
+        const uint32_t totalb = (uint32_t)__builtin_amdgcn_readlane((int)inclb, 63);  // (a scalar: the rounds' loop is uniform)
         const uint32_t b_at = b0 - (inclb - nbb);  // + k: the place of the word's k-th B entry, for k in this lane's row (mod 2^32)
         // (a round's operands -- the search, three shuffles, the lane's B entry -- are fetched while the round before is
         // worked)
@@ -118,6 +172,7 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
             }
             cur = nxt;
         }
+        }  // (trip)
     }
     __syncthreads();
     // the tile's slots: row i = i_base + li holds columns j_base .. of slot i (i - 1) / 2 + j -- contiguous in j
