@@ -647,8 +647,13 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                     n_low = nl;
                 }
             }
-            // (the index is (rare rows + 1) x sample blocks words, twice while it is built: not beyond 4 GB)
-            const bool fits = 8.0 * (double)(n_low + 1) * (double)((N + std::max(tile, 1) - 1) / std::max(tile, 1)) <= 4e9;
+            // (the index is (rare rows + 1) x sample blocks words, twice while it is built: not beyond 4 GB; and it counts
+            // the rare rows' entries -- their flat nodes -- in 32 bits)
+            double rare_entries = 0;
+            for (int64_t r = 0; r < R; ++r)
+                if ((double)h_cnt[(size_t)r] <= rare_max) rare_entries += (double)h_cnt[(size_t)r];
+            const bool fits = 8.0 * (double)(n_low + 1) * (double)((N + std::max(tile, 1) - 1) / std::max(tile, 1)) <= 4e9 &&
+                              rare_entries < 4.0e9;
             const bool take = R - n_low >= 16 && n_low > 0 && fits && (force > 0 || t_split <= 0.93 * t_now);
             if (take) {
                 std::vector<int32_t> h_qt((size_t)B, -1), h_low((size_t)B, -1);
