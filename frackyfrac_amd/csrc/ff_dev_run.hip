@@ -82,8 +82,13 @@ int schedule_sad(ff_plan *pl, char *err, size_t errlen)
     //     5.00-5.13 / 5.04-5.26).  Round 3's rule gave the first rank alone the 12-wave kernel whatever the shard's
     //     size, and said otherwise in this comment.
     pl->waves_per_wg = pl->sparse ? WAVES_PER_WG : waves_per_wg();
+    // The first rule holds from 8,000 matrix rows up only: with the rare rows out of the matrix (round 5) a tile has a
+    // quarter of the rows to sweep between loading its columns and writing its sums, and the 8-wave kernel with its
+    // full prefetch does that better (matrix rows' kernel, ms, 12 / 8 waves: C3 with 4,968 rows 1.306 / 1.260, 6,000
+    // samples with 4,679 rows 2.76 / 2.69, C5's tree at 1 % / 0.2 % density with 2,438 / 528 rows 2.64 / 2.42 and 0.77 /
+    // 0.58; C5 with 12,462 rows 12.17 / 12.51; C4 -- the second rule -- 16.5 / 17.0).
     if (!pl->sparse && !ff::tuning("FF_WAVES_PER_WG").has_value() &&
-        ((inf.row_begin == 0 && inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 11) ||
+        ((inf.row_begin == 0 && inf.n_tiles * 4 >= (int64_t)pl->n_workgroups * 11 && rows >= 8000) ||
          (double)inf.n_tiles * (double)rows >= 200000.0 * (double)pl->n_workgroups))
         pl->waves_per_wg = L_WAVES_PER_WG;
     pl->lds_bytes = 96 * 1024;  // unused dynamic LDS sized so that exactly one workgroup fits a CU

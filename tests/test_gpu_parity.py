@@ -1143,19 +1143,27 @@ def test_three_waves_per_simd_kernel_gives_the_same_integers(monkeypatch):
 
 
 def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
-    """A shard that begins at row 0 and holds 2.75 pair tiles per workgroup or more (3,300 samples up on 256 CUs)
-    is scheduled on the 12-wave kernel without any switch being set, and so is any shard of 200,000 (tile, branch row)
-    units per workgroup or more; a smaller one, and a later row shard under that size (the ranks of a multi-GPU run on
-    C3's pairs each), on the 8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same
-    distances.  (What each rank of the BASELINE configs takes: test_kernel_choice_per_rank_of_the_baseline_configs.)"""
+    """A shard that begins at row 0, holds 2.75 pair tiles per workgroup or more (3,300 samples up on 256 CUs) AND has
+    8,000 matrix rows or more is scheduled on the 12-wave kernel without any switch being set, and so is any shard of
+    200,000 (tile, branch row) units per workgroup or more; a smaller one, one with fewer matrix rows (what the rare-row
+    split leaves of C3), and a later row shard under that size (the ranks of a multi-GPU run on C3's pairs each), on the
+    8-wave kernel; the choice is bit-neutral: forcing the 8-wave kernel gives the same distances.  (What each rank of
+    the BASELINE configs takes: test_kernel_choice_per_rank_of_the_baseline_configs.)"""
+    monkeypatch.setenv("FF_SPARSE_SPLIT", "0")   # (every row in the matrix: the rule is about its rows)
     small, *_ = synth_problem(2048, 150, 0.2, 79)
     plan = ff.Plan(small, True, precision="fixed32")
     assert plan.info.n_tiles * 4 < 11 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
     plan.close()
-    nodes, ip, on, ft = synth_problem(10240, 150, 0.2, 78)
+    few_rows, *_ = synth_problem(10240, 150, 0.2, 78)   # many tiles, 299 rows
+    plan = ff.Plan(few_rows, True, precision="fixed32")
+    assert plan.info.n_tiles >= 24 * plan.info.n_compute_units and plan.info.n_wave_slots == 8 * plan.info.n_compute_units
+    plan.close()
+    n = 3584
+    nodes, ip, on, ft = synth_problem(n, 4500, 0.2, 78)
     plan = ff.Plan(nodes, True, precision="fixed32")
     cus = plan.info.n_compute_units
-    assert plan.info.n_tiles >= 24 * cus and plan.info.n_wave_slots == 12 * cus and plan.info.kernel == 0
+    assert plan.info.n_tiles * 4 >= 11 * cus and plan.info.n_rows >= 8000
+    assert plan.info.n_wave_slots == 12 * cus and plan.info.kernel == 0
     got = plan.run_host()
     plan.close()
     monkeypatch.setenv("FF_WAVES_PER_WG", "8")
@@ -1166,7 +1174,7 @@ def test_many_tile_shards_take_the_three_wave_kernel_by_themselves(monkeypatch):
     assert np.array_equal(got, want)
     monkeypatch.delenv("FF_WAVES_PER_WG")
     plan = ff.Plan(nodes, True, precision="fixed32", rank=1, world=2)   # a later row shard: the 8-wave kernel
-    a, b = ff.shard_slots(10240, 1, 2)
+    a, b = ff.shard_slots(n, 1, 2)
     assert plan.info.row_begin > 0 and plan.info.n_wave_slots == 8 * cus and np.array_equal(plan.run_host(), got[a:b])
     plan.close()
     # a sample of pairs against the oracle
