@@ -900,7 +900,7 @@ def test_sparse_aware_kernel(monkeypatch):
 @pytest.mark.parametrize("tile", ["128", "112", "96", "80", "64"])
 def test_sparse_split_on_clustered_samples(monkeypatch, tile):
     """Samples are not independent draws in a real table: a clade may live in one run of consecutive samples and nowhere
-    else.  Its rows are rare by count (a quarter of the samples or fewer) while a sample block holds them in EVERY
+    else.  Its rows are rare by count (far under half of the samples) while a sample block holds them in EVERY
     sample: pair_low_kernel's widest groups (64 lanes), second and third trips over B lists longer than the group, the
     diagonal blocks with A = B = the whole block, rows whose entries all sit in one or two blocks.  1,100 samples, 9
     runs of 128 / 256 consecutive samples owning a slice of the leaves each (all of it, or every other leaf), a thin
