@@ -304,7 +304,7 @@ def roofline_of(info, B, n_samples, shard_pairs, kernel_ms, launches, weighted, 
         common["rare_rows"] = int(info.rare_rows)
         common["frac_note"] = ("priced on ALL 2*B lane-ops per pair (SURVEY 8d); %d of the %d staged rows are kept out of the matrix and "
                                "reduced by pair_low_kernel over the pairs that both have them, so fewer lane-ops are issued than "
-                               "counted: the fraction may pass 1 (the matrix part alone runs at 0.87-0.89 of the peak on its own rows: "
+                               "counted: the fraction may pass 1 (each kernel on its own rows: `parts`, from an event between the two launches; "
                                "profiles/r05_*_kernel_stats.csv)" % (int(info.rare_rows), int(info.n_rows)))
         if rare_ms and 0 < rare_ms < kernel_ms:
             # each kernel on its own rows, from the event the plan records between the two launches
