@@ -68,15 +68,20 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
     const bool diagonal = bi == bj;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // The wave's words are wave, wave + 16, wave + 32 .. (the rows are numbered by weight: every wave gets its share of the
-    // heavy ones); it looks at 64 of them at a time, a word per lane, and counts the rows each has in both sample blocks.
+    // The wave's words are one of every 16 (the rows are numbered by weight: every wave gets its share of the heavy ones);
+    // it looks at 64 of them at a time, a word per lane, and counts the rows each has in both sample blocks.
     //   Dense words (32 rows or more on average): word by word, lane l looks up row l of the word.
     //   Sparse ones (a table at 0.2 % density: 3 rows of 64): the 64 words' rows are compacted -- the k-th of them found by a
     //   search over the scanned counts, then the k-th set bit of that word -- and looked up 64 at a time, so that the look-
     //   ups, the scan and the search below are paid per 64 ROWS, not per word.
     constexpr int WAVES = LOW_THREADS / 64;
-    for (int64_t chunk = 0; wave + WAVES * 64 * chunk < words; ++chunk) {
-        const int64_t my_word = wave + WAVES * (64 * chunk + lane);
+    // (boustrophedon: the g-th group of 16 words goes to the waves in ascending order for even g, descending for odd -- the
+    // words' weights fall with their index, and wave 0 would get the heaviest word of every group)
+    auto word_of = [&](int64_t g) { return WAVES * g + ((g & 1) ? WAVES - 1 - wave : wave); };
+    for (int64_t chunk = 0;; ++chunk) {
+        const int64_t my_word = word_of(64 * chunk + lane);
+        const uint32_t n_words = (uint32_t)__builtin_popcountll(__ballot(my_word < words));  // (a prefix of the lanes)
+        if (n_words == 0) break;
         const unsigned long long cw = my_word < words ? wi[my_word] & wj[my_word] : 0ull;
         const uint32_t pc = (uint32_t)__builtin_popcountll(cw);
         uint32_t incl_pc = pc;
@@ -87,8 +92,6 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
         }
         const uint32_t rows_here = (uint32_t)__builtin_amdgcn_readlane((int)incl_pc, 63);  // (a scalar: what follows is uniform)
         if (rows_here == 0) continue;
-        const int64_t words_left = (words - wave - WAVES * 64 * chunk + WAVES - 1) / WAVES;  // of this wave, from this chunk on
-        const uint32_t n_words = (uint32_t)(words_left < 64 ? words_left : 64);
         const bool dense = rows_here >= 32u * n_words;                                   // (uniform)
         const uint32_t trips = dense ? n_words : (rows_here + 63u) / 64u;
         for (uint32_t trip = 0; trip < trips; ++trip) {
@@ -99,7 +102,7 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
                 const unsigned long long c = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cw, (int)trip) |
                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cw >> 32), (int)trip) << 32;
                 if (c == 0) continue;  // (uniform)
-                if ((c >> lane) & 1ull) r = (wave + WAVES * (64 * chunk + (int64_t)trip)) * 64 + lane;
+                if ((c >> lane) & 1ull) r = word_of(64 * chunk + (int64_t)trip) * 64 + lane;
             } else {
                 const uint32_t k = trip * 64u + (uint32_t)lane;
                 int L = 0;  // the lane whose word holds the chunk's k-th row: the number of lanes with incl_pc <= k
@@ -121,7 +124,7 @@ void pair_low_kernel(const uint32_t *__restrict__ ptr, const uint2 *__restrict__
                         const uint32_t below = (uint32_t)__builtin_popcount(x & ((1u << width) - 1u));
                         if (j >= below) { j -= below; x >>= width; pos += width; }
                     }
-                    r = (wave + WAVES * (64 * chunk + (int64_t)L)) * 64 + pos;
+                    r = word_of(64 * chunk + (int64_t)L) * 64 + pos;
                 }
             }
             if (r >= 0) {
