@@ -50,7 +50,7 @@ class ff_plan_info(ctypes.Structure):
                 ("staged_bytes", c_double), ("elements", c_double), ("kernel", c_int32), ("n_digits", c_int32),
                 ("n_rows", c_int64), ("n_sweeps", c_int32), ("planes_per_sweep", c_int32),
                 ("rows_three_planes", c_int64), ("audit_checked", c_int64), ("audit_failed", c_int64),
-                ("audit_worst_rel_err", c_double), ("audit_min_headroom", c_double), ("active_fraction", c_double), ("rare_rows", c_int64)]
+                ("audit_worst_rel_err", c_double), ("audit_min_headroom", c_double), ("active_fraction", c_double), ("rare_rows", c_int64), ("rare_updates", c_double)]
 
 # ff_dists_fn: int (*)(void *user, int64_t slot_begin, const double *dists, int64_t n)
 DISTS_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int64, POINTER(c_double), c_int64)

@@ -678,6 +678,9 @@ int stage_for_sad(StageCtx &x, char *err, size_t errlen)
                 pl->low_tile = tile;
                 pl->low_rows = Rl;
                 inf.rare_rows = Rl;
+                double upd = 0;  // (the kernel's own work: bench.py's roofline.parts prices it)
+                for (int64_t r : rare) upd += 0.5 * (double)h_cnt[(size_t)r] * (double)(h_cnt[(size_t)r] - 1);
+                inf.rare_updates = upd * Ps / std::max(1.0, 0.5 * (double)N * (double)(N - 1));
             }
         }
     }

@@ -225,6 +225,9 @@ typedef struct ff_plan_info {
                                   the rest) and what decides between it and the dense kernel; 1 where not counted */
     int64_t rare_rows;         /* FIXED32 weighted on a sparse table: staged rows kept OUT of the matrix (few samples
                                   reach them) and reduced by pair_low_kernel over the pairs that both have them; 0: none */
+    double rare_updates;       /* pair_low_kernel's own work per pass: the sum over the rare rows of n_r (n_r - 1) / 2, n_r =
+                                  the samples with a flat node on the row (an update = one min + one LDS add).
+                                  A row shard's plan: the whole triangle's count times the shard's share of the pairs */
 } ff_plan_info;
 
 typedef enum ff_kernel {

@@ -37,7 +37,7 @@ def test_struct_layouts(tmp_path):
     import ctypes
     assert ctypes.sizeof(L.ff_problem) == 48
     assert ctypes.sizeof(L.ff_options) == 32
-    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8 + 8 + 8 + 8 + 4 * 8 + 8 + 8   # (+ the audit's four fields, + active_fraction, + rare_rows)
+    assert ctypes.sizeof(L.ff_plan_info) == 16 + 11 * 8 + 16 + 8 + 8 + 8 + 8 + 4 * 8 + 8 + 8 + 8   # (+ the audit's four fields, + active_fraction, + rare_rows, + rare_updates)
     # the same from the header itself, as a C compiler lays it out (sizes and the offsets of the last fields)
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "frackyfrac_amd.h"\n'

@@ -69,6 +69,9 @@ def test_single_gpu_line_carries_the_secondary_entries():
     assert matrix["rows"] + rare["rows"] == r["rows_staged"] and rare["rows"] == r["rare_rows"]
     assert 0.5 < matrix["frac"] < 1.0 and 0 < rare["ms"] < r["kernel_ms_between_events"]
     assert abs(matrix["ms"] + rare["ms"] - r["kernel_ms"]) <= 1e-6 * r["kernel_ms"]
+    # (the rare rows' kernel on its own work: updates of an LDS accumulator against the rate the LDS takes ds_add_u32 at)
+    assert rare["bound"] == "lds" and 1e9 < rare["updates"] < 1e10 and 0.05 < rare["frac"] < 1.0
+    assert abs(rare["achieved"] * 1e12 * rare["ms"] * 1e-3 - rare["updates"]) <= 1e-6 * rare["updates"]
     a = out["audit"]
     assert a["uniform_sample"] == 4096 and a["pairs"] == 4096 + a["risk_pairs_checked"] and a["failed"] == 0
     assert a["min_headroom"] is None or a["min_headroom"] >= 1.0   # (everything under 1 is re-computed exactly)
@@ -115,6 +118,7 @@ def test_single_gpu_line_carries_the_secondary_entries():
         assert "error" not in e, e
         assert e["outputs_identical"] and e["lines_ok"], e
         assert [r["flags"] for r in e["runs"]] == ["(default)", "-p 1", "-p %d" % cb["cores"]]
+        assert e["cold_start"]["rc"] == 0 and e["cold_start"]["wall_s"] > 0   # (the command's first run on the box, apart)
         for r in e["runs"]:
             assert r["rc"] == 0 and r["lines"] == e["pairs"] and r["precision"] == "fixed32"
             assert set(r["seconds"]) == {"tree", "load", "validate", "open", "convert", "distances", "write", "close"}

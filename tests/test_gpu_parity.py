@@ -938,6 +938,10 @@ def test_sparse_split_on_clustered_samples(monkeypatch, tile):
         monkeypatch.setenv("FF_LOW_TILE", tile)
         plan = ff.Plan(nodes, True, precision="fixed32")
         assert (plan.info.rare_rows > 100) == (flag == "1")
+        # (the rare rows' kernel's own work, an update per pair of flat nodes on a row: none without the split, and no
+        # more than every staged row's pairs with it)
+        per_row = np.bincount(nodes.branch_id.astype(np.int64)).astype(np.float64)
+        assert (plan.info.rare_updates > 0) == (flag == "1") and plan.info.rare_updates <= (per_row * (per_row - 1) / 2).sum()
         out = torch.empty(plan.n_slots, dtype=torch.float64, device="cuda")
         plan.run(out.data_ptr())
         torch.cuda.synchronize()
