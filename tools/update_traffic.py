@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, note = sys.argv[1], sys.argv[2]
 KEYS = {"c3": "C3_n1_k0", "c3_unweighted": "C3_n1_k2_unweighted", "c3_unweighted_exact": "C3_n1_k5_unweighted",
         "c3_exact64": "C3_n1_k7", "c4": "C4_n1_k0", "c5": "C5_n1_k0",
-        "c5s01": "8192x50000@0.01_n1_k3", "c5s002": "8192x50000@0.002_n1_k3"}
+        "c5s01": "8192x50000@0.01_n1_k0", "c5s002": "8192x50000@0.002_n1_k0"}
 path = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(path))
 for w, key in KEYS.items():
