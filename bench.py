@@ -797,8 +797,9 @@ def main():
     if (rank == 0 and world == 1 and not args.no_secondary and args.workload == "C3" and not args.unweighted and
             args.precision == "fixed32" and args.lengths == "generator"):
         # Where real tables live: BASELINE configs[4]'s tree and sample count at 1 % and 0.2 % leaf density
-        # instead of its 5-10 %.  The engine compacts the branches no sample reaches and walks only the (sample block,
-        # branch) cells with something in them (pair_sad_sparse_kernel); the roofline stays priced on the UNCOMPACTED
+        # instead of its 5-10 %.  The engine compacts the branches no sample reaches, reduces the rows few samples reach
+        # over the pairs that both have them (pair_low_kernel: 97-99 % of the rows here) and keeps the rest
+        # in the matrix (pair_sad_kernel; `parts`); the roofline stays priced on the UNCOMPACTED
         # 2*B lane-ops per pair, so skipping shows as a fraction above the dense kernel's -- and the
         # reference's merge walk costs O(flat nodes), not O(B), there: its rate on the SAME table stands beside it.
         sparse = []
