@@ -61,6 +61,7 @@ VALU_PEAK_TLANEOPS = 78.65        # 157.3 TFLOP/s FP32 vector / 2 flops per lane
 MFMA_I8_PEAK_TOPS = 5000.0        # int8 MFMA issues at 2x the dense bf16 rate (~2.5 PFLOP/s)
 LDS_PEAK_TADDS = 9.83             # ds_add_u32 moves an address and a data dword per lane like ds_write_b32: 4 cycles per
                                   # wave-instruction (same guide, LDS table) = 16 lane-adds per CU and clock x 256 CUs x 2.4 GHz
+                                  # (measured: 15.8 per CU and clock, tools/microbench/lds_add_rate.hip, profiles/r05_lds_add_rate.txt)
 
 
 def log(*a):
