@@ -90,3 +90,22 @@ with open(os.path.join(DIR, "host", "77_counter_collection.csv"), "w") as f:
     assert bench.under_a_profiler()
     monkeypatch.delenv("LD_PRELOAD")
     assert not bench.under_a_profiler()
+
+
+def test_committed_traffic_keys_name_a_kernel_and_an_existing_counter_file():
+    """profiles/traffic.json is looked up by bench.py as <workload>_n<gpus>_k<ff_kernel>[_unweighted] (traffic_of): every
+    key has that shape, its counter file is committed, and the sparse-regime workloads are there under the kernel that
+    runs them since the rare-row split (pair_sad_kernel + pair_low_kernel: ff_kernel 0), not the sparse-aware one."""
+    import json
+    import re
+
+    import bench
+
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    keys = [k for k in t if not k.startswith("_")]
+    assert keys
+    for k in keys:
+        assert re.fullmatch(r".+_n\d+_k\d+(_unweighted)?", k), k
+        assert t[k]["bytes"] > 0 and os.path.exists(os.path.join(ROOT, t[k]["source"])), k
+    for wl in bench.SPARSE_REGIME:
+        assert "%s_n1_k0" % wl in t, wl
